@@ -1,0 +1,32 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def rel_err(a, b):
+    """Tensor-scale relative error max|a-b| / max|b| (hard parts)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    denom = np.max(np.abs(b)) if b.size else 1.0
+    return float(np.max(np.abs(a - b)) / (denom if denom > 0 else 1.0)) if b.size else 0.0
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return {n: load_golden(n + ".npz") for n in ("kernels", "apply", "residuals", "conformal")}

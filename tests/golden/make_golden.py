@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+Run once, here, with /root/reference present:  python tests/golden/make_golden.py
+The GPU box never sees /root/reference; only the .npz files below travel.
+
+What is executed from the reference (nothing of it is copied into this repo):
+  * ``Utils/ConvOps_2d.py`` / ``Utils/ConvOps_1d.py``  - imported; every constructor
+    combination -> kernels.npz; ``D(x)`` on seeded inputs -> apply.npz
+  * ``Other_UQ/Evaluation/PRE_estimations.py``          - imported; PRE_Wave / PRE_NS /
+    PRE_MHD ``.residual`` -> residuals.npz
+  * the residual *function definitions* of ``Marginal/NS_Residuals_CP.py``,
+    ``Marginal/MHD_Residuals_CP.py``, ``Joint/Burgers_Residuals_CP.py`` and the additive
+    kernel assignment of ``Marginal/Advection_Residuals_CP.py``: those scripts cannot be
+    imported (top-level ``from Neural_PDE...``), so the defs are located with ``ast`` at
+    generation time, compiled from the reference file itself and executed against the
+    reference's own ConvOperator instances -> residuals.npz
+  * conformal.npz is BUILD-DEFINED (numpy, oracle/conformal.py): the reference's
+    ``Neural_PDE.UQ.inductive_cp`` is absent, so these vectors pin the oracle to numpy,
+    not to the reference ("parity unpinned").
+"""
+import ast
+import importlib.util
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("MPLBACKEND", "Agg")
+warnings.filterwarnings("ignore")
+sys.path[:0] = [REF, os.path.join(REF, "Utils")]
+
+from Utils.ConvOps_2d import ConvOperator as Ref2D   # noqa: E402
+from Utils.ConvOps_1d import ConvOperator as Ref1D   # noqa: E402
+
+_spec = importlib.util.spec_from_file_location(
+    "PRE_estimations", os.path.join(REF, "Other_UQ/Evaluation/PRE_estimations.py"))
+pre = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(pre)
+
+DOMAINS_2D = ["t", "x", "y", ("x", "y"), ("x", "y", "t"), "z", None]
+DOMAINS_1D = ["t", "x", ("x", "t"), "y", None]
+ORDERS = [0, 1, 2, 3]
+TAYLORS = [2, 4, 6]
+SCALES = [1.0, 0.37]
+
+
+def dom_tag(d):
+    return "none" if d is None else ("".join(d) if isinstance(d, tuple) else d)
+
+
+def gen_kernels():
+    out = {}
+    for tag, cls, doms in (("2d", Ref2D, DOMAINS_2D), ("1d", Ref1D, DOMAINS_1D)):
+        for d in doms:
+            for o in ORDERS:
+                for ty in TAYLORS:
+                    for s in SCALES:
+                        key = f"{tag}|{dom_tag(d)}|{o}|{ty}|{s}"
+                        op = cls(d, o, scale=s, taylor_order=ty)
+                        if hasattr(op, "kernel"):
+                            out[key] = op.kernel.numpy()
+                        else:
+                            out[key] = np.zeros((0,), np.float32)     # "no kernel"
+    np.savez_compressed(os.path.join(HERE, "kernels.npz"), **out)
+    return out
+
+
+def gen_apply(kernels):
+    out = {}
+    torch.manual_seed(0)
+    x4 = {"a": torch.randn(3, 7, 9, 11), "b": torch.randn(1, 1, 16, 16), "c": torch.randn(2, 5, 4, 8)}
+    x3 = {"a": torch.randn(2, 5, 8), "b": torch.randn(3, 1, 12), "c": torch.randn(1, 9, 7)}
+    for k, v in x4.items():
+        out[f"in4|{k}"] = v.numpy()
+    for k, v in x3.items():
+        out[f"in3|{k}"] = v.numpy()
+    for key, kern in kernels.items():
+        if kern.size == 0 or not key.endswith("|1.0"):
+            continue
+        tag = key.split("|")[0]
+        cls, xs = (Ref2D, x4) if tag == "2d" else (Ref1D, x3)
+        op = cls()
+        op.kernel = torch.from_numpy(kern)
+        for name, x in xs.items():
+            out[f"out|{key}|{name}"] = op(x).numpy()
+    # additive composites (README.md:47-54)
+    w = pre.PRE_Wave(dt=0.01, dx=0.02, c=1.0)
+    out["kern|wave"] = w.D.kernel.numpy()
+    for name, x in x4.items():
+        out[f"out|wave|{name}"] = w.D(x).numpy()
+    np.savez_compressed(os.path.join(HERE, "apply.npz"), **out)
+
+
+def ref_defs(relpath, names):
+    """Compile the named top-level function defs straight from a reference script."""
+    path = os.path.join(REF, relpath)
+    tree = ast.parse(open(path).read(), path)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {n.name for n in body} == set(names), (relpath, [n.name for n in body])
+    return compile(ast.Module(body=body, type_ignores=[]), path, "exec")
+
+
+def ref_assign_value(relpath, target_src):
+    """Compile the RHS of the first top-level assignment to ``target_src``."""
+    path = os.path.join(REF, relpath)
+    tree = ast.parse(open(path).read(), path)
+    for n in tree.body:
+        if isinstance(n, ast.Assign) and ast.unparse(n.targets[0]) == target_src:
+            return compile(ast.Expression(n.value), path, "eval")
+    raise KeyError(target_src)
+
+
+def ops2d():
+    return dict(D_t=Ref2D(domain="t", order=1), D_x=Ref2D(domain="x", order=1),
+                D_y=Ref2D(domain="y", order=1), D_xx_yy=Ref2D(domain=("x", "y"), order=2))
+
+
+def gen_residuals():
+    out = {}
+    g = torch.Generator().manual_seed(1)
+    v6 = torch.rand(4, 6, 6, 10, 12, generator=g) + 0.5          # U(0.5,1.5): rho, p > 0
+    u1 = torch.rand(5, 9, 14, generator=g) + 0.5
+    out["vars6"], out["u1d"] = v6.numpy(), u1.numpy()
+    dt, dx, dy = 0.01, 1.0 / 64, 1.0 / 48
+    out["coef"] = np.array([dt, dx, dy], np.float64)
+
+    # packaged classes (imported)
+    for b in (False, True):
+        out[f"PRE_Wave|{int(b)}"] = pre.PRE_Wave(dt=0.01, dx=0.02, c=1.0).residual(v6[:, :1], boundary=b).contiguous().numpy()
+        out[f"PRE_NS|{int(b)}"] = pre.PRE_NS(dt, dx, dy).residual(v6[:, :3], boundary=b).contiguous().numpy()
+        out[f"PRE_MHD|{int(b)}"] = pre.PRE_MHD(dt, dx, dy).residual(v6, boundary=b).contiguous().numpy()
+
+    # script-level defs, compiled from the reference files
+    ns = dict(ops2d(), dx=dx, dy=dy, dt=dt, nu=0.001)
+    exec(ref_defs("Marginal/NS_Residuals_CP.py",
+                  ["residual_continuity", "residual_momentum", "periodic_bc_residual"]), ns)
+    for b in (False, True):
+        out[f"ns_continuity|{int(b)}"] = ns["residual_continuity"](v6[:, :2], boundary=b).contiguous().numpy()
+        out[f"ns_momentum|{int(b)}"] = ns["residual_momentum"](v6[:, :3], boundary=b).contiguous().numpy()
+    for wall in ("top", "bottom", "left", "right"):
+        out[f"ns_periodic_bc|{wall}"] = ns["periodic_bc_residual"](v6[:, 0], wall=wall).contiguous().numpy()
+
+    mhd = dict(ops2d(), gamma=5 / 3)
+    names = ["residual_continuity", "residual_momentum", "residual_energy", "residual_induction", "residual_gauss"]
+    exec(ref_defs("Marginal/MHD_Residuals_CP.py", names), mhd)
+    for n in names:
+        for b in (False, True):
+            out[f"mhd_{n.split('_')[1]}|{int(b)}"] = mhd[n](v6, boundary=b).contiguous().numpy()
+
+    bdx, bdt, bnu = 2.0 / 14, 1.25 / 9, 0.002
+    out["burgers_coef"] = np.array([bdx, bdt, bnu], np.float64)
+    bur = dict(D_t=Ref1D(domain="t", order=1), D_x=Ref1D(domain="x", order=1), D_xx=Ref1D(domain="x", order=2),
+               dx=torch.tensor(bdx, dtype=torch.float32), dt=torch.tensor(bdt, dtype=torch.float32),
+               nu=torch.tensor(bnu, dtype=torch.float32))
+    exec(ref_defs("Joint/Burgers_Residuals_CP.py", ["residual"]), bur)
+    for b in (False, True):
+        out[f"burgers|{int(b)}"] = bur["residual"](u1, boundary=b).contiguous().numpy()
+
+    adv = dict(D_t=Ref1D(domain="t", order=1), D_x=Ref1D(domain="x", order=1), v=1.0, disc=2, dt=0.005, dx=0.01)
+    kadv = eval(ref_assign_value("Marginal/Advection_Residuals_CP.py", "D.kernel"), adv)
+    D = Ref1D()
+    D.kernel = kadv
+    out["advection_kernel"] = kadv.numpy()
+    out["advection|1"] = D(u1).numpy()
+    out["advection|0"] = D(u1)[..., 1:-1, 1:-1].contiguous().numpy()
+    np.savez_compressed(os.path.join(HERE, "residuals.npz"), **out)
+
+
+def gen_conformal():
+    """BUILD-DEFINED vectors (numpy): not reference-derived."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import conformal as oc
+    out = {"_note": np.array("build-defined, not reference-derived (Neural_PDE.UQ.inductive_cp absent)")}
+    rng = np.random.default_rng(7)
+    for n in (7, 100, 256):
+        s = np.abs(rng.standard_normal((n, 5, 6))).astype(np.float32)
+        s[: n // 3, 0, 0] = s[0, 0, 0]                       # ties
+        r = rng.standard_normal((n, 5, 6)).astype(np.float32)
+        out[f"scores|{n}"], out[f"res|{n}"] = s, r
+        mod = oc.modulation_func(r, np.zeros_like(r))
+        out[f"mod|{n}"] = mod
+        js = oc.ncf_metric_joint(r, np.zeros_like(r), mod)
+        out[f"jscore|{n}"] = js
+        for i, a in enumerate(oc.ALPHA_LEVELS):
+            try:
+                out[f"k|{n}|{i}"] = np.array(oc.kth_index(n, a))
+                out[f"qhat|{n}|{i}"] = oc.calibrate(s, n, a)
+                qj = oc.calibrate(js, n, a)
+                out[f"qhat_joint|{n}|{i}"] = qj
+                out[f"cov|{n}|{i}"] = np.array(oc.emp_cov([-out[f"qhat|{n}|{i}"], out[f"qhat|{n}|{i}"]], r))
+                out[f"cov_joint|{n}|{i}"] = np.array(oc.emp_cov_joint([-qj * mod, qj * mod], r))
+            except ValueError:
+                out[f"k|{n}|{i}"] = np.array(-1)             # level > 1: numpy raises
+    np.savez_compressed(os.path.join(HERE, "conformal.npz"), **out)
+
+
+if __name__ == "__main__":
+    ks = gen_kernels()
+    gen_apply(ks)
+    gen_residuals()
+    gen_conformal()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
