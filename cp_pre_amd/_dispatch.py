@@ -1,0 +1,132 @@
+"""Host-side marshalling between the Python operator surface and the C ABI.
+
+Nothing here computes field values: kernels (<= 343 floats) are inspected on the host to
+build tap lists, tensors are handed to ``libcp_pre_hip.so`` by device pointer + strides on
+the current HIP stream.  CPU tensors (what every ``Marginal/`` / ``Joint/`` script passes)
+are staged through the GPU and the result is returned on the caller's device - the
+arithmetic always runs in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DTYPE_NAMES = {torch.float64: "Double", torch.float16: "Half", torch.bfloat16: "BFloat16", torch.int64: "Long",
+                torch.int32: "Int"}
+
+
+def _dtype_error(dtype):
+    # wording of the RuntimeError F.conv3d raises for a dtype mismatch with the fp32 kernel
+    return RuntimeError(f"expected scalar type Float but found {_DTYPE_NAMES.get(dtype, str(dtype))}")
+
+
+_kernel_cache = {}   # id(tensor) -> (weakref, version, ndarray); device kernels only
+
+
+def host_kernel(kernel):
+    """fp32 numpy copy of an operator kernel.  Device kernels are cached per tensor object
+    and ``_version`` so the D2H copy (a sync) happens once per distinct kernel value."""
+    if not isinstance(kernel, torch.Tensor):
+        raise TypeError("operator kernel must be a torch.Tensor")
+    if kernel.dtype != torch.float32:
+        raise _dtype_error(kernel.dtype)
+    if not kernel.is_cuda:
+        return np.ascontiguousarray(kernel.detach().numpy())
+    key = id(kernel)
+    hit = _kernel_cache.get(key)
+    if hit is not None and hit[0]() is kernel and hit[1] == kernel._version:
+        return hit[2]
+    arr = kernel.detach().cpu().numpy().copy()
+    if len(_kernel_cache) > 256:
+        for k in [k for k, v in _kernel_cache.items() if v[0]() is None]:
+            del _kernel_cache[k]
+    _kernel_cache[key] = (weakref.ref(kernel), kernel._version, arr)
+    return arr
+
+
+def taps_of(karr):
+    """(weights, offsets) of the non-zero taps; offset = index - extent//2 (zero padding
+    ``k//2`` of ``Utils/ConvOps_2d.py:149`` / ``Utils/ConvOps_1d.py:150``)."""
+    if any(s % 2 == 0 for s in karr.shape):
+        raise NotImplementedError("even kernel extents change the output shape in the reference; not supported")
+    if any(s > 7 for s in karr.shape):
+        raise NotImplementedError("kernel extents above 7 are not supported")
+    idx = np.argwhere(karr != 0)
+    w = karr[tuple(idx.T)].astype(np.float32) if len(idx) else np.zeros((0,), np.float32)
+    off = idx - np.array([s // 2 for s in karr.shape])
+    return w, off.astype(np.int32)
+
+
+def to_device(t):
+    """(device tensor, original device).  Raises without a GPU: no CPU fallback."""
+    if t.is_cuda:
+        return t, None
+    _lib.require_gpu()
+    return t.cuda(), t.device
+
+
+def from_device(out, origin):
+    return out if origin is None else out.to(origin)
+
+
+def _check_field(field):
+    if not isinstance(field, torch.Tensor):
+        raise TypeError("field must be a torch.Tensor")
+    if field.dtype != torch.float32:
+        raise _dtype_error(field.dtype)
+
+
+def xcorr(field, kernel, nd, flags=0):
+    """Zero-padded single-channel cross-correlation of ``field`` with ``kernel``.
+
+    nd=3: field [BS,Nt,Nx,Ny], kernel k*k*k.   nd=2: field [BS,Nt,Nx] (or [BS,1,Nt,Nx]), kernel k*k.
+    """
+    _check_field(field)
+    karr = host_kernel(kernel)
+    if karr.ndim != nd:
+        raise RuntimeError(f"expected a {nd}-D kernel, got shape {tuple(karr.shape)}")
+    w, off = taps_of(karr)
+    squeeze = False
+    if nd == 2 and field.dim() == 4:
+        if field.shape[1] != 1:
+            raise RuntimeError("expected a single-channel [BS,1,Nt,Nx] field")
+        field, squeeze = field[:, 0], False
+    if field.dim() != nd + 1:
+        raise RuntimeError(f"expected a {nd + 1}-D field [BS,Nt,Nx{',Ny' if nd == 3 else ''}], got {tuple(field.shape)}")
+    lib = _lib.load()
+    dev, origin = to_device(field)
+    out = torch.empty(dev.shape, dtype=torch.float32, device=dev.device)
+    if out.numel() == 0:
+        return from_device(out, origin)
+    wv = _lib.farr(w) if len(w) else (ctypes.c_float * 1)()
+    ov = _lib.iarr32(off.reshape(-1)) if len(w) else (ctypes.c_int32 * 1)()
+    with torch.cuda.device(dev.device):
+        if nd == 3:
+            f = _lib.field(dev)
+            rc = lib.pre_stencil3d_f32(ctypes.byref(f), _lib.ptr(out), wv, ov, len(w), *dev.shape, flags, _lib.stream())
+            _lib.check(rc, "pre_stencil3d_f32")
+        else:
+            rc = lib.pre_stencil2d_f32(_lib.ptr(dev), _lib.iarr64(dev.stride()), _lib.ptr(out), wv, ov, len(w),
+                                       *dev.shape, flags, _lib.stream())
+            _lib.check(rc, "pre_stencil2d_f32")
+    return from_device(out, origin)
+
+
+def dense27(kernel):
+    """27 host floats of a 3x3x3 operator kernel, or None if it has another shape."""
+    k = host_kernel(kernel)
+    if k.shape != (3, 3, 3):
+        return None
+    return _lib.farr(k.reshape(-1))
+
+
+def dense9(kernel):
+    k = host_kernel(kernel)
+    if k.shape != (3, 3):
+        return None
+    return _lib.farr(k.reshape(-1))

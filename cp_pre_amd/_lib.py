@@ -1,0 +1,109 @@
+"""ctypes binding of ``libcp_pre_hip.so`` (C ABI: ``include/cp_pre_hip.h``).
+
+The library is the product; this module only marshals device pointers, sizes and the
+current HIP stream.  There is no CPU fallback: if the shared object is missing, or no
+MI355X is visible when a compute entry point is called, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_ulonglong, c_void_p
+
+import torch  # imported first on purpose: the .so must bind to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libcp_pre_hip.so")
+
+PRE_OK, PRE_E_NULL, PRE_E_SHAPE, PRE_E_UNSUPPORTED, PRE_E_RANGE = 0, -1, -2, -3, -4
+PRE_FLAG_ABS = 1
+_ERR = {PRE_E_NULL: "null pointer / bad size", PRE_E_SHAPE: "unsupported shape",
+        PRE_E_UNSUPPORTED: "operator kernels not star-shaped or layout not streamable",
+        PRE_E_RANGE: "rank / crop out of range"}
+
+
+class PreField(ctypes.Structure):
+    """``pre_field_t``: a strided [B,T,X,Y] view (element strides)."""
+    _fields_ = [("ptr", c_void_p), ("sB", c_int64), ("sT", c_int64), ("sX", c_int64), ("sY", c_int64)]
+
+
+_fp, _fld = c_void_p, POINTER(PreField)
+# name -> argtypes; every symbol include/cp_pre_hip.h declares
+SIGNATURES = {
+    "pre_abi_version": [],
+    "pre_stencil3d_f32": [_fld, _fp, POINTER(c_float), POINTER(c_int32), c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p],
+    "pre_stencil2d_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_float), POINTER(c_int32), c_int, c_int64, c_int64, c_int64, c_int, c_void_p],
+    "pre_residual_ns_momentum_f32": [_fld, _fld, _fld, _fp] + [POINTER(c_float)] * 4 + [c_float] * 4 + [c_int64] * 4 + [c_int, c_void_p],
+    "pre_residual_linear2_f32": [_fld, _fld, _fp, POINTER(c_float), POINTER(c_float), c_float] + [c_int64] * 4 + [c_int, c_void_p],
+    "pre_residual_burgers_f32": [_fp, POINTER(c_int64), _fp] + [POINTER(c_float)] * 3 + [c_float] * 4 + [c_int64] * 3 + [c_int, c_void_p],
+    "pre_residual_mhd_f32": [c_int, POINTER(PreField), _fp] + [POINTER(c_float)] * 3 + [c_double] + [c_int64] * 4 + [c_int, c_void_p],
+    "pre_absdiff_f32": [_fp, _fp, _fp, c_int64, c_void_p],
+    "pre_std_axis0_f32": [_fp, _fp, c_int64, c_int64, c_float, _fp, c_void_p],
+    "pre_moments_axis0_f64": [_fp, _fp, c_int64, c_int64, _fp, _fp, c_void_p],
+    "pre_std_from_moments_f32": [_fp, _fp, c_int64, c_int64, c_float, _fp, c_void_p],
+    "pre_joint_score_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, _fp, c_void_p],
+    "pre_kth_f32": [_fp, c_int64, POINTER(c_int64), c_int, _fp, c_void_p],
+    "pre_kth_axis0_f32": [_fp, c_int64, c_int64, POINTER(c_int32), c_int, _fp, c_void_p],
+    "pre_cov_count_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int, _fp, c_void_p],
+    "pre_cov_joint_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int, _fp, c_void_p],
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise loudly if the extension is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  cp_pre_amd has no CPU fallback.")
+        lib = ctypes.CDLL(SO_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)        # AttributeError here = header / library out of sync
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        _lib = lib
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("cp_pre_amd: no HIP device visible; the residual / calibration path runs only on "
+                           "an MI355X (there is deliberately no CPU fallback)")
+
+
+def check(rc, what):
+    if rc == PRE_OK:
+        return
+    if rc < 0:
+        raise RuntimeError(f"{what}: {_ERR.get(rc, 'error')} (rc={rc})")
+    raise RuntimeError(f"{what}: hipError_t {rc}")
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def field(t):
+    """PreField for a 4-D fp32 device view (any strides)."""
+    assert t.dim() == 4
+    s = t.stride()
+    return PreField(t.data_ptr(), s[0], s[1], s[2], s[3])
+
+
+def farr(values):
+    return (c_float * len(values))(*[float(v) for v in values])
+
+
+def iarr32(values):
+    return (c_int32 * len(values))(*[int(v) for v in values])
+
+
+def iarr64(values):
+    return (c_int64 * len(values))(*[int(v) for v in values])

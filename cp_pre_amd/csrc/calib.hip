@@ -1,0 +1,451 @@
+// calib.hip - nonconformity scores, modulation, joint score, radix-select quantiles and
+// coverage for gfx950.  All kernels are HBM-bound streaming passes (4 B per element per
+// pass); there is no contraction here and nothing is reshaped into one.
+//
+// Layout convention: a calibration tensor is contiguous [n, M] - n samples (batch axis,
+// slowest) by M cells.  "lane = cell": consecutive lanes read consecutive cells of one
+// sample row (coalesced), and a lane walks the batch axis for its own cell, so per-cell
+// state (running sums, radix prefixes) lives in registers and never crosses lanes.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ |a-b|
+__global__ void __launch_bounds__(256) absdiff_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                      float *__restrict__ out, long long n)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool vec = !(((uintptr_t)a | (uintptr_t)out | (uintptr_t)(b ? b : a)) & 15);
+    long long done = 0;
+    if (vec) {
+        const long long n4 = n / 4;
+        const float4 *a4 = reinterpret_cast<const float4 *>(a);
+        const float4 *b4 = reinterpret_cast<const float4 *>(b);
+        float4 *o4 = reinterpret_cast<float4 *>(out);
+        for (long long i = tid; i < n4; i += stride) {
+            float4 v = a4[i];
+            if (b) { const float4 w = b4[i]; v = make_float4(v.x - w.x, v.y - w.y, v.z - w.z, v.w - w.w); }
+            o4[i] = make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
+        }
+        done = n4 * 4;
+    }
+    for (long long i = done + tid; i < n; i += stride) out[i] = fabsf(b ? a[i] - b[i] : a[i]);
+}
+
+// ------------------------------------------------------------------ std over axis 0, numpy order
+// numpy's np.std(x, axis=0) on float32 [n, M]: s = x[0]+x[1]+... (sequential fp32), mean = s/n,
+// d = x-mean, d = d*d, v = d[0]+d[1]+... (sequential fp32), sqrt(v/n).  Reproduced op for op
+// (no fma contraction), so the result is bit-identical to the numpy oracle.
+__global__ void __launch_bounds__(256) std_axis0_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                        int n, long long M, float eps, float *__restrict__ mod)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= M) return;
+    const float *pa = a + c, *pb = b ? b + c : nullptr;
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < n; ++i) {
+        const float v = pb ? __fsub_rn(pa[(long long)i * M], pb[(long long)i * M]) : pa[(long long)i * M];
+        s = __fadd_rn(s, v);
+    }
+    const float mean = __fdiv_rn(s, (float)n);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < n; ++i) {
+        const float v = pb ? __fsub_rn(pa[(long long)i * M], pb[(long long)i * M]) : pa[(long long)i * M];
+        const float d = __fsub_rn(v, mean);
+        acc = __fadd_rn(acc, __fmul_rn(d, d));
+    }
+    mod[c] = __fadd_rn(__fsqrt_rn(__fdiv_rn(acc, (float)n)), eps);
+}
+
+// ------------------------------------------------------------------ streaming moments (fp64)
+__global__ void __launch_bounds__(256) moments_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                      int n, long long M, int rows_per_split,
+                                                      double *__restrict__ sum, double *__restrict__ sumsq)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= M) return;
+    const int i0 = blockIdx.y * rows_per_split;
+    const int i1 = min(n, i0 + rows_per_split);
+    double s = 0.0, q = 0.0;
+#pragma unroll 8
+    for (int i = i0; i < i1; ++i) {
+        float v = a[(long long)i * M + c];
+        if (b) v = __fsub_rn(v, b[(long long)i * M + c]);
+        const double d = (double)v;
+        s += d;
+        q += d * d;
+    }
+    if (gridDim.y == 1) { sum[c] += s; sumsq[c] += q; }
+    else { atomicAdd(&sum[c], s); atomicAdd(&sumsq[c], q); }
+}
+
+__global__ void __launch_bounds__(256) std_from_moments_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
+                                                               double n_total, long long M, float eps, float *__restrict__ mod)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= M) return;
+    const double mean = sum[c] / n_total;
+    double var = sumsq[c] / n_total - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    mod[c] = __fadd_rn((float)sqrt(var), eps);
+}
+
+// ------------------------------------------------------------------ joint score
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// grid (row-chunks, n); one block reduces RB rows (t,x) of sample blockIdx.y
+constexpr int JS_RB = 8;
+__global__ void __launch_bounds__(256) joint_score_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                          const float *__restrict__ mod, int T, int X, int Y,
+                                                          int ct, int cx, int cy, float *__restrict__ scores)
+{
+    const long long plane = (long long)X * Y, vol = plane * T;
+    const int smp = blockIdx.y;
+    const float *pa = a + smp * vol, *pb = b ? b + smp * vol : nullptr;
+    const long long r0 = (long long)blockIdx.x * JS_RB, nrows = (long long)T * X;
+    const bool vec = (Y % 4 == 0) && !(((uintptr_t)a | (uintptr_t)mod | (uintptr_t)(b ? b : a)) & 15);
+    float m = 0.f;
+    for (int rr = 0; rr < JS_RB; ++rr) {
+        const long long r = r0 + rr;
+        if (r >= nrows) break;
+        const int t = (int)(r / X), x = (int)(r % X);
+        if (t < ct || t >= T - ct || x < cx || x >= X - cx) continue;
+        const long long ro = r * Y;
+        if (vec) {
+            for (int y = threadIdx.x * 4; y < Y; y += blockDim.x * 4) {
+                float4 v = *reinterpret_cast<const float4 *>(pa + ro + y);
+                if (pb) { const float4 w = *reinterpret_cast<const float4 *>(pb + ro + y); v = make_float4(v.x - w.x, v.y - w.y, v.z - w.z, v.w - w.w); }
+                const float4 s = *reinterpret_cast<const float4 *>(mod + ro + y);
+                const float e[4] = {fabsf(v.x) / s.x, fabsf(v.y) / s.y, fabsf(v.z) / s.z, fabsf(v.w) / s.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (y + k >= cy && y + k < Y - cy) m = fmaxf(m, e[k]);
+            }
+        } else {
+            for (int y = cy + threadIdx.x; y < Y - cy; y += blockDim.x) {
+                float v = pa[ro + y];
+                if (pb) v -= pb[ro + y];
+                m = fmaxf(m, fabsf(v) / mod[ro + y]);
+            }
+        }
+    }
+    __shared__ float red[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        // non-negative floats order like their bit patterns
+        atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, __float_as_uint(m));
+    }
+}
+
+// ------------------------------------------------------------------ scalar k-th (radix select)
+struct KList { int nk; long long k[16]; };
+
+__global__ void __launch_bounds__(1024) kth_kernel(const float *__restrict__ s, long long N, const KList kl, float *__restrict__ out)
+{
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int sh_prefix;
+    __shared__ long long sh_rank;
+    for (int j = 0; j < kl.nk; ++j) {
+        unsigned int prefix = 0, mask = 0;
+        long long rank = kl.k[j];
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (long long i = threadIdx.x; i < N; i += blockDim.x) {
+                const unsigned int key = f2key(s[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                long long cum = 0;
+                unsigned int d = 0;
+                for (; d < 255; ++d) {
+                    if (cum + hist[d] > rank) break;
+                    cum += hist[d];
+                }
+                sh_prefix = prefix | (d << shift);
+                sh_rank = rank - cum;
+            }
+            __syncthreads();
+            prefix = sh_prefix;
+            rank = sh_rank;
+            mask |= 255u << shift;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[j] = key2f(prefix);
+    }
+}
+
+// ------------------------------------------------------------------ per-cell k-th over axis 0
+// MSD radix select, 8-bit digits, 4 passes over [n, M], ALL requested ranks at once.
+// One workgroup (1024 threads) owns 16 adjacent cells (64 B of every sample row); lane&15 is
+// the cell, the other thread bits walk the batch axis 64 rows at a time.  Per pass, one LDS
+// histogram per *distinct* prefix among the ranks of a cell ("slot"; ranks are ascending, so
+// equal prefixes are adjacent): [slot][256 bins][16 cells] of 16-bit counters packed two cells
+// to a word (counts <= n < 65536).  After the pass one wave per (rank, cell) pair scans its
+// 256 bins with a wave prefix sum and narrows prefix and rank.
+constexpr int KA_W = 16, KA_MAXK = 10, KA_ROWS = 64;
+struct KAList { int nk; int k[KA_MAXK]; };
+
+__global__ void __launch_bounds__(1024) kth_axis0_kernel(const float *__restrict__ s, int n, long long M, const KAList kl,
+                                                         float *__restrict__ out)
+{
+    __shared__ unsigned int hist[KA_MAXK * 256 * (KA_W / 2)];     // 80 KiB
+    __shared__ unsigned int s_prefix[KA_MAXK][KA_W];
+    __shared__ unsigned int s_rank[KA_MAXK][KA_W];
+    __shared__ int s_slot[KA_MAXK][KA_W];
+
+    const int tid = threadIdx.x, cell = tid & (KA_W - 1), rsub = tid >> 4;
+    const int nk = kl.nk;
+    const long long c0 = (long long)blockIdx.x * KA_W, c = c0 + cell;
+    const bool cok = c < M;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    if (tid < nk * KA_W) { s_prefix[tid / KA_W][tid % KA_W] = 0u; s_rank[tid / KA_W][tid % KA_W] = (unsigned)kl.k[tid / KA_W]; }
+    unsigned int mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        __syncthreads();
+        for (int i = tid; i < nk * 256 * (KA_W / 2); i += 1024) hist[i] = 0u;
+        if (tid < KA_W) {            // slot = first rank index carrying the same prefix
+            int lead = 0;
+            for (int j = 0; j < nk; ++j) {
+                if (j > 0 && s_prefix[j][tid] != s_prefix[j - 1][tid]) lead = j;
+                s_slot[j][tid] = lead;
+            }
+        }
+        __syncthreads();
+        unsigned int pf[KA_MAXK];
+        unsigned int leaders = 0;
+#pragma unroll
+        for (int j = 0; j < KA_MAXK; ++j) {
+            pf[j] = j < nk ? s_prefix[j][cell] : 0u;
+            if (j < nk && s_slot[j][cell] == j) leaders |= 1u << j;
+        }
+        const unsigned int inc = 1u << (16 * (cell & 1));
+        unsigned int *hcol = hist + (cell >> 1);
+        if (cok) {
+#pragma unroll 4
+            for (int i = rsub; i < n; i += KA_ROWS) {
+                const unsigned int key = f2key(s[(long long)i * M + c]);
+                const unsigned int dig = (key >> shift) & 255u, hi = key & mask;
+#pragma unroll
+                for (int j = 0; j < KA_MAXK; ++j)
+                    if (((leaders >> j) & 1u) && hi == pf[j]) atomicAdd(hcol + (j * 256 + dig) * (KA_W / 2), inc);
+            }
+        }
+        __syncthreads();
+        // narrow: pair p = (rank index j, cell cc); 16 waves share the pairs
+        for (int p = wave; p < nk * KA_W; p += 16) {
+            const int j = p / KA_W, cc = p % KA_W;
+            const int slot = s_slot[j][cc];
+            const unsigned int r = s_rank[j][cc];
+            const unsigned int *h = hist + (slot * 256) * (KA_W / 2) + (cc >> 1);
+            const int sh16 = 16 * (cc & 1);
+            unsigned int b4[4], tot = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { b4[u] = (h[(lane * 4 + u) * (KA_W / 2)] >> sh16) & 0xffffu; tot += b4[u]; }
+            unsigned int incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            const unsigned long long crossed = __ballot(incl > r);
+            const int win = __ffsll((long long)crossed) - 1;      // first lane whose inclusive sum exceeds r
+            if (lane == win) {
+                unsigned int cum = incl - tot;
+                int u = 0;
+                for (; u < 3; ++u) { if (cum + b4[u] > r) break; cum += b4[u]; }
+                s_prefix[j][cc] |= (unsigned)(lane * 4 + u) << shift;
+                s_rank[j][cc] = r - cum;
+            }
+        }
+        mask |= 255u << shift;
+    }
+    __syncthreads();
+    if (tid < nk * KA_W) {
+        const int j = tid / KA_W, cc = tid % KA_W;
+        if (c0 + cc < M) out[(long long)j * M + c0 + cc] = key2f(s_prefix[j][cc]);
+    }
+}
+
+// ------------------------------------------------------------------ coverage
+__global__ void __launch_bounds__(256) cov_count_kernel(const float *__restrict__ y, const float *__restrict__ lo,
+                                                        const float *__restrict__ hi, long long total, long long M,
+                                                        int per_sample, unsigned long long *count)
+{
+    unsigned int local = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long c = per_sample ? i : i % M;
+        const float v = y[i];
+        local += (v >= lo[c]) && (v <= hi[c]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    __shared__ unsigned int red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(count, (unsigned long long)(red[0] + red[1] + red[2] + red[3]));
+}
+
+// grid (chunks, n): clear inside[i] if any cell of sample i leaves [lo, hi]
+__global__ void __launch_bounds__(256) cov_joint_kernel(const float *__restrict__ y, const float *__restrict__ lo,
+                                                        const float *__restrict__ hi, long long M, int per_sample,
+                                                        uint8_t *inside)
+{
+    const int smp = blockIdx.y;
+    const float *py = y + smp * M;
+    const float *plo = lo + (per_sample ? smp * M : 0), *phi = hi + (per_sample ? smp * M : 0);
+    bool bad = false;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < M; c += (long long)gridDim.x * blockDim.x) {
+        const float v = py[c];
+        bad |= !((v >= plo[c]) && (v <= phi[c]));
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) inside[smp] = 0;
+}
+
+inline unsigned grid_for(long long items, int block, long long cap = 256LL * 32)
+{
+    long long g = (items + block - 1) / block;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pre_absdiff_f32(const float *a, const float *b, float *out, int64_t n, void *stream)
+{
+    if (!a || !out || n < 0) return PRE_E_NULL;
+    if (n == 0) return PRE_OK;
+    hipLaunchKernelGGL(absdiff_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, as_stream(stream), a, b, out, (long long)n);
+    PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
+
+int pre_std_axis0_f32(const float *a, const float *b, int64_t n, int64_t M, float eps, float *mod, void *stream)
+{
+    if (!a || !mod || n <= 0 || M <= 0) return PRE_E_NULL;
+    if (n > 0x7fffffff) return PRE_E_SHAPE;
+    hipLaunchKernelGGL(std_axis0_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), a, b, (int)n,
+                       (long long)M, eps, mod);
+    PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
+
+int pre_moments_axis0_f64(const float *a, const float *b, int64_t n, int64_t M, double *sum, double *sumsq, void *stream)
+{
+    if (!a || !sum || !sumsq || n <= 0 || M <= 0) return PRE_E_NULL;
+    if (n > 0x7fffffff) return PRE_E_SHAPE;
+    const long long bx = (M + 255) / 256;
+    // enough workgroups to fill 256 CUs even when M is small: split the batch axis
+    long long splits = 1;
+    while (bx * splits < 1024 && splits * 32 < n) splits *= 2;
+    const int rows = (int)((n + splits - 1) / splits);
+    splits = (n + rows - 1) / rows;
+    hipLaunchKernelGGL(moments_kernel, dim3((unsigned)bx, (unsigned)splits), dim3(256), 0, as_stream(stream), a, b, (int)n,
+                       (long long)M, rows, sum, sumsq);
+    PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
+
+int pre_std_from_moments_f32(const double *sum, const double *sumsq, int64_t n_total, int64_t M, float eps, float *mod,
+                             void *stream)
+{
+    if (!sum || !sumsq || !mod || n_total <= 0 || M <= 0) return PRE_E_NULL;
+    hipLaunchKernelGGL(std_from_moments_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), sum, sumsq,
+                       (double)n_total, (long long)M, eps, mod);
+    PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
+
+int pre_joint_score_f32(const float *a, const float *b, const float *mod, int64_t n, int64_t T, int64_t X, int64_t Y,
+                        int crop_t, int crop_x, int crop_y, float *scores, void *stream)
+{
+    if (!a || !mod || !scores || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
+    if (crop_t < 0 || crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
+    if (n > 65535 * 1024LL || T * X > 0x7fffffffLL * JS_RB || Y > 0x7fffffff) return PRE_E_SHAPE;
+    const long long chunks = (T * X + JS_RB - 1) / JS_RB;
+    // gridDim.y is limited to 65535: walk the batch axis in slices
+    for (int64_t s0 = 0; s0 < n; s0 += 65535) {
+        const int64_t ns = (n - s0) < 65535 ? (n - s0) : 65535;
+        const long long vol = (long long)T * X * Y;
+        hipLaunchKernelGGL(joint_score_kernel, dim3((unsigned)chunks, (unsigned)ns), dim3(256), 0, as_stream(stream),
+                           a + s0 * vol, b ? b + s0 * vol : nullptr, mod, (int)T, (int)X, (int)Y, crop_t, crop_x, crop_y,
+                           scores + s0);
+        PRE_LAUNCH_CHECK();
+    }
+    return PRE_OK;
+}
+
+int pre_kth_f32(const float *scores, int64_t N, const int64_t *ks, int nk, float *out, void *stream)
+{
+    if (!scores || !ks || !out || N <= 0 || nk <= 0) return PRE_E_NULL;
+    for (int j = 0; j < nk; ++j)
+        if (ks[j] < 0 || ks[j] >= N) return PRE_E_RANGE;
+    for (int j0 = 0; j0 < nk; j0 += 16) {
+        KList kl;
+        kl.nk = (nk - j0) < 16 ? (nk - j0) : 16;
+        for (int j = 0; j < kl.nk; ++j) kl.k[j] = ks[j0 + j];
+        hipLaunchKernelGGL(kth_kernel, dim3(1), dim3(1024), 0, as_stream(stream), scores, (long long)N, kl, out + j0);
+        PRE_LAUNCH_CHECK();
+    }
+    return PRE_OK;
+}
+
+int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks, int nk, float *out, void *stream)
+{
+    if (!scores || !ks || !out || n <= 0 || M <= 0 || nk <= 0) return PRE_E_NULL;
+    if (n >= 65536 || nk > 16) return PRE_E_SHAPE;
+    for (int j = 0; j < nk; ++j) {
+        if (ks[j] < 0 || ks[j] >= n) return PRE_E_RANGE;
+        if (j > 0 && ks[j] < ks[j - 1]) return PRE_E_RANGE;      // ascending (slots rely on it)
+    }
+    const long long tiles = (M + KA_W - 1) / KA_W;
+    if (tiles > 0x7fffffffLL) return PRE_E_SHAPE;
+    for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
+        KAList kl;
+        kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
+        for (int j = 0; j < kl.nk; ++j) kl.k[j] = ks[j0 + j];
+        hipLaunchKernelGGL(kth_axis0_kernel, dim3((unsigned)tiles), dim3(1024), 0, as_stream(stream), scores, (int)n,
+                           (long long)M, kl, out + (long long)j0 * M);
+        PRE_LAUNCH_CHECK();
+    }
+    return PRE_OK;
+}
+
+int pre_cov_count_f32(const float *y, const float *lo, const float *hi, int64_t n, int64_t M, int per_sample_bounds,
+                      unsigned long long *count, void *stream)
+{
+    if (!y || !lo || !hi || !count || n <= 0 || M <= 0) return PRE_E_NULL;
+    hipLaunchKernelGGL(cov_count_kernel, dim3(grid_for(n * M, 256)), dim3(256), 0, as_stream(stream), y, lo, hi,
+                       (long long)(n * M), (long long)M, per_sample_bounds, count);
+    PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
+
+int pre_cov_joint_f32(const float *y, const float *lo, const float *hi, int64_t n, int64_t M, int per_sample_bounds,
+                      uint8_t *inside, void *stream)
+{
+    if (!y || !lo || !hi || !inside || n <= 0 || M <= 0) return PRE_E_NULL;
+    const unsigned gx = grid_for(M, 256, 64);
+    for (int64_t s0 = 0; s0 < n; s0 += 65535) {
+        const int64_t ns = (n - s0) < 65535 ? (n - s0) : 65535;
+        hipLaunchKernelGGL(cov_joint_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, as_stream(stream), y + s0 * M,
+                           per_sample_bounds ? lo + s0 * M : lo, per_sample_bounds ? hi + s0 * M : hi, (long long)M,
+                           per_sample_bounds, inside + s0);
+        PRE_LAUNCH_CHECK();
+    }
+    return PRE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,534 @@
+// star_march.hip - streaming evaluation of 7-point-star stencils and fused PDE residuals
+// over [B,T,X,Y] fp32 fields on gfx950 (MI355X).
+//
+// Bound: HBM.  Algorithmic traffic is 4*(F+1) bytes per cell (F input fields read once,
+// one residual written once).  Structure of one workgroup (NR x TYQ threads):
+//   * owns an (x,y) tile of NR rows x 4*TYQ columns of ONE sample and marches over t;
+//   * every thread keeps a 4-plane sliding window (t-1, t, t+1 and the in-flight t+2) of
+//     its own float4 per field in REGISTERS, so each input cell is fetched once per
+//     workgroup and the t-taps cost nothing;
+//   * the current plane is staged through LDS (double-buffered, one barrier per plane) for
+//     the x-neighbours, including one halo row above and below the tile;
+//   * y-neighbours come from the adjacent lane by a wavefront shuffle; only the two edge
+//     lanes of each 64-wide wave fetch a halo scalar;
+//   * loads for plane t+2 are issued before plane t is computed (software prefetch);
+//   * blockIdx is remapped so each XCD's L2 sees a contiguous run of tiles (shared halos).
+// The residual algebra is a compile-time functor; operator weights are run-time scalars
+// taken from the caller's dense 3x3x3 kernels, so the reference's kernel-construction
+// quirks are inherited (see include/cp_pre_hip.h).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXF = 6;
+
+struct Geom {
+    const float *f[MAXF];
+    long long sB[MAXF], sT[MAXF], sX[MAXF];
+    float *out;
+    int B, T, X, Y;
+    int tSeg, nTSeg, nXT, nYT;
+    int flags;
+};
+
+// c, t-, t+, x-, x+, y-, y+
+struct Star { float c, tm, tp, xm, xp, ym, yp; };
+
+struct Nbr { float4 c, tm, tp, xm, xp, ym, yp; };
+
+__device__ __forceinline__ float4 f4(float s) { return make_float4(s, s, s, s); }
+__device__ __forceinline__ float4 fabs4(const float4 &a) { return make_float4(fabsf(a.x), fabsf(a.y), fabsf(a.z), fabsf(a.w)); }
+
+enum Kind { K_T3, K_X3, K_Y3, K_XY5, K_STAR7 };
+
+template <int KIND>
+__device__ __forceinline__ float4 apply(const Star &w, const Nbr &n)
+{
+    if (KIND == K_T3) return w.tm * n.tm + w.c * n.c + w.tp * n.tp;
+    if (KIND == K_X3) return w.xm * n.xm + w.c * n.c + w.xp * n.xp;
+    if (KIND == K_Y3) return w.ym * n.ym + w.c * n.c + w.yp * n.yp;
+    if (KIND == K_XY5) return w.xm * n.xm + w.ym * n.ym + w.c * n.c + w.yp * n.yp + w.xp * n.xp;
+    return w.tm * n.tm + w.xm * n.xm + w.ym * n.ym + w.c * n.c + w.yp * n.yp + w.xp * n.xp + w.tp * n.tp;
+}
+
+// ------------------------------------------------------------------ residual functors
+// MODE 0: the tap structure the reference constructs (D_t,D_y along Nt; D_x along Nx;
+//         Laplacian on the (Nx,Ny) cross).  MODE 1: D_y along Ny (the physically intended
+//         stencil).  MODE 2: every operator a general 7-point star.
+template <int MODE> struct OpKinds {
+    static constexpr int DT = MODE == 2 ? K_STAR7 : K_T3;
+    static constexpr int DX = MODE == 2 ? K_STAR7 : K_X3;
+    static constexpr int DY = MODE == 2 ? K_STAR7 : (MODE == 1 ? K_Y3 : K_T3);
+    static constexpr int LAP = MODE == 2 ? K_STAR7 : K_XY5;
+};
+
+struct Linear1 {       // out = S(f0): any single ConvOperator / additive kernel (README.md:47-54)
+    static constexpr int F = 1;
+    struct Params { Star s; };
+    static __device__ __forceinline__ float4 eval(const Nbr (&n)[1], const Params &p) { return apply<K_STAR7>(p.s, n[0]); }
+};
+
+struct Linear2 {       // out = Sa(f0) + ratio*Sb(f1)
+    static constexpr int F = 2;
+    struct Params { Star a, b; float ratio; };
+    static __device__ __forceinline__ float4 eval(const Nbr (&n)[2], const Params &p)
+    {
+        return apply<K_STAR7>(p.a, n[0]) + p.ratio * apply<K_STAR7>(p.b, n[1]);
+    }
+};
+
+struct NSParams { Star Dt, Dx, Dy, L; float dt, dx, dy, nu; };
+struct BurgersParams { Star Dt, Dx, Dxx; float dx, dt, nu, c3; };
+struct MHDParams { Star Dt, Dx, Dy; float gamma, gm2; };
+
+template <int MODE>
+struct NSMomentum {    // Marginal/NS_Residuals_CP.py:231-240
+    static constexpr int F = 3;
+    using Params = NSParams;
+    static __device__ __forceinline__ float4 eval(const Nbr (&n)[3], const Params &p)
+    {
+        using K = OpKinds<MODE>;
+        const Nbr &u = n[0], &v = n[1], &pr = n[2];
+        float4 rx = apply<K::DT>(p.Dt, u) * p.dx * p.dy;
+        rx = rx + u.c * apply<K::DX>(p.Dx, u) * p.dt * p.dy;
+        rx = rx + v.c * apply<K::DY>(p.Dy, u) * p.dt * p.dx;
+        rx = rx - p.nu * apply<K::LAP>(p.L, u) * p.dt;
+        rx = rx + apply<K::DX>(p.Dx, pr) * p.dt * p.dy;
+        float4 ry = apply<K::DT>(p.Dt, v) * p.dx * p.dy;
+        ry = ry + u.c * apply<K::DX>(p.Dx, v) * p.dt * p.dx;
+        ry = ry + v.c * apply<K::DY>(p.Dy, v) * p.dt * p.dy;
+        ry = ry - p.nu * apply<K::LAP>(p.L, v) * p.dt;
+        ry = ry + apply<K::DY>(p.Dy, pr) * p.dt * p.dx;
+        return rx + ry;
+    }
+};
+
+// 1-D Burgers on the [1,B,T,X] view: the script's D_t runs along our x axis, D_x / D_xx along y.
+template <int MODE>
+struct Burgers {       // Joint/Burgers_Residuals_CP.py:182-187
+    static constexpr int F = 1;
+    using Params = BurgersParams;
+    static __device__ __forceinline__ float4 eval(const Nbr (&n)[1], const Params &p)
+    {
+        constexpr int KT = MODE == 2 ? K_STAR7 : K_X3, KX = MODE == 2 ? K_STAR7 : K_Y3;
+        const Nbr &u = n[0];
+        float4 r = p.dx * apply<KT>(p.Dt, u);
+        r = r + (p.dt * u.c) * apply<KX>(p.Dx, u);
+        r = r - (p.nu * apply<KX>(p.Dxx, u)) * p.c3;
+        return r;
+    }
+};
+
+template <int MODE>
+struct MHDContinuity { // Marginal/MHD_Residuals_CP.py:225-231   fields rho,u,v
+    static constexpr int F = 3;
+    using Params = MHDParams;
+    static __device__ __forceinline__ float4 eval(const Nbr (&n)[3], const Params &p)
+    {
+        using K = OpKinds<MODE>;
+        const Nbr &rho = n[0], &u = n[1], &v = n[2];
+        float4 r = apply<K::DT>(p.Dt, rho) + u.c * apply<K::DX>(p.Dx, rho);
+        r = r + rho.c * apply<K::DX>(p.Dx, u);
+        r = r + v.c * apply<K::DY>(p.Dy, rho);
+        r = r + rho.c * apply<K::DY>(p.Dy, v);
+        return r;
+    }
+};
+
+template <int MODE>
+struct MHDMomentum {   // Marginal/MHD_Residuals_CP.py:234-243   fields rho,u,v,p,Bx,By
+    static constexpr int F = 6;
+    using Params = MHDParams;
+    static __device__ __forceinline__ float4 eval(const Nbr (&n)[6], const Params &p)
+    {
+        using K = OpKinds<MODE>;
+        const Nbr &rho = n[0], &u = n[1], &v = n[2], &pr = n[3], &bx = n[4], &by = n[5];
+        const float4 irho = f4(1.0f) / rho.c, bxr = bx.c / rho.c, byr = by.c / rho.c;
+        float4 rx = apply<K::DT>(p.Dt, u) + u.c * apply<K::DX>(p.Dx, u);
+        rx = rx + irho * apply<K::DX>(p.Dx, pr);
+        rx = rx - (2.0f * bxr) * apply<K::DX>(p.Dx, bx);
+        rx = rx + v.c * apply<K::DY>(p.Dy, u);
+        rx = rx - byr * apply<K::DY>(p.Dy, bx);
+        rx = rx - bxr * apply<K::DY>(p.Dy, by);
+        float4 ry = apply<K::DT>(p.Dt, v) + u.c * apply<K::DX>(p.Dx, v);
+        ry = ry + irho * apply<K::DY>(p.Dy, pr);
+        ry = ry - (2.0f * byr) * apply<K::DY>(p.Dy, by);
+        ry = ry + v.c * apply<K::DY>(p.Dy, v);
+        ry = ry - byr * apply<K::DX>(p.Dx, bx);
+        ry = ry - bxr * apply<K::DX>(p.Dx, by);
+        return rx + ry;
+    }
+};
+
+template <int MODE>
+struct MHDEnergy {     // Marginal/MHD_Residuals_CP.py:247-256; PRE_estimations.py:70-80
+    static constexpr int F = 6;
+    using Params = MHDParams;
+    static __device__ __forceinline__ float4 eval(const Nbr (&n)[6], const Params &p)
+    {
+        using K = OpKinds<MODE>;
+        const Nbr &rho = n[0], &u = n[1], &v = n[2], &pr = n[3], &bx = n[4], &by = n[5];
+        const float4 bx2 = bx.c * bx.c, by2 = by.c * by.c;
+        const float4 pgas = pr.c - 0.5f * (bx2 + by2);
+        float4 r = apply<K::DT>(p.Dt, rho) + u.c * apply<K::DX>(p.Dx, pr);
+        r = r + v.c * apply<K::DY>(p.Dy, pr);
+        r = r + (p.gm2 * (u.c * bx.c + v.c * by.c)) * (apply<K::DX>(p.Dx, bx) + apply<K::DY>(p.Dy, by));
+        r = r + (p.gamma * pgas + by2) * apply<K::DX>(p.Dx, u);
+        r = r + (p.gamma * pgas + bx2) * apply<K::DY>(p.Dy, v);
+        r = r - (bx.c * by.c) * (apply<K::DY>(p.Dy, u) + apply<K::DX>(p.Dx, v));
+        return r;
+    }
+};
+
+template <int MODE>
+struct MHDInduction {  // Marginal/MHD_Residuals_CP.py:259-268   fields u,v,Bx,By
+    static constexpr int F = 4;
+    using Params = MHDParams;
+    static __device__ __forceinline__ float4 eval(const Nbr (&n)[4], const Params &p)
+    {
+        using K = OpKinds<MODE>;
+        const Nbr &u = n[0], &v = n[1], &bx = n[2], &by = n[3];
+        float4 rx = apply<K::DT>(p.Dt, bx) - by.c * apply<K::DY>(p.Dy, u);
+        rx = rx + bx.c * apply<K::DY>(p.Dy, v);
+        rx = rx - v.c * apply<K::DY>(p.Dy, bx);
+        rx = rx + u.c * apply<K::DY>(p.Dy, by);
+        float4 ry = apply<K::DT>(p.Dt, by) + by.c * apply<K::DX>(p.Dx, u);
+        ry = ry - bx.c * apply<K::DX>(p.Dx, v);
+        ry = ry - v.c * apply<K::DX>(p.Dx, bx);
+        ry = ry + u.c * apply<K::DX>(p.Dx, by);
+        return rx + ry;
+    }
+};
+
+// ------------------------------------------------------------------ the marching kernel
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// Barrier that orders LDS traffic only: __syncthreads() would also drain vmcnt and with it
+// the global prefetches that are meant to stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int F> struct Halo { float4 row[F]; float yl[F], yr[F]; };
+
+template <class Fn, int NR, int TYQ>
+__global__ void __launch_bounds__(NR *TYQ) march_kernel(const Geom g, const typename Fn::Params prm)
+{
+    constexpr int F = Fn::F;
+    static_assert(NR >= 2, "tile needs at least two rows (top and bottom halo owners differ)");
+    __shared__ float4 lds[2][F][NR + 2][TYQ];
+
+    const int q = threadIdx.x, ty = threadIdx.y;
+    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int yt = L % g.nYT; L /= g.nYT;
+    const int xt = L % g.nXT; L /= g.nXT;
+    const int ts = L % g.nTSeg;
+    const int b = L / g.nTSeg;
+
+    const int x = xt * NR + ty, y = (yt * TYQ + q) * 4;
+    const bool inb = (x < g.X) && (y < g.Y);
+    const int t0 = ts * g.tSeg;
+    const int t1 = min(t0 + g.tSeg, g.T);
+
+    // halo-row duty: thread-row 0 fetches the row above the tile, thread-row NR-1 the row below
+    const bool top = (ty == 0), bot = (ty == NR - 1);
+    const int hx = top ? x - 1 : x + 1;
+    const bool hrow = (top || bot) && (hx >= 0) && (hx < g.X) && (y < g.Y);
+    const int hslot = top ? 0 : NR + 1;
+    // y-halo duty: the edge lanes of each wave (and of the tile) fetch one scalar
+    const bool ledge = ((q & 63) == 0), redge = ((q & 63) == 63) || (q == TYQ - 1);
+    const bool lload = ledge && inb && (y > 0);
+    const bool rload = redge && inb && (y + 4 < g.Y);
+
+    const float *own[F], *hal[F];
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        const float *base = g.f[i] + (long long)b * g.sB[i];
+        own[i] = base + (long long)x * g.sX[i] + y;
+        hal[i] = base + (long long)hx * g.sX[i] + y;
+    }
+    float *outp = g.out + (((long long)b * g.T) * g.X + x) * (long long)g.Y + y;
+    const long long oT = (long long)g.X * g.Y;
+
+    auto load_own = [&](int t, float4(&dst)[F]) __attribute__((always_inline)) {
+        const bool ok = inb && (t >= 0) && (t < g.T);
+#pragma unroll
+        for (int i = 0; i < F; ++i) dst[i] = ok ? ldg4(own[i] + (long long)t * g.sT[i]) : f4(0.f);
+    };
+    auto load_halo = [&](int t, Halo<F> &h) __attribute__((always_inline)) {
+        const bool okt = (t >= 0) && (t < g.T);
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            h.row[i] = (hrow && okt) ? ldg4(hal[i] + (long long)t * g.sT[i]) : f4(0.f);
+            h.yl[i] = (lload && okt) ? own[i][(long long)t * g.sT[i] - 1] : 0.f;
+            h.yr[i] = (rload && okt) ? own[i][(long long)t * g.sT[i] + 4] : 0.f;
+        }
+    };
+
+    // One plane.  P,C,N hold planes t-1,t,t+1 of the own cells; D receives plane t+2;
+    // hc is the halo of plane t, hn receives the halo of plane t+1.  The caller rotates the
+    // roles instead of moving registers, so D/hn stay in flight until they are first read.
+    auto step = [&](int t, float4(&P)[F], float4(&C)[F], float4(&N)[F], float4(&D)[F],
+                    Halo<F> &hc, Halo<F> &hn) __attribute__((always_inline)) {
+        const int bi = (t - t0) & 1;
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            lds[bi][i][ty + 1][q] = C[i];
+            if (top || bot) lds[bi][i][hslot][q] = hc.row[i];
+        }
+        load_own(t + 2, D);
+        load_halo(t + 1, hn);
+        lds_barrier();
+
+        Nbr n[F];
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            n[i].c = C[i];
+            n[i].tm = P[i];
+            n[i].tp = N[i];
+            n[i].xm = lds[bi][i][ty][q];
+            n[i].xp = lds[bi][i][ty + 2][q];
+            float lft = __shfl_up(C[i].w, 1);
+            float rgt = __shfl_down(C[i].x, 1);
+            lft = ledge ? hc.yl[i] : lft;
+            rgt = redge ? hc.yr[i] : rgt;
+            n[i].ym = make_float4(lft, C[i].x, C[i].y, C[i].z);
+            n[i].yp = make_float4(C[i].y, C[i].z, C[i].w, rgt);
+        }
+        float4 r = Fn::eval(n, prm);
+        if (g.flags & PRE_FLAG_ABS) r = fabs4(r);
+        if (inb) *reinterpret_cast<float4 *>(outp + (long long)t * oT) = r;
+    };
+
+    float4 w0[F], w1[F], w2[F], w3[F];
+    Halo<F> h0, h1;
+    load_own(t0 - 1, w0);
+    load_own(t0, w1);
+    load_own(t0 + 1, w2);
+    load_halo(t0, h0);
+
+    for (int t = t0; t < t1; t += 4) {
+        step(t, w0, w1, w2, w3, h0, h1);
+        if (t + 1 >= t1) break;
+        step(t + 1, w1, w2, w3, w0, h1, h0);
+        if (t + 2 >= t1) break;
+        step(t + 2, w2, w3, w0, w1, h0, h1);
+        if (t + 3 >= t1) break;
+        step(t + 3, w3, w0, w1, w2, h1, h0);
+    }
+}
+
+// ------------------------------------------------------------------ host side
+bool star_from_dense27(const float *K, Star *s)
+{
+    // axes (Nt,Nx,Ny); index (a,b,c) -> offset (a-1,b-1,c-1).  True iff all weight is on the star.
+    auto at = [&](int a, int b, int c) { return K[(a * 3 + b) * 3 + c]; };
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            for (int c = 0; c < 3; ++c) {
+                const int off = (a != 1) + (b != 1) + (c != 1);
+                if (off > 1 && at(a, b, c) != 0.0f) return false;
+            }
+    s->c = at(1, 1, 1);
+    s->tm = at(0, 1, 1); s->tp = at(2, 1, 1);
+    s->xm = at(1, 0, 1); s->xp = at(1, 2, 1);
+    s->ym = at(1, 1, 0); s->yp = at(1, 1, 2);
+    return true;
+}
+
+struct Shape { bool t, x, y; };
+Shape shape_of(const Star &s) { return {s.tm != 0.f || s.tp != 0.f, s.xm != 0.f || s.xp != 0.f, s.ym != 0.f || s.yp != 0.f}; }
+
+// which compiled tap structure do (D_t, D_x, D_y[, Lap]) fit?  0 reference, 1 y-fixed, 2 general
+int pick_mode(const Star &Dt, const Star &Dx, const Star &Dy, const Star *L)
+{
+    const Shape st = shape_of(Dt), sx = shape_of(Dx), sy = shape_of(Dy);
+    const bool dt_ok = !st.x && !st.y, dx_ok = !sx.t && !sx.y;
+    const bool lap_ok = !L || !shape_of(*L).t;
+    if (dt_ok && dx_ok && lap_ok && !sy.x && !sy.y) return 0;
+    if (dt_ok && dx_ok && lap_ok && !sy.x && !sy.t) return 1;
+    return 2;
+}
+
+bool fast_layout_ok(const pre_field_t *const *fs, int nf, int64_t Y, const float *out)
+{
+    if (Y % 4 != 0) return false;
+    if (((uintptr_t)out) & 15) return false;
+    for (int i = 0; i < nf; ++i) {
+        const pre_field_t *f = fs[i];
+        if (f->sY != 1) return false;
+        if ((((uintptr_t)f->ptr) & 15) || (f->sB % 4) || (f->sT % 4) || (f->sX % 4)) return false;
+    }
+    return true;
+}
+
+template <class Fn, int NR, int TYQ>
+int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st)
+{
+    g.nXT = (g.X + NR - 1) / NR;
+    g.nYT = (g.Y + 4 * TYQ - 1) / (4 * TYQ);
+    // split long T axes so the grid fills the chip (>= ~4 workgroups per CU) without
+    // paying the 2-plane window prologue too often
+    long long tiles = (long long)g.B * g.nXT * g.nYT;
+    int tSeg = g.T;
+    while (tiles * ((g.T + tSeg - 1) / tSeg) < 2048 && tSeg > 16) tSeg = (tSeg + 1) / 2;
+    g.tSeg = tSeg;
+    g.nTSeg = (g.T + tSeg - 1) / tSeg;
+    tiles *= g.nTSeg;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return PRE_E_SHAPE;
+    hipLaunchKernelGGL((march_kernel<Fn, NR, TYQ>), dim3((unsigned)tiles), dim3(TYQ, NR), 0, st, g, prm);
+    PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
+
+template <class Fn>
+int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st)
+{
+    // 512 threads per workgroup; rows of the tile trade halo re-reads (2/NR) against columns covered
+    if (g.Y >= 192) return launch_tiled<Fn, 8, 64>(g, prm, st);
+    if (g.Y >= 96) return launch_tiled<Fn, 16, 32>(g, prm, st);
+    return launch_tiled<Fn, 32, 16>(g, prm, st);
+}
+
+int fill_geom(Geom &g, const pre_field_t *const *fs, int nf, float *out, int64_t B, int64_t T, int64_t X, int64_t Y, int flags)
+{
+    if (!out || B <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
+    if (B > 0x7fffffff || T > 0x7fffffff || X > 0x7fffffff || Y > 0x7fffffff) return PRE_E_SHAPE;
+    for (int i = 0; i < nf; ++i) {
+        if (!fs[i] || !fs[i]->ptr) return PRE_E_NULL;
+        g.f[i] = fs[i]->ptr; g.sB[i] = fs[i]->sB; g.sT[i] = fs[i]->sT; g.sX[i] = fs[i]->sX;
+    }
+    for (int i = nf; i < MAXF; ++i) { g.f[i] = nullptr; g.sB[i] = g.sT[i] = g.sX[i] = 0; }
+    g.out = out; g.B = (int)B; g.T = (int)T; g.X = (int)X; g.Y = (int)Y; g.flags = flags;
+    return PRE_OK;
+}
+
+template <template <int> class FnT, class P>
+int launch_mode(int mode, Geom &g, const P &prm, hipStream_t st)
+{
+    if (mode == 0) return launch<FnT<0>>(g, prm, st);
+    if (mode == 1) return launch<FnT<1>>(g, prm, st);
+    return launch<FnT<2>>(g, prm, st);
+}
+
+}  // namespace
+
+// Internal: called by stencil_generic.hip when a tap list is star-shaped and the layout allows it.
+int pre_star_try_linear1(const pre_field_t *in, float *out, const float star7[7],
+                         int64_t B, int64_t T, int64_t X, int64_t Y, int flags, hipStream_t st)
+{
+    const pre_field_t *fs[1] = {in};
+    if (!fast_layout_ok(fs, 1, Y, out)) return PRE_E_UNSUPPORTED;
+    Geom g;
+    int rc = fill_geom(g, fs, 1, out, B, T, X, Y, flags);
+    if (rc) return rc;
+    Linear1::Params p;
+    p.s = Star{star7[0], star7[1], star7[2], star7[3], star7[4], star7[5], star7[6]};
+    return launch<Linear1>(g, p, st);
+}
+
+extern "C" {
+
+int pre_residual_ns_momentum_f32(const pre_field_t *u, const pre_field_t *v, const pre_field_t *p, float *out,
+                                 const float *K_t, const float *K_x, const float *K_y, const float *K_xx_yy,
+                                 float dt, float dx, float dy, float nu,
+                                 int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)
+{
+    if (!K_t || !K_x || !K_y || !K_xx_yy) return PRE_E_NULL;
+    const pre_field_t *fs[3] = {u, v, p};
+    Geom g;
+    int rc = fill_geom(g, fs, 3, out, B, T, X, Y, flags);
+    if (rc) return rc;
+    NSParams prm;
+    if (!star_from_dense27(K_t, &prm.Dt) || !star_from_dense27(K_x, &prm.Dx) ||
+        !star_from_dense27(K_y, &prm.Dy) || !star_from_dense27(K_xx_yy, &prm.L))
+        return PRE_E_UNSUPPORTED;
+    if (!fast_layout_ok(fs, 3, Y, out)) return PRE_E_UNSUPPORTED;
+    prm.dt = dt; prm.dx = dx; prm.dy = dy; prm.nu = nu;
+    return launch_mode<NSMomentum>(pick_mode(prm.Dt, prm.Dx, prm.Dy, &prm.L), g, prm, as_stream(stream));
+}
+
+int pre_residual_linear2_f32(const pre_field_t *f0, const pre_field_t *f1, float *out,
+                             const float *K_a, const float *K_b, float ratio,
+                             int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)
+{
+    if (!K_a || !K_b) return PRE_E_NULL;
+    const pre_field_t *fs[2] = {f0, f1};
+    Geom g;
+    int rc = fill_geom(g, fs, 2, out, B, T, X, Y, flags);
+    if (rc) return rc;
+    Linear2::Params prm;
+    if (!star_from_dense27(K_a, &prm.a) || !star_from_dense27(K_b, &prm.b)) return PRE_E_UNSUPPORTED;
+    if (!fast_layout_ok(fs, 2, Y, out)) return PRE_E_UNSUPPORTED;
+    prm.ratio = ratio;
+    return launch<Linear2>(g, prm, as_stream(stream));
+}
+
+int pre_residual_burgers_f32(const float *u, const int64_t in_strides[3], float *out,
+                             const float *K_t, const float *K_x, const float *K_xx,
+                             float dx, float dt, float nu, float c3,
+                             int64_t B, int64_t T, int64_t X, int flags, void *stream)
+{
+    if (!u || !in_strides || !K_t || !K_x || !K_xx) return PRE_E_NULL;
+    // [B,T,X] -> [1, B, T, X]; 3x3 kernel (a over Nt, b over Nx) -> dense27 index (1, a, b)
+    pre_field_t f{u, 0, in_strides[0], in_strides[1], in_strides[2]};
+    const pre_field_t *fs[1] = {&f};
+    Geom g;
+    int rc = fill_geom(g, fs, 1, out, 1, B, T, X, flags);
+    if (rc) return rc;
+    float d27[3][27] = {};
+    const float *k9[3] = {K_t, K_x, K_xx};
+    for (int o = 0; o < 3; ++o)
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) d27[o][(1 * 3 + a) * 3 + c] = k9[o][a * 3 + c];
+    BurgersParams prm;
+    if (!star_from_dense27(d27[0], &prm.Dt) || !star_from_dense27(d27[1], &prm.Dx) || !star_from_dense27(d27[2], &prm.Dxx))
+        return PRE_E_UNSUPPORTED;
+    if (!fast_layout_ok(fs, 1, X, out)) return PRE_E_UNSUPPORTED;
+    prm.dx = dx; prm.dt = dt; prm.nu = nu; prm.c3 = c3;
+    // mode 0 needs D_t purely along Nt (our x) and D_x, D_xx purely along Nx (our y)
+    const Shape a = shape_of(prm.Dt), b2 = shape_of(prm.Dx), c2 = shape_of(prm.Dxx);
+    const int mode = (!a.y && !b2.x && !c2.x) ? 0 : 2;
+    return launch_mode<Burgers>(mode, g, prm, as_stream(stream));
+}
+
+int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], float *out,
+                         const float *K_t, const float *K_x, const float *K_y, double gamma,
+                         int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)
+{
+    if (!fields || !K_t || !K_x || !K_y) return PRE_E_NULL;
+    if (eq < 0 || eq > 3) return PRE_E_RANGE;
+    MHDParams prm;
+    if (!star_from_dense27(K_t, &prm.Dt) || !star_from_dense27(K_x, &prm.Dx) || !star_from_dense27(K_y, &prm.Dy))
+        return PRE_E_UNSUPPORTED;
+    prm.gamma = (float)gamma;
+    prm.gm2 = (float)(gamma - 2.0);   // "(gamma-2)" is a float64 Python scalar in the reference
+    const int mode = pick_mode(prm.Dt, prm.Dx, prm.Dy, nullptr);
+    const pre_field_t *all[6] = {&fields[0], &fields[1], &fields[2], &fields[3], &fields[4], &fields[5]};
+    Geom g;
+    hipStream_t st = as_stream(stream);
+    if (eq == 0) {
+        const pre_field_t *fs[3] = {all[0], all[1], all[2]};
+        int rc = fill_geom(g, fs, 3, out, B, T, X, Y, flags);
+        if (rc) return rc;
+        if (!fast_layout_ok(fs, 3, Y, out)) return PRE_E_UNSUPPORTED;
+        return launch_mode<MHDContinuity>(mode, g, prm, st);
+    }
+    if (eq == 3) {
+        const pre_field_t *fs[4] = {all[1], all[2], all[4], all[5]};
+        int rc = fill_geom(g, fs, 4, out, B, T, X, Y, flags);
+        if (rc) return rc;
+        if (!fast_layout_ok(fs, 4, Y, out)) return PRE_E_UNSUPPORTED;
+        return launch_mode<MHDInduction>(mode, g, prm, st);
+    }
+    int rc = fill_geom(g, all, 6, out, B, T, X, Y, flags);
+    if (rc) return rc;
+    if (!fast_layout_ok(all, 6, Y, out)) return PRE_E_UNSUPPORTED;
+    if (eq == 1) return launch_mode<MHDMomentum>(mode, g, prm, st);
+    return launch_mode<MHDEnergy>(mode, g, prm, st);
+}
+
+}  // extern "C"

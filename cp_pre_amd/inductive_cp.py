@@ -1,0 +1,214 @@
+"""Split-conformal calibration on the MI355X: the functions the reference imports from
+``Neural_PDE.UQ.inductive_cp`` (``Marginal/NS_Residuals_CP.py:58``), same names and call
+signatures: ``calibrate``, ``modulation_func``, ``ncf_metric_joint``, ``emp_cov``,
+``emp_cov_joint`` (+ ``filter_sims_joint``, ``Joint/Burgers_Residuals_CP.py:298-300``).
+
+PARITY UNPINNED: that module is an un-vendored, un-pinned submodule absent from the
+reference snapshot; the definitions implemented here are the standard split-CP forms
+inferred from the call sites and from ``Tests/test_advection_inv_sampling_marginal.py:428-431,465``
+(SURVEY.md 8a a11-a14, 8c).  They are tested against numpy (``oracle/conformal.py``).
+
+    calibrate(scores, n, alpha)        = np.quantile(scores, ceil((n+1)(1-alpha))/n, axis=0, method='higher')
+    modulation_func(a, b)              = np.std(a - b, axis=0)
+    ncf_metric_joint(a, b, modulation) = np.max(np.abs(a - b)/modulation, axis=(1..))
+    emp_cov(sets, y)                   = ((y >= lo) & (y <= hi)).mean()
+    emp_cov_joint(sets, y)             = ((y >= lo).all(1..) & (y <= hi).all(1..)).mean()
+
+numpy arrays in -> numpy out (what the reference scripts pass); torch tensors in -> torch
+out on the same device.  The arithmetic runs in ``libcp_pre_hip.so`` either way (radix
+select, sequential-order std, max-reduce); q-hat is bit-for-bit one of the input scores.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _dispatch, _lib
+
+
+# ------------------------------------------------------------------ marshalling
+def _dev(x, like=None):
+    """fp32 contiguous device tensor + a function that converts results back."""
+    if isinstance(x, torch.Tensor):
+        if x.dtype != torch.float32:
+            raise RuntimeError("cp_pre_amd.inductive_cp works on float32 tensors")
+        d, origin = _dispatch.to_device(x)
+        return d.contiguous(), (lambda r: _dispatch.from_device(r, origin))
+    arr = np.asarray(x)
+    if arr.dtype != np.float32:
+        arr = arr.astype(np.float32)
+    _lib.require_gpu()
+    return torch.from_numpy(np.ascontiguousarray(arr)).cuda(), (lambda r: r.cpu().numpy())
+
+
+def _is_zero_like(b):
+    """``np.zeros(res.shape)`` is how the scripts say 'no second argument' (Joint/Burgers_..:274)."""
+    if b is None:
+        return True
+    if isinstance(b, np.ndarray):
+        return not b.any()
+    return False
+
+
+# ------------------------------------------------------------------ ranks
+def quantile_level(n, alpha):
+    return math.ceil((n + 1) * (1 - alpha)) / n
+
+
+def kth_index(n_rows, n, alpha):
+    """0-based sorted index numpy's ``method='higher'`` selects: ceil(q*(n_rows-1)), float64."""
+    q = np.ceil((n + 1) * (1 - alpha)) / n
+    if not (0.0 <= q <= 1.0):
+        raise ValueError("Quantiles must be in the range [0, 1]")
+    return int(np.ceil((n_rows - 1) * q))
+
+
+def kth_axis0(scores, ks):
+    """Order statistics ``ks`` (0-based ranks, any order) along axis 0 of a device tensor
+    [n, ...] -> [len(ks), ...].  1-D scores use the scalar radix select."""
+    lib = _lib.load()
+    n = scores.shape[0]
+    order = sorted(range(len(ks)), key=lambda i: ks[i])
+    sk = [int(ks[i]) for i in order]
+    with torch.cuda.device(scores.device):
+        if scores.dim() == 1:
+            out = torch.empty(len(sk), dtype=torch.float32, device=scores.device)
+            _lib.check(lib.pre_kth_f32(_lib.ptr(scores), n, _lib.iarr64(sk), len(sk), _lib.ptr(out), _lib.stream()),
+                       "pre_kth_f32")
+        else:
+            M = scores.numel() // n
+            out = torch.empty((len(sk),) + tuple(scores.shape[1:]), dtype=torch.float32, device=scores.device)
+            for j0 in range(0, len(sk), 16):
+                part = sk[j0:j0 + 16]
+                _lib.check(lib.pre_kth_axis0_f32(_lib.ptr(scores), n, M, _lib.iarr32(part), len(part),
+                                                 _lib.ptr(out[j0:]), _lib.stream()), "pre_kth_axis0_f32")
+    inv = [0] * len(ks)
+    for pos, i in enumerate(order):
+        inv[i] = pos
+    return out[inv] if inv != list(range(len(ks))) else out
+
+
+# ------------------------------------------------------------------ the five functions
+def calibrate(scores, n, alpha):
+    """q-hat over axis 0; array of shape ``scores.shape[1:]`` (scalar for 1-D scores)."""
+    d, back = _dev(scores)
+    k = kth_index(d.shape[0], n, alpha)
+    res = back(kth_axis0(d, [k])[0])
+    if d.dim() == 1 and not isinstance(scores, torch.Tensor):
+        return res[()]                                       # numpy scalar, like np.quantile
+    return res
+
+
+def calibrate_multi(scores, n, alphas):
+    """All levels in ONE radix sweep (the reference loops ``calibrate`` over 10 alphas,
+    Marginal/Wave_Residuals_CP.py:284-288).  Returns [len(alphas), ...]."""
+    d, back = _dev(scores)
+    ks = [kth_index(d.shape[0], n, a) for a in alphas]
+    return back(kth_axis0(d, ks))
+
+
+def _wide(*xs):
+    """numpy promotes float32 - float64 to float64 (``modulation_func(res, np.zeros(res.shape))``,
+    Joint/Burgers_Residuals_CP.py:274): such calls get the fp64-accumulated route and a float64 result."""
+    return any(isinstance(x, np.ndarray) and x.dtype == np.float64 for x in xs)
+
+
+def modulation_func(a, b=None, eps=0.0):
+    """Per-cell population std of (a-b) over axis 0.
+
+    float32 inputs: float32 sequential accumulation in numpy's own operation order
+    (bit-identical to ``np.std(a-b, axis=0)`` on float32).  If an argument is a float64 numpy
+    array (numpy would then compute in float64) the sums are accumulated in fp64 on the device."""
+    da, back = _dev(a)
+    db = None if _is_zero_like(b) else _dev(b)[0]
+    n, M = da.shape[0], da.numel() // da.shape[0]
+    mod = torch.empty(da.shape[1:], dtype=torch.float32, device=da.device)
+    lib = _lib.load()
+    with torch.cuda.device(da.device):
+        if _wide(a, b):
+            mom = torch.zeros(2, M, dtype=torch.float64, device=da.device)
+            _lib.check(lib.pre_moments_axis0_f64(_lib.ptr(da), _lib.ptr(db), n, M, _lib.ptr(mom[0]), _lib.ptr(mom[1]),
+                                                 _lib.stream()), "pre_moments_axis0_f64")
+            _lib.check(lib.pre_std_from_moments_f32(_lib.ptr(mom[0]), _lib.ptr(mom[1]), n, M, float(eps), _lib.ptr(mod),
+                                                    _lib.stream()), "pre_std_from_moments_f32")
+            return back(mod).astype(np.float64)
+        _lib.check(lib.pre_std_axis0_f32(_lib.ptr(da), _lib.ptr(db), n, M, float(eps), _lib.ptr(mod), _lib.stream()),
+                   "pre_std_axis0_f32")
+    return back(mod)
+
+
+def ncf_metric_joint(a, b, modulation, crop=0):
+    """Per-sample max over cells of |a-b|/modulation -> [n].  ``crop`` > 0 restricts the max to
+    the interior of the last three axes of UNCROPPED [n,T,X,Y] inputs (fusing the reference's
+    ``[...,1:-1,1:-1,1:-1]``)."""
+    da, back = _dev(a)
+    db = None if _is_zero_like(b) else _dev(b)[0]
+    dm, _ = _dev(modulation)
+    n = da.shape[0]
+    if crop:
+        if da.dim() != 4:
+            raise ValueError("crop needs [n,T,X,Y] inputs")
+        T, X, Y = da.shape[1:]
+        ct = cx = cy = int(crop)
+    else:
+        T, X, Y, ct, cx, cy = 1, 1, da.numel() // n, 0, 0, 0
+    scores = torch.zeros(n, dtype=torch.float32, device=da.device)
+    with torch.cuda.device(da.device):
+        _lib.check(_lib.load().pre_joint_score_f32(_lib.ptr(da), _lib.ptr(db), _lib.ptr(dm), n, T, X, Y, ct, cx, cy,
+                                                   _lib.ptr(scores), _lib.stream()), "pre_joint_score_f32")
+    res = back(scores)
+    return res.astype(np.float64) if _wide(a, b, modulation) else res
+
+
+def _bounds(pred_sets, y):
+    dy, _ = _dev(y)
+    lo, _ = _dev(pred_sets[0])
+    hi, _ = _dev(pred_sets[1])
+    n, M = dy.shape[0], dy.numel() // dy.shape[0]
+    per_sample = []
+    for t in (lo, hi):
+        if t.numel() == M:
+            per_sample.append(0)
+        elif t.numel() == n * M:
+            per_sample.append(1)
+        else:                                   # scalar / other broadcast: materialise per cell
+            per_sample.append(-1)
+    if per_sample[0] != per_sample[1] or -1 in per_sample:
+        shape = dy.shape if 1 in per_sample else dy.shape[1:]
+        lo = lo.expand(shape).contiguous() if lo.numel() != math.prod(shape) else lo
+        hi = hi.expand(shape).contiguous() if hi.numel() != math.prod(shape) else hi
+        ps = 1 if 1 in per_sample else 0
+    else:
+        ps = per_sample[0]
+    return dy, lo, hi, n, M, ps
+
+
+def emp_cov(pred_sets, y):
+    """Fraction of all cells of all samples inside [lo, hi]."""
+    dy, lo, hi, n, M, ps = _bounds(pred_sets, y)
+    count = torch.zeros(1, dtype=torch.int64, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.load().pre_cov_count_f32(_lib.ptr(dy), _lib.ptr(lo), _lib.ptr(hi), n, M, ps, _lib.ptr(count),
+                                                 _lib.stream()), "pre_cov_count_f32")
+    return float(count.item()) / float(n * M)
+
+
+def filter_sims_joint(pred_sets, y):
+    """Per-sample 'every cell inside the band' flags (bool [n])."""
+    dy, lo, hi, n, M, ps = _bounds(pred_sets, y)
+    inside = torch.ones(n, dtype=torch.uint8, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.load().pre_cov_joint_f32(_lib.ptr(dy), _lib.ptr(lo), _lib.ptr(hi), n, M, ps, _lib.ptr(inside),
+                                                 _lib.stream()), "pre_cov_joint_f32")
+    flags = inside.bool()
+    return flags if isinstance(y, torch.Tensor) else flags.cpu().numpy()
+
+
+def emp_cov_joint(pred_sets, y):
+    f = filter_sims_joint(pred_sets, y)
+    return float(f.float().mean().item()) if isinstance(f, torch.Tensor) else float(f.mean())
+
+
+ALPHA_LEVELS = np.arange(0.05, 0.95 + 0.1, 0.1)     # Marginal/Wave_Residuals_CP.py:284

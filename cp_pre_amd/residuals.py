@@ -1,0 +1,302 @@
+"""PDE residual operators (PRE) over surrogate outputs, evaluated on the MI355X.
+
+Mirrors the residual definitions the reference writes inline per experiment script and
+packages in ``Other_UQ/Evaluation/PRE_estimations.py:5-80`` (``PRE_Wave``, ``PRE_NS``,
+``PRE_MHD`` keep that file's class names, constructor arguments and ``.residual(vars,
+boundary)`` signature).  Every class owns reference-style ``ConvOperator`` objects
+(``D_t, D_x, D_y, D_xx_yy`` ...), whose ``.kernel`` tensors may be replaced by the caller.
+
+Two evaluation routes, same numbers:
+  * fused (default): one streaming HIP pass reads each field once and writes the residual
+    once (``pre_residual_*_f32``); the operators' CURRENT dense kernels are handed to the
+    library, so the reference's ``D_y == D_t`` construction quirk is inherited, not re-coded;
+  * composed (``fused=False``, or automatically when a kernel is not a 3x3x3 star or a view
+    is not streamable): the reference expression, operator by operator, each
+    ``ConvOperator`` call being a HIP stencil pass and the products/sums torch device ops.
+
+``vars`` is [BS,F,Nt,Nx,Ny]; ``boundary=False`` crops one cell per side like the reference
+(a view of the full residual).  ``absolute=True`` returns |residual| (the marginal score).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _dispatch, _lib
+from .convops_1d import ConvOperator as ConvOperator1D
+from .convops_2d import ConvOperator as ConvOperator2D
+
+_CROP3 = (Ellipsis, slice(1, -1), slice(1, -1), slice(1, -1))
+_CROP2 = (Ellipsis, slice(1, -1), slice(1, -1))
+
+
+def _stage(fields):
+    """Device views of the fields (+ where the result has to go back to)."""
+    origin = None
+    out = []
+    for f in fields:
+        _dispatch._check_field(f)
+        d, o = _dispatch.to_device(f)
+        origin = origin or o
+        out.append(d)
+    return out, origin
+
+
+def _on_device(fields, fn):
+    """Composed route: stage the fields once, evaluate ``fn`` on device tensors, return home."""
+    devs, origin = _stage(fields)
+    return _dispatch.from_device(fn(*devs), origin)
+
+
+def _fused_call(name, call):
+    """Run a fused entry point; None means 'compose instead'."""
+    rc = call()
+    if rc == _lib.PRE_E_UNSUPPORTED:
+        return False
+    _lib.check(rc, name)
+    return True
+
+
+class _Residual2D:
+    """Shared plumbing: the operator set of ``Marginal/NS_Residuals_CP.py:213-219``."""
+
+    def __init__(self, device='cpu', fused=True, y_axis_fix=False):
+        self.fused = fused
+        self.D_t = ConvOperator2D(domain='t', order=1, device=device)
+        self.D_x = ConvOperator2D(domain='x', order=1, device=device)
+        self.D_y = ConvOperator2D(domain='y', order=1, device=device, y_axis_fix=y_axis_fix)
+        self.D_x_y = ConvOperator2D(domain=('x', 'y'), order=1, device=device)     # kernel-less, as in the reference
+        self.D_xx_yy = ConvOperator2D(domain=('x', 'y'), order=2, device=device)
+
+    def _k27(self, *ops):
+        ks = [_dispatch.dense27(o.kernel) for o in ops]
+        return None if any(k is None for k in ks) else ks
+
+
+def _finish(res, boundary, crop, absolute, already_abs):
+    if absolute and not already_abs:
+        res = res.abs()
+    return res if boundary else res[crop]
+
+
+# ======================================================================= Navier-Stokes
+class NavierStokes(_Residual2D):
+    """``Marginal/NS_Residuals_CP.py:203-240``: continuity and momentum residuals of (u, v, p)."""
+
+    def __init__(self, dt, dx, dy, nu=0.001, **kw):
+        super().__init__(**kw)
+        self.dt, self.dx, self.dy, self.nu = dt, dx, dy, nu
+
+    def residual_continuity(self, vars, boundary=False, absolute=False):
+        u, v = vars[:, 0], vars[:, 1]
+        ratio = self.dx / self.dy
+        res = None
+        if self.fused:
+            from .vector_convops import linear2
+            res = linear2(u, self.D_x.kernel, v, self.D_y.kernel, ratio, _lib.PRE_FLAG_ABS if absolute else 0)
+        done_abs = res is not None and absolute
+        if res is None:
+            res = _on_device((u, v), lambda u, v: self.D_x(u) + ratio * self.D_y(v))
+        return _finish(res, boundary, _CROP3, absolute, done_abs)
+
+    def residual_momentum(self, vars, boundary=False, absolute=False):
+        u, v, p = vars[:, 0], vars[:, 1], vars[:, 2]
+        dt, dx, dy, nu = self.dt, self.dx, self.dy, self.nu
+        ks = self._k27(self.D_t, self.D_x, self.D_y, self.D_xx_yy) if self.fused else None
+        if ks is not None:
+            (du, dv, dp), origin = _stage((u, v, p))
+            out = torch.empty(du.shape, dtype=torch.float32, device=du.device)
+            fu, fv, fp = _lib.field(du), _lib.field(dv), _lib.field(dp)
+            with torch.cuda.device(du.device):
+                ok = _fused_call("pre_residual_ns_momentum_f32", lambda: _lib.load().pre_residual_ns_momentum_f32(
+                    ctypes.byref(fu), ctypes.byref(fv), ctypes.byref(fp), _lib.ptr(out), *ks,
+                    float(dt), float(dx), float(dy), float(nu), *du.shape,
+                    _lib.PRE_FLAG_ABS if absolute else 0, _lib.stream()))
+            if ok:
+                return _finish(_dispatch.from_device(out, origin), boundary, _CROP3, absolute, True)
+        D_t, D_x, D_y, D_xx_yy = self.D_t, self.D_x, self.D_y, self.D_xx_yy
+
+        def composed(u, v, p):
+            res_x = D_t(u)*dx*dy + u*D_x(u)*dt*dy + v*D_y(u)*dt*dx - nu*D_xx_yy(u)*dt + D_x(p)*dt*dy
+            res_y = D_t(v)*dx*dy + u*D_x(v)*dt*dx + v*D_y(v)*dt*dy - nu*D_xx_yy(v)*dt + D_y(p)*dt*dx
+            return res_x + res_y
+        return _finish(_on_device((u, v, p), composed), boundary, _CROP3, absolute, False)
+
+    def periodic_bc_residual(self, u, wall='right'):
+        """``Marginal/NS_Residuals_CP.py:468-478`` (edge differences; plain slicing)."""
+        res = {'top': lambda: u[..., 0, :] - u[..., -1, :], 'bottom': lambda: u[..., -1, :] - u[..., 0, :],
+               'left': lambda: u[..., :, 0] - u[..., :, -1], 'right': lambda: u[..., :, -1] - u[..., :, 0]}[wall]()
+        return res * self.dx
+
+
+class PRE_NS(NavierStokes):
+    """``Other_UQ/Evaluation/PRE_estimations.py:24-50``: ``PRE_NS(dt, dx, dy).residual(vars)``."""
+
+    def __init__(self, dt, dx, dy, **kw):
+        super().__init__(dt, dx, dy, nu=0.001, **kw)
+
+    def residual(self, vars, boundary=False):
+        return self.residual_momentum(vars, boundary)
+
+
+# ======================================================================= MHD
+_MHD_EQ = {'continuity': 0, 'momentum': 1, 'energy': 2, 'induction': 3}
+
+
+class MHD(_Residual2D):
+    """``Marginal/MHD_Residuals_CP.py:204-278``: ideal-MHD residuals of (rho,u,v,p,Bx,By)."""
+
+    def __init__(self, gamma=5 / 3, **kw):
+        super().__init__(**kw)
+        self.gamma = gamma
+
+    def _fused(self, eq, vars, absolute):
+        ks = self._k27(self.D_t, self.D_x, self.D_y) if self.fused else None
+        if ks is None or vars.shape[1] < 6:
+            return None
+        fields, origin = _stage([vars[:, i] for i in range(6)])
+        out = torch.empty(fields[0].shape, dtype=torch.float32, device=fields[0].device)
+        arr = (_lib.PreField * 6)(*[_lib.field(f) for f in fields])
+        with torch.cuda.device(out.device):
+            ok = _fused_call("pre_residual_mhd_f32", lambda: _lib.load().pre_residual_mhd_f32(
+                _MHD_EQ[eq], arr, _lib.ptr(out), *ks, float(self.gamma), *out.shape,
+                _lib.PRE_FLAG_ABS if absolute else 0, _lib.stream()))
+        return _dispatch.from_device(out, origin) if ok else None
+
+    def residual_continuity(self, vars, boundary=False, absolute=False):
+        res = self._fused('continuity', vars, absolute)
+        if res is None:
+            D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
+            res = _on_device((vars[:, 0], vars[:, 1], vars[:, 2]), lambda rho, u, v:
+                             D_t(rho) + u*D_x(rho) + rho*D_x(u) + v*D_y(rho) + rho*D_y(v))
+            return _finish(res, boundary, _CROP3, absolute, False)
+        return _finish(res, boundary, _CROP3, absolute, True)
+
+    def residual_momentum(self, vars, boundary=False, absolute=False):
+        res = self._fused('momentum', vars, absolute)
+        if res is None:
+            D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
+
+            def composed(rho, u, v, p, Bx, By):
+                res_x = D_t(u) + u*D_x(u) + (1/rho)*D_x(p) - 2*(Bx/rho)*D_x(Bx) + v*D_y(u) - (By/rho)*D_y(Bx) - (Bx/rho)*D_y(By)
+                res_y = D_t(v) + u*D_x(v) + (1/rho)*D_y(p) - 2*(By/rho)*D_y(By) + v*D_y(v) - (By/rho)*D_x(Bx) - (Bx/rho)*D_x(By)
+                return res_x + res_y
+            res = _on_device([vars[:, i] for i in range(6)], composed)
+            return _finish(res, boundary, _CROP3, absolute, False)
+        return _finish(res, boundary, _CROP3, absolute, True)
+
+    def residual_energy(self, vars, boundary=False, absolute=False):
+        res = self._fused('energy', vars, absolute)
+        if res is None:
+            D_t, D_x, D_y, gamma = self.D_t, self.D_x, self.D_y, self.gamma
+
+            def composed(rho, u, v, p, Bx, By):
+                p_gas = p - 0.5*(Bx**2 + By**2)
+                return (D_t(rho) + u*D_x(p) + v*D_y(p) + (gamma-2)*(u*Bx+v*By)*(D_x(Bx) + D_y(By))
+                        + (gamma*p_gas+By**2)*D_x(u) + (gamma*p_gas+Bx**2)*D_y(v) - Bx*By*(D_y(u) + D_x(v)))
+            res = _on_device([vars[:, i] for i in range(6)], composed)
+            return _finish(res, boundary, _CROP3, absolute, False)
+        return _finish(res, boundary, _CROP3, absolute, True)
+
+    def residual_induction(self, vars, boundary=False, absolute=False):
+        res = self._fused('induction', vars, absolute)
+        if res is None:
+            D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
+
+            def composed(u, v, Bx, By):
+                res_x = D_t(Bx) - By*D_y(u) + Bx*D_y(v) - v*D_y(Bx) + u*D_y(By)
+                res_y = D_t(By) + By*D_x(u) - Bx*D_x(v) - v*D_x(Bx) + u*D_x(By)
+                return res_x + res_y
+            res = _on_device((vars[:, 1], vars[:, 2], vars[:, 4], vars[:, 5]), composed)
+            return _finish(res, boundary, _CROP3, absolute, False)
+        return _finish(res, boundary, _CROP3, absolute, True)
+
+    def residual_gauss(self, vars, boundary=False, absolute=False):
+        Bx, By = vars[:, 4], vars[:, 5]
+        res = None
+        if self.fused:
+            from .vector_convops import linear2
+            res = linear2(Bx, self.D_x.kernel, By, self.D_y.kernel, 1.0, _lib.PRE_FLAG_ABS if absolute else 0)
+        done_abs = res is not None and absolute
+        if res is None:
+            res = _on_device((Bx, By), lambda Bx, By: self.D_x(Bx) + self.D_y(By))
+        return _finish(res, boundary, _CROP3, absolute, done_abs)
+
+
+class PRE_MHD(MHD):
+    """``Other_UQ/Evaluation/PRE_estimations.py:54-80``: the energy equation."""
+
+    def __init__(self, dt, dx, dy, **kw):
+        super().__init__(gamma=5 / 3, **kw)
+        self.dt, self.dx, self.dy = dt, dx, dy
+
+    def residual(self, vars, boundary=False):
+        return self.residual_energy(vars, boundary)
+
+
+# ======================================================================= linear: wave / advection
+class PRE_Wave:
+    """``Other_UQ/Evaluation/PRE_estimations.py:5-21`` / ``Marginal/Wave_Residuals_CP.py:170-184``:
+    ONE additive kernel ``D_tt - (c dt/dx)^2 D_xx_yy`` applied in one pass."""
+
+    def __init__(self, dt, dx, c=1.0, device='cpu'):
+        D_tt = ConvOperator2D('t', 2, device=device)
+        D_xx_yy = ConvOperator2D(('x', 'y'), 2, device=device)
+        self.D = ConvOperator2D()
+        c = torch.tensor(c, dtype=torch.float32)
+        self.D.kernel = D_tt.kernel - ((c * dt / dx) ** 2).to(device) * D_xx_yy.kernel
+
+    def residual(self, uu, boundary=False, absolute=False):
+        uu = uu[:, 0] if uu.dim() == 5 else uu
+        res = _dispatch.xcorr(uu, self.D.kernel, nd=3, flags=_lib.PRE_FLAG_ABS if absolute else 0)
+        return res if boundary else res[_CROP3]
+
+
+class Advection:
+    """``Marginal/Advection_Residuals_CP.py:156-164,234-235``: ``D_t + (v disc dt/dx) D_x`` on [BS,Nt,Nx]."""
+
+    def __init__(self, v, dt, dx, disc=2, device='cpu'):
+        D_t = ConvOperator1D(domain='t', order=1, device=device)
+        D_x = ConvOperator1D(domain='x', order=1, device=device)
+        self.D = ConvOperator1D()
+        self.D.kernel = D_t.kernel + (v * disc * dt / dx) * D_x.kernel
+
+    def residual(self, uu, boundary=False, absolute=False):
+        res = _dispatch.xcorr(uu, self.D.kernel, nd=2, flags=_lib.PRE_FLAG_ABS if absolute else 0)
+        return res if boundary else res[_CROP2]
+
+
+# ======================================================================= Burgers (1-D)
+class Burgers:
+    """``Joint/Burgers_Residuals_CP.py:171-187``:
+    ``dx*D_t(u) + dt*u*D_x(u) - nu*D_xx(u)*(2*dt/dx)`` on [BS,Nt,Nx]."""
+
+    def __init__(self, dx, dt, nu, device='cpu', fused=True):
+        self.fused = fused
+        self.D_t = ConvOperator1D(domain='t', order=1, device=device)
+        self.D_x = ConvOperator1D(domain='x', order=1, device=device)
+        self.D_xx = ConvOperator1D(domain='x', order=2, device=device)
+        # the script turns the three coefficients into fp32 0-d tensors first
+        self.dx, self.dt, self.nu = (torch.tensor(v, dtype=torch.float32) for v in (dx, dt, nu))
+
+    def residual(self, uu, boundary=False, absolute=False):
+        dx, dt, nu = self.dx, self.dt, self.nu
+        ks = [_dispatch.dense9(o.kernel) for o in (self.D_t, self.D_x, self.D_xx)] if self.fused else [None]
+        if all(k is not None for k in ks) and uu.dim() == 3:
+            (du,), origin = _stage((uu,))
+            out = torch.empty(du.shape, dtype=torch.float32, device=du.device)
+            c3 = float(2 * dt / dx)                       # evaluated in fp32 like the reference
+            with torch.cuda.device(du.device):
+                ok = _fused_call("pre_residual_burgers_f32", lambda: _lib.load().pre_residual_burgers_f32(
+                    _lib.ptr(du), _lib.iarr64(du.stride()), _lib.ptr(out), *ks, float(dx), float(dt), float(nu), c3,
+                    *du.shape, _lib.PRE_FLAG_ABS if absolute else 0, _lib.stream()))
+            if ok:
+                res = _dispatch.from_device(out, origin)
+                return res if boundary else res[_CROP2]
+
+        def composed(uu):
+            dxd, dtd, nud = (c.to(uu.device) for c in (dx, dt, nu))
+            return dxd * self.D_t(uu) + dtd * uu * self.D_x(uu) - nud * self.D_xx(uu) * (2 * dtd / dxd)
+        return _finish(_on_device((uu,), composed), boundary, _CROP2, absolute, False)

@@ -1,0 +1,141 @@
+/* cp_pre_hip.h - C ABI of libcp_pre_hip.so, the MI355X (gfx950) implementation of the
+ * CP-PRE physics-residual hot path.
+ *
+ * The reference (gitvicky/CP-PRE) is 100 % Python and has no FFI; the entry points
+ * below are what a binding for this path replaces.  Each one cites the reference
+ * interface it stands in for (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is documented "host";
+ *   - all tensors are IEEE fp32; sizes are in elements, strides in elements;
+ *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued
+ *     asynchronously on it, nothing synchronises, nothing allocates;
+ *   - return value: 0 = ok, <0 = argument error (PRE_E_*), >0 = hipError_t;
+ *   - no global state, re-entrant, host-thread-safe.
+ */
+#ifndef CP_PRE_HIP_H
+#define CP_PRE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRE_OK             0
+#define PRE_E_NULL        -1   /* null pointer / bad size                                  */
+#define PRE_E_SHAPE       -2   /* unsupported shape (even kernel extent, > 343 taps, ...)    */
+#define PRE_E_UNSUPPORTED -3   /* operator kernels not star-shaped: caller composes unfused */
+#define PRE_E_RANGE       -4   /* k / crop out of range                                     */
+
+#define PRE_FLAG_ABS       1   /* store |residual| (marginal score, Marginal/Wave_Residuals_CP.py:280) */
+
+/* A strided view of one field [B,T,X,Y] (what `vars[:, i]` or a permuted surrogate
+ * output is, Marginal/NS_Residuals_CP.py:282; Other_UQ/Evaluation/PRE_estimations.py:41). */
+typedef struct {
+    const float *ptr;
+    int64_t sB, sT, sX, sY;
+} pre_field_t;
+
+int pre_abi_version(void);
+
+/* ---- a4/a5/a6: ConvOperator.convolution ---------------------------------------------
+ * Utils/ConvOps_2d.py:135-150  F.conv3d(field[:,None], K[None,None], padding=k//2)
+ * Utils/ConvOps_1d.py:130-150  F.conv2d(...)
+ * Zero-padded single-channel cross-correlation given as a tap list (host arrays):
+ *   out[b,t,x,y] = sum_i w[i] * in[b, t+off[3i], x+off[3i+1], y+off[3i+2]]   (0 outside)
+ * `out` is contiguous [B,T,X,Y]; `in` may be any strided view.  |off| <= 3, ntaps <= 343.
+ * Star-shaped 3x3x3 tap sets on a y-contiguous 16-byte aligned view take the streaming
+ * kernel; everything else takes the generic kernel.  Same result either way. */
+int pre_stencil3d_f32(const pre_field_t *in, float *out,
+                      const float *tap_w /*host*/, const int32_t *tap_off /*host, 3*ntaps*/, int ntaps,
+                      int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream);
+
+/* [B,T,X] fields with a 2-D kernel; tap_off is 2*ntaps (dt,dx); in_strides = {sB,sT,sX}. */
+int pre_stencil2d_f32(const float *in, const int64_t in_strides[3], float *out,
+                      const float *tap_w /*host*/, const int32_t *tap_off /*host*/, int ntaps,
+                      int64_t B, int64_t T, int64_t X, int flags, void *stream);
+
+/* ---- a9: fused PDE residuals --------------------------------------------------------
+ * Operators are passed as the DENSE 3x3x3 kernels the caller's ConvOperator objects hold
+ * (27 floats each, host, axes (Nt,Nx,Ny)), so every construction quirk of the reference
+ * (D_y == D_t, Utils/ConvOps_2d.py:72-73) is inherited.  Returns PRE_E_UNSUPPORTED if a
+ * kernel has a tap off the 7-point star; the caller then composes pre_stencil3d_f32 calls.
+ * `out` is contiguous [B,T,X,Y] (uncropped; the caller crops [...,1:-1,1:-1,1:-1]). */
+
+/* Marginal/NS_Residuals_CP.py:231-240; Other_UQ/Evaluation/PRE_estimations.py:40-50 */
+int pre_residual_ns_momentum_f32(const pre_field_t *u, const pre_field_t *v, const pre_field_t *p, float *out,
+                                 const float *K_t, const float *K_x, const float *K_y, const float *K_xx_yy,
+                                 float dt, float dx, float dy, float nu,
+                                 int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream);
+/* Marginal/NS_Residuals_CP.py:222-228   res = D_x(u) + ratio*D_y(v)   (also Divergence/Curl/gauss:
+ * out = Ka(f0) + ratio*Kb(f1), Utils/VectorConvOps.py:38,65; Marginal/MHD_Residuals_CP.py:272-278) */
+int pre_residual_linear2_f32(const pre_field_t *f0, const pre_field_t *f1, float *out,
+                             const float *K_a, const float *K_b, float ratio,
+                             int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream);
+/* Joint/Burgers_Residuals_CP.py:171-187   [B,T,X]; 3x3 kernels (9 floats, host), axes (Nt,Nx);
+ * res = dx*D_t(u) + dt*u*D_x(u) - nu*D_xx(u)*c3   with c3 = 2*dt/dx evaluated by the caller in fp32 */
+int pre_residual_burgers_f32(const float *u, const int64_t in_strides[3], float *out,
+                             const float *K_t, const float *K_x, const float *K_xx,
+                             float dx, float dt, float nu, float c3,
+                             int64_t B, int64_t T, int64_t X, int flags, void *stream);
+/* Marginal/MHD_Residuals_CP.py:225-278; eq: 0 continuity, 1 momentum, 2 energy, 3 induction.
+ * fields = {rho,u,v,p,Bx,By} (all six views must be valid even if the equation skips some). */
+int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], float *out,
+                         const float *K_t, const float *K_x, const float *K_y, double gamma,
+                         int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream);
+
+/* ---- a10: marginal nonconformity score ------------------------------------------------
+ * out = |a - b| (b may be NULL: |a|).  Marginal/Wave_Residuals_CP.py:219,280 */
+int pre_absdiff_f32(const float *a, const float *b, float *out, int64_t n, void *stream);
+
+/* ---- a12: modulation_func(a, b) = std(a-b, axis 0), ddof 0 ----------------------------
+ * (Neural_PDE.UQ.inductive_cp, absent; Tests/test_advection_inv_sampling_marginal.py:428)
+ * a, b: contiguous [n, M] (b may be NULL).
+ * pre_std_axis0_f32: the whole calibration set resident; float32 sequential two-pass,
+ *   the exact operation order numpy uses for an axis-0 reduction, + eps (Joint/MHD_Residuals_CP.py:350).
+ * pre_moments_axis0_f64: streaming / sharded form; ACCUMULATES sum and sum of squares of
+ *   (a-b) over the n rows into sum[M], sumsq[M] (fp64, caller zeroes them before the first
+ *   chunk, all-reduces them across ranks), then pre_std_from_moments_f32 finishes. */
+int pre_std_axis0_f32(const float *a, const float *b, int64_t n, int64_t M, float eps, float *mod, void *stream);
+int pre_moments_axis0_f64(const float *a, const float *b, int64_t n, int64_t M,
+                          double *sum, double *sumsq, void *stream);
+int pre_std_from_moments_f32(const double *sum, const double *sumsq, int64_t n_total, int64_t M,
+                             float eps, float *mod, void *stream);
+
+/* ---- a13: ncf_metric_joint(a, b, modulation) = max_cells |a-b|/mod per sample -----------
+ * (Tests/test_advection_inv_sampling_marginal.py:430-431).  a, b: contiguous [n,T,X,Y]
+ * UNCROPPED, mod: [T,X,Y]; only cells with crop <= index < extent-crop on each of the last
+ * three axes take part (crop_t/x/y = 1 reproduces the reference's [...,1:-1,1:-1,1:-1]).
+ * scores[n] must be zero-filled by the caller; the kernel max-accumulates into it, so
+ * per-slab calls over a split T axis compose. */
+int pre_joint_score_f32(const float *a, const float *b, const float *mod,
+                        int64_t n, int64_t T, int64_t X, int64_t Y,
+                        int crop_t, int crop_x, int crop_y, float *scores, void *stream);
+
+/* ---- a11: calibrate(scores, n, alpha) ---------------------------------------------------
+ * (Neural_PDE.UQ.inductive_cp, absent; call sites Marginal/Wave_Residuals_CP.py:288,
+ * Joint/Burgers_Residuals_CP.py:283).  Exact order statistics by MSD radix select on the
+ * order-preserving uint32 image of fp32; result is bit-for-bit an input value.
+ * ks: host array of 0-based sorted ranks (the caller derives them from alpha).
+ * pre_kth_f32:       scores[N]            -> out[nk]
+ * pre_kth_axis0_f32: scores[n, M] contiguous -> out[nk, M]   (per-cell over the batch axis),
+ *                    n < 65536, nk <= 16. */
+int pre_kth_f32(const float *scores, int64_t N, const int64_t *ks /*host*/, int nk, float *out, void *stream);
+int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks /*host*/, int nk,
+                      float *out, void *stream);
+
+/* ---- a14: emp_cov / emp_cov_joint / filter_sims_joint -----------------------------------
+ * (Joint/Burgers_Residuals_CP.py:298-300; Tests/test_advection_inv_sampling_marginal.py:465)
+ * y: [n, M] contiguous; lo, hi: [M] (broadcast over n) or [n, M] when per_sample_bounds != 0.
+ * pre_cov_count_f32:  count[0] += #{ lo <= y <= hi }           (uint64, caller zeroes)
+ * pre_cov_joint_f32:  inside[i] = all_cells(lo <= y[i] <= hi)  (uint8 per sample; caller fills with 1) */
+int pre_cov_count_f32(const float *y, const float *lo, const float *hi, int64_t n, int64_t M,
+                      int per_sample_bounds, unsigned long long *count, void *stream);
+int pre_cov_joint_f32(const float *y, const float *lo, const float *hi, int64_t n, int64_t M,
+                      int per_sample_bounds, uint8_t *inside, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CP_PRE_HIP_H */

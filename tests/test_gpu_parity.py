@@ -1,0 +1,322 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI via the drop-in
+Python surface, against (1) the committed golden vectors produced by the reference and
+(2) the CPU oracle on seeded inputs.
+
+Tolerances (north_star): residual tensors within 1e-5 tensor-scale relative error
+(max|a-b|/max|b|, SURVEY.md 7 'hard parts'); conformal q-hat within 1e-6 relative - and in
+fact bit-exact wherever the scores are bit-exact, because a radix select returns an input.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+RES_TOL = 1e-5
+QHAT_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    assert torch.cuda.is_available(), "pytest -m gpu needs the MI355X"
+    from cp_pre_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _parse(key):
+    tag, dom, order, taylor, scale = key.split("|")
+    dom = {"none": None, "xy": ("x", "y"), "xyt": ("x", "y", "t"), "xt": ("x", "t")}.get(dom, dom)
+    return tag, dom, int(order), int(taylor), float(scale)
+
+
+# ---------------------------------------------------------------- a4/a5: ConvOperator
+def test_convoperator_matches_reference_golden(gpu, golden):
+    """Every constructible operator of both files on the reference's own D(x) dumps (odd sizes,
+    Nt=1, Y not a multiple of 4: generic kernel; 5^3 / 7^3 Taylor kernels included)."""
+    from cp_pre_amd.convops_1d import ConvOperator as C1
+    from cp_pre_amd.convops_2d import ConvOperator as C2
+    ap = golden["apply"]
+    n = 0
+    for key in ap.files:
+        if not key.startswith("out|") or key.startswith("out|wave"):
+            continue
+        parts = key.split("|")
+        name = parts[-1]
+        tag, dom, order, taylor, scale = _parse("|".join(parts[1:-1]))
+        op = (C2 if tag == "2d" else C1)(dom, order, scale=scale, taylor_order=taylor, device=gpu)
+        x = torch.from_numpy(ap[("in4|" if tag == "2d" else "in3|") + name]).to(gpu)
+        got = op(x)
+        assert got.is_cuda and got.shape == x.shape
+        assert rel_err(got.cpu().numpy(), ap[key]) <= RES_TOL, key
+        n += 1
+    assert n > 60
+
+
+def test_additive_kernel_wave_golden_cpu_and_gpu_tensors(gpu, golden):
+    from cp_pre_amd.residuals import PRE_Wave
+    ap = golden["apply"]
+    w = PRE_Wave(dt=0.01, dx=0.02, c=1.0)
+    assert np.array_equal(w.D.kernel.numpy(), ap["kern|wave"])
+    for name in "abc":
+        x = torch.from_numpy(ap[f"in4|{name}"])
+        got_cpu = w.D(x)                 # CPU tensor in -> staged through the GPU -> CPU tensor out
+        assert not got_cpu.is_cuda
+        assert rel_err(got_cpu.numpy(), ap[f"out|wave|{name}"]) <= RES_TOL
+        assert torch.equal(w.D(x.to(gpu)).cpu(), got_cpu)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 16, 64), (1, 1, 8, 256), (3, 9, 11, 260), (2, 20, 40, 512), (1, 3, 7, 1028)])
+def test_streaming_star_kernel_vs_oracle(gpu, shape):
+    """Aligned, y-contiguous views take the LDS/sliding-window kernel: every tile shape,
+    partial tiles in x and y, t-segments, against the oracle."""
+    from cp_pre_amd.convops_2d import ConvOperator
+    from oracle.cstencil import xcorr_c
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    D = ConvOperator()
+    k = torch.zeros(3, 3, 3)
+    for i, idx in enumerate([(1, 1, 1), (0, 1, 1), (2, 1, 1), (1, 0, 1), (1, 2, 1), (1, 1, 0), (1, 1, 2)]):
+        k[idx] = 0.3 * (i + 1) * (-1) ** i
+    D.kernel = k
+    got = D(x.to(gpu)).cpu().numpy()
+    assert rel_err(got, xcorr_c(x.numpy(), k.numpy())) <= RES_TOL
+
+
+def test_strided_views_and_dense_kernels_vs_oracle(gpu):
+    """What real callers pass (SURVEY 8b layout pitfalls): vars[:,i] of [BS,F,Nt,Nx,Ny] (streaming
+    kernel, batch stride F*vol) and a permuted surrogate output with Nt fastest (generic kernel);
+    plus a dense 27-tap kernel (generic kernel)."""
+    from cp_pre_amd.convops_2d import ConvOperator
+    from oracle.cstencil import xcorr_c
+    g = torch.Generator().manual_seed(3)
+    vars_ = torch.randn(3, 4, 6, 12, 32, generator=g)
+    D = ConvOperator(("x", "y"), 2)
+    got = D(vars_.to(gpu)[:, 2])
+    assert rel_err(got.cpu().numpy(), xcorr_c(vars_[:, 2].contiguous().numpy(), D.kernel.numpy())) <= RES_TOL
+    surrogate = torch.randn(3, 2, 12, 32, 6, generator=g)           # [BS,F,Nx,Ny,Nt]
+    view = surrogate.permute(0, 1, 4, 2, 3)[:, 0]                   # Marginal/Wave_Residuals_CP.py:216
+    got = ConvOperator("t", 2)(view.to(gpu))
+    assert rel_err(got.cpu().numpy(), xcorr_c(view.contiguous().numpy(), ConvOperator("t", 2).kernel.numpy())) <= RES_TOL
+    dense = torch.randn(3, 3, 3, generator=g)
+    Dd = ConvOperator()
+    Dd.kernel = dense
+    x = torch.randn(2, 5, 9, 16, generator=g)
+    assert rel_err(Dd(x.to(gpu)).cpu().numpy(), xcorr_c(x.numpy(), dense.numpy())) <= RES_TOL
+    # convolution(field, kernel) replaces the operator's kernel (Utils/ConvOps_2d.py:146-147)
+    Dd.convolution(x.to(gpu), D.kernel)
+    assert Dd.kernel is D.kernel
+
+
+def test_vector_ops_vs_oracle(gpu):
+    from cp_pre_amd import vector_convops as V
+    from oracle import convops as ocv
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(2, 6, 10, 16, generator=g), torch.randn(2, 6, 10, 16, generator=g)
+    ad, bd = a.to(gpu), b.to(gpu)
+    for name in ("Divergence", "Curl"):
+        got = getattr(V, name)()(ad, bd).cpu().numpy()
+        assert rel_err(got, getattr(ocv, name)()(a, b).numpy()) <= RES_TOL, name
+    for name in ("Gradient", "Laplace"):
+        got = getattr(V, name)()(ad, bd).cpu().numpy()
+        assert got.shape == (2,) + tuple(a.shape)
+        assert rel_err(got, getattr(ocv, name)()(a, b).numpy()) <= RES_TOL, name
+    assert torch.equal(V.cross((ad, bd), (bd, ad)).cpu(), ocv.cross((a, b), (b, a)))
+    assert torch.equal(V.dot((ad, bd), (bd, ad)).cpu(), ocv.dot((a, b), (b, a)))
+
+
+# ---------------------------------------------------------------- a9: fused residuals
+def _residual_cases(v6, u1, g):
+    from cp_pre_amd import residuals as R
+    dt, dx, dy = g["coef"].tolist()
+    bdx, bdt, bnu = g["burgers_coef"].tolist()
+    ns = lambda f: R.NavierStokes(dt, dx, dy, fused=f)            # noqa: E731
+    mhd = lambda f: R.MHD(fused=f)                                # noqa: E731
+    return {
+        "PRE_Wave": lambda b, f: R.PRE_Wave(dt=0.01, dx=0.02, c=1.0).residual(v6[:, :1], boundary=b),
+        "PRE_NS": lambda b, f: R.PRE_NS(dt, dx, dy, fused=f).residual(v6[:, :3], boundary=b),
+        "PRE_MHD": lambda b, f: R.PRE_MHD(dt, dx, dy, fused=f).residual(v6, boundary=b),
+        "ns_continuity": lambda b, f: ns(f).residual_continuity(v6[:, :2], boundary=b),
+        "ns_momentum": lambda b, f: ns(f).residual_momentum(v6[:, :3], boundary=b),
+        "mhd_continuity": lambda b, f: mhd(f).residual_continuity(v6, boundary=b),
+        "mhd_momentum": lambda b, f: mhd(f).residual_momentum(v6, boundary=b),
+        "mhd_energy": lambda b, f: mhd(f).residual_energy(v6, boundary=b),
+        "mhd_induction": lambda b, f: mhd(f).residual_induction(v6, boundary=b),
+        "mhd_gauss": lambda b, f: mhd(f).residual_gauss(v6, boundary=b),
+        "burgers": lambda b, f: R.Burgers(bdx, bdt, bnu, fused=f).residual(u1, boundary=b),
+        "advection": lambda b, f: R.Advection(1.0, 0.005, 0.01, disc=2).residual(u1, boundary=b),
+    }
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_residuals_match_reference_golden(gpu, golden, fused):
+    """All residual equations, fused single pass and operator-by-operator composition, against
+    outputs of the reference's own residual functions (Y=12 / X=14: generic + streaming mix)."""
+    g = golden["residuals"]
+    v6 = torch.from_numpy(g["vars6"]).to(gpu)
+    u1 = torch.from_numpy(g["u1d"]).to(gpu)
+    for name, fn in _residual_cases(v6, u1, g).items():
+        for b in (0, 1):
+            got = fn(bool(b), fused)
+            assert got.is_cuda
+            ref = g[f"{name}|{b}"]
+            assert tuple(got.shape) == ref.shape, name
+            assert rel_err(got.cpu().numpy(), ref) <= RES_TOL, (name, b, fused)
+
+
+def test_fused_residuals_streaming_sizes_vs_oracle(gpu):
+    """Same equations at sizes that take the fused streaming kernels (Y % 4 == 0, several tiles)."""
+    from cp_pre_amd import residuals as R
+    from oracle import residuals as orr
+    g = torch.Generator().manual_seed(11)
+    v6 = torch.rand(3, 6, 9, 20, 264, generator=g) + 0.5
+    d6 = v6.to(gpu)
+    dt, dx, dy = 0.01, 1 / 64, 1 / 48
+    ns, mhd = R.NavierStokes(dt, dx, dy), R.MHD()
+    pairs = {
+        "ns_momentum": (ns.residual_momentum(d6[:, :3], True), orr.ns_momentum(v6[:, :3], dt, dx, dy, boundary=True)),
+        "ns_continuity": (ns.residual_continuity(d6[:, :2], True), orr.ns_continuity(v6[:, :2], dx, dy, boundary=True)),
+        "mhd_continuity": (mhd.residual_continuity(d6, True), orr.mhd_continuity(v6, boundary=True)),
+        "mhd_momentum": (mhd.residual_momentum(d6, True), orr.mhd_momentum(v6, boundary=True)),
+        "mhd_energy": (mhd.residual_energy(d6, True), orr.mhd_energy(v6, boundary=True)),
+        "mhd_induction": (mhd.residual_induction(d6, True), orr.mhd_induction(v6, boundary=True)),
+        "mhd_gauss": (mhd.residual_gauss(d6, True), orr.mhd_gauss(v6, boundary=True)),
+    }
+    for name, (got, ref) in pairs.items():
+        assert rel_err(got.cpu().numpy(), ref.numpy()) <= RES_TOL, name
+    u1 = torch.rand(70, 33, 128, generator=g) + 0.5
+    got = R.Burgers(2 / 128, 1.25 / 33, 0.002).residual(u1.to(gpu), boundary=True)
+    assert rel_err(got.cpu().numpy(), orr.burgers_residual(u1, 2 / 128, 1.25 / 33, 0.002, boundary=True).numpy()) <= RES_TOL
+    # absolute=True is |residual| (marginal score), identical bits to abs() of the residual
+    a = ns.residual_momentum(d6[:, :3], True, absolute=True)
+    assert torch.equal(a, ns.residual_momentum(d6[:, :3], True).abs())
+    # y_axis_fix (physically intended D_y; NOT reference parity) differs from strict mode and
+    # equals the composition with an Ny-axis operator
+    fix = R.NavierStokes(dt, dx, dy, y_axis_fix=True)
+    rf = fix.residual_momentum(d6[:, :3], True)
+    assert rel_err(rf.cpu().numpy(), R.NavierStokes(dt, dx, dy, y_axis_fix=True, fused=False)
+                   .residual_momentum(d6[:, :3], True).cpu().numpy()) <= RES_TOL
+    assert rel_err(rf.cpu().numpy(), pairs["ns_momentum"][1].numpy()) > 1e-3
+
+
+def test_linearity_and_shift_properties_large(gpu):
+    """Size-independent properties at a BASELINE-scale plane (512x512): D(a*x+b*y) = a*D(x)+b*D(y);
+    a constant field has zero Laplacian away from the zero-padded rim; D_t of a t-ramp is 2."""
+    from cp_pre_amd.convops_2d import ConvOperator
+    g = torch.Generator(device="cpu").manual_seed(2)
+    x = torch.randn(4, 8, 512, 512, generator=g).to(gpu)
+    y = torch.randn(4, 8, 512, 512, generator=g).to(gpu)
+    L = ConvOperator(("x", "y"), 2, device=gpu)
+    lhs = L(2.0 * x - 0.5 * y)
+    rhs = 2.0 * L(x) - 0.5 * L(y)
+    assert (lhs - rhs).abs().max().item() <= 1e-5 * rhs.abs().max().item()
+    ones = torch.ones(2, 4, 512, 512, device=gpu)
+    assert L(ones)[..., 1:-1, 1:-1].abs().max().item() == 0.0
+    assert (L(ones)[..., 0, 1:-1] == -1.0).all()                      # zero padding, not periodic
+    ramp = torch.arange(8, dtype=torch.float32, device=gpu).view(1, 8, 1, 1).expand(2, 8, 512, 512).contiguous()
+    assert (ConvOperator("t", 1, device=gpu)(ramp)[:, 1:-1] == 2.0).all()
+
+
+# ---------------------------------------------------------------- a10-a14: conformal
+def test_conformal_golden_vectors(gpu, golden):
+    """Build-defined numpy vectors (parity with the reference's absent inductive_cp is unpinned)."""
+    from cp_pre_amd import inductive_cp as icp
+    from oracle import conformal as oc
+    g = golden["conformal"]
+    for n in (7, 100, 256):
+        s, r = g[f"scores|{n}"], g[f"res|{n}"]
+        mod = icp.modulation_func(r, np.zeros_like(r))
+        assert mod.dtype == np.float32 and np.array_equal(mod, g[f"mod|{n}"])       # numpy-order std: bit exact
+        js = icp.ncf_metric_joint(r, np.zeros_like(r), mod)
+        assert np.array_equal(js, g[f"jscore|{n}"])
+        alphas = [a for i, a in enumerate(oc.ALPHA_LEVELS) if int(g[f"k|{n}|{i}"]) >= 0]
+        multi = icp.calibrate_multi(s, n, alphas)
+        j = 0
+        for i, a in enumerate(oc.ALPHA_LEVELS):
+            if int(g[f"k|{n}|{i}"]) < 0:
+                with pytest.raises(ValueError):
+                    icp.calibrate(s, n, a)
+                continue
+            q = icp.calibrate(s, n, a)
+            assert np.array_equal(q, g[f"qhat|{n}|{i}"]) and np.array_equal(multi[j], q)
+            qj = icp.calibrate(js, n, a)
+            assert qj == g[f"qhat_joint|{n}|{i}"]
+            assert icp.emp_cov([-q, q], r) == pytest.approx(float(g[f"cov|{n}|{i}"]), abs=1e-12)
+            assert icp.emp_cov_joint([-qj * mod, qj * mod], r) == pytest.approx(float(g[f"cov_joint|{n}|{i}"]), abs=1e-12)
+            j += 1
+
+
+@pytest.mark.parametrize("n,cells", [(33, (5, 7)), (512, (3, 40, 50)), (1000, (4099,)), (4096, (2, 16, 48))])
+def test_marginal_qhat_bit_exact_vs_numpy(gpu, n, cells):
+    """Per-cell radix select over the batch axis: ragged cell counts, ties, negatives, +-0, inf."""
+    from cp_pre_amd import inductive_cp as icp
+    from oracle import conformal as oc
+    rng = np.random.default_rng(n)
+    s = (rng.standard_normal((n,) + cells) * np.exp(rng.standard_normal(cells) * 3)).astype(np.float32)
+    s[: n // 4, ..., 0] = 1.5
+    s[n // 2, ..., -1] = np.inf
+    s[0].flat[:3] = [0.0, -0.0, -np.inf]
+    alphas = [a for a in oc.ALPHA_LEVELS if oc.quantile_level(n, a) <= 1]
+    got = icp.calibrate_multi(torch.from_numpy(s).to(gpu), n, alphas).cpu().numpy()
+    for j, a in enumerate(alphas):
+        assert np.array_equal(got[j], oc.calibrate(s, n, a)), (n, a)
+    # |res| scores as the pipeline produces them
+    a_ = np.abs(s[:, ..., 1:-1]) if s.ndim > 2 else np.abs(s)
+    a_[~np.isfinite(a_)] = 0
+    q = icp.calibrate(a_, n, 0.1)
+    assert np.array_equal(q, oc.calibrate(a_, n, 0.1))
+
+
+def test_joint_recipe_vs_numpy(gpu):
+    """modulation -> per-sample score -> scalar q-hat -> bounds -> joint coverage; q-hat within 1e-6."""
+    from cp_pre_amd import inductive_cp as icp
+    from oracle import conformal as oc
+    rng = np.random.default_rng(1)
+    n = 2000
+    res = (rng.standard_normal((n, 6, 10, 12)) * (1 + rng.random((6, 10, 12)))).astype(np.float32)
+    pred = (res[:500] * 0.9).astype(np.float32)
+    # (1) fp32 second argument: numpy computes in fp32 -> bit-exact
+    b32 = (0.1 * rng.standard_normal(res.shape)).astype(np.float32)
+    mod = icp.modulation_func(res, b32)
+    assert np.array_equal(mod, oc.modulation_func(res, b32))
+    sc = icp.ncf_metric_joint(res, b32, mod)
+    assert np.array_equal(sc, oc.ncf_metric_joint(res, b32, mod))
+    # (2) the scripts' np.zeros(res.shape) (float64): numpy promotes to float64
+    z = np.zeros(res.shape)
+    mod64 = icp.modulation_func(res, z)
+    ref64 = oc.modulation_func(res, z)
+    assert mod64.dtype == ref64.dtype == np.float64
+    assert np.max(np.abs(mod64 - ref64) / ref64) <= QHAT_TOL
+    sc64 = icp.ncf_metric_joint(res, z, mod64)
+    ref_sc = oc.ncf_metric_joint(res, z, ref64)
+    assert np.max(np.abs(sc64 - ref_sc) / ref_sc) <= QHAT_TOL
+    for a in oc.ALPHA_LEVELS:
+        q, qr = icp.calibrate(sc64, n, a), oc.calibrate(ref_sc, n, a)
+        assert abs(q - qr) <= QHAT_TOL * abs(qr)
+        sets = [-qr * ref64, qr * ref64]
+        assert icp.emp_cov_joint(sets, pred) == pytest.approx(oc.emp_cov_joint(sets, pred), abs=1e-12)
+        assert np.array_equal(icp.filter_sims_joint(sets, pred), oc.filter_sims_joint(sets, pred))
+    # eps of Joint/MHD_Residuals_CP.py:350 and the fused interior crop
+    assert np.array_equal(icp.modulation_func(res, b32, eps=1e-6), oc.modulation_func(res, b32) + np.float32(1e-6))
+    full = torch.from_numpy(res).to(gpu)
+    m_full = icp.modulation_func(full, None)
+    s_crop = icp.ncf_metric_joint(full, None, m_full, crop=1).cpu().numpy()
+    inner = res[:, 1:-1, 1:-1, 1:-1]
+    assert np.array_equal(s_crop, oc.ncf_metric_joint(inner, np.zeros_like(inner), oc.modulation_func(inner, np.zeros_like(inner))))
+
+
+def test_scalar_kth_large_and_absdiff(gpu):
+    from cp_pre_amd import _lib, inductive_cp as icp
+    rng = np.random.default_rng(9)
+    s = rng.standard_normal(65536).astype(np.float32)
+    srt = np.sort(s)
+    ks = [0, 1, 3277, 32768, 65535]
+    got = icp.kth_axis0(torch.from_numpy(s).to(gpu), ks).cpu().numpy()
+    assert np.array_equal(got, srt[ks])
+    a = torch.randn(1000003, device=gpu)
+    b = torch.randn(1000003, device=gpu)
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().pre_absdiff_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), _lib.stream()), "absdiff")
+    assert torch.equal(out, (a - b).abs())
