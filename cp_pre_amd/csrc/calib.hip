@@ -8,6 +8,10 @@
 // state (running sums, radix prefixes) lives in registers and never crosses lanes.
 #include "common.h"
 
+// The reductions below reproduce numpy's operation order: a*b+c must stay two roundings.
+// This file is compiled with -ffp-contract=off (csrc/Makefile); the pragma covers other builds.
+#pragma clang fp contract(off)
+
 namespace {
 
 // ------------------------------------------------------------------ |a-b|
@@ -46,18 +50,19 @@ __global__ void __launch_bounds__(256) std_axis0_kernel(const float *__restrict_
     float s = 0.f;
 #pragma unroll 8
     for (int i = 0; i < n; ++i) {
-        const float v = pb ? __fsub_rn(pa[(long long)i * M], pb[(long long)i * M]) : pa[(long long)i * M];
-        s = __fadd_rn(s, v);
+        const float v = pb ? pa[(long long)i * M] - pb[(long long)i * M] : pa[(long long)i * M];
+        s = s + v;
     }
-    const float mean = __fdiv_rn(s, (float)n);
+    const float mean = s / (float)n;
     float acc = 0.f;
 #pragma unroll 8
     for (int i = 0; i < n; ++i) {
-        const float v = pb ? __fsub_rn(pa[(long long)i * M], pb[(long long)i * M]) : pa[(long long)i * M];
-        const float d = __fsub_rn(v, mean);
-        acc = __fadd_rn(acc, __fmul_rn(d, d));
+        const float v = pb ? pa[(long long)i * M] - pb[(long long)i * M] : pa[(long long)i * M];
+        const float d = v - mean;
+        const float dd = d * d;
+        acc = acc + dd;
     }
-    mod[c] = __fadd_rn(__fsqrt_rn(__fdiv_rn(acc, (float)n)), eps);
+    mod[c] = sqrtf(acc / (float)n) + eps;
 }
 
 // ------------------------------------------------------------------ streaming moments (fp64)
@@ -73,7 +78,7 @@ __global__ void __launch_bounds__(256) moments_kernel(const float *__restrict__ 
 #pragma unroll 8
     for (int i = i0; i < i1; ++i) {
         float v = a[(long long)i * M + c];
-        if (b) v = __fsub_rn(v, b[(long long)i * M + c]);
+        if (b) v = v - b[(long long)i * M + c];
         const double d = (double)v;
         s += d;
         q += d * d;
@@ -90,7 +95,7 @@ __global__ void __launch_bounds__(256) std_from_moments_kernel(const double *__r
     const double mean = sum[c] / n_total;
     double var = sumsq[c] / n_total - mean * mean;
     var = var > 0.0 ? var : 0.0;
-    mod[c] = __fadd_rn((float)sqrt(var), eps);
+    mod[c] = (float)sqrt(var) + eps;
 }
 
 // ------------------------------------------------------------------ joint score

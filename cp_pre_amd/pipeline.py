@@ -1,0 +1,139 @@
+"""Streaming calibration drivers: residual tensors larger than HBM are processed slab by
+slab (or batch chunk by batch chunk) while only small calibration state stays resident.
+
+Hot-path position: the step right after ``residual(...)`` in the reference scripts -
+``Joint/Burgers_Residuals_CP.py:272-285`` (modulation -> per-sample score -> scalar q-hat)
+and ``Marginal/Wave_Residuals_CP.py:280-290`` (per-cell q-hat) - restated for tensors that
+the reference holds whole in host RAM (n_cal <= 1000 there) but BASELINE configs cannot
+(C3: 275 GB per field).
+
+``ops`` is the compute back end.  The product back end is :class:`HipOps` (C ABI calls on
+device tensors).  Tests inject a numpy back end to exercise the sharding / collective
+logic under ``gloo`` on CPU; nothing in this package constructs one.
+
+Multi-GPU (one process per GPU, batch axis sharded, ``group`` = a ``torch.distributed``
+process group over RCCL/xGMI):
+  * joint: the per-cell moments are summed with ONE all-reduce per slab (fp64, 16 B per cell),
+    the per-sample scores travel in ONE all-gather at the end (4 B per sample);
+  * marginal: per-cell order statistics need every sample of a cell in one place: an
+    all-to-all turns the batch sharding into a cell sharding, each rank selects its cells,
+    and an all-gather returns the q-hat field.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from . import inductive_cp as icp
+
+
+class HipOps:
+    """Device back end: every method is one or two ``libcp_pre_hip.so`` launches."""
+
+    @staticmethod
+    def zeros_moments(M, device):
+        return torch.zeros(2, M, dtype=torch.float64, device=device)
+
+    @staticmethod
+    def add_moments(res, mom):
+        n, M = res.shape[0], res.numel() // res.shape[0]
+        with torch.cuda.device(res.device):
+            _lib.check(_lib.load().pre_moments_axis0_f64(_lib.ptr(res), None, n, M, _lib.ptr(mom[0]), _lib.ptr(mom[1]),
+                                                         _lib.stream()), "pre_moments_axis0_f64")
+
+    @staticmethod
+    def std_from_moments(mom, n_total, shape, eps):
+        M = mom.shape[1]
+        mod = torch.empty(shape, dtype=torch.float32, device=mom.device)
+        with torch.cuda.device(mom.device):
+            _lib.check(_lib.load().pre_std_from_moments_f32(_lib.ptr(mom[0]), _lib.ptr(mom[1]), n_total, M, float(eps),
+                                                            _lib.ptr(mod), _lib.stream()), "pre_std_from_moments_f32")
+        return mod
+
+    @staticmethod
+    def zeros_scores(n, device):
+        return torch.zeros(n, dtype=torch.float32, device=device)
+
+    @staticmethod
+    def max_scores(res, mod, crop, scores):
+        """scores[i] = max(scores[i], max_cells |res[i]|/mod) over the cropped interior."""
+        n, (T, X, Y) = res.shape[0], res.shape[1:]
+        ct, cx, cy = crop
+        with torch.cuda.device(res.device):
+            _lib.check(_lib.load().pre_joint_score_f32(_lib.ptr(res), None, _lib.ptr(mod), n, T, X, Y, ct, cx, cy,
+                                                       _lib.ptr(scores), _lib.stream()), "pre_joint_score_f32")
+
+    @staticmethod
+    def kth(scores, ks):
+        return icp.kth_axis0(scores, ks)
+
+
+def _ranks(n_total, alphas):
+    return [icp.kth_index(n_total, n_total, a) for a in alphas]
+
+
+class JointCalibration:
+    """Joint CP over a calibration set streamed as T-slabs of [n_local, T_slab, X, Y] residuals.
+
+    Per slab (all local samples, a few time planes): ``add_slab(res, crop)`` accumulates the
+    per-cell moments, all-reduces them across ranks, finishes the modulation for those planes
+    and max-accumulates every local sample's score.  ``finish(alphas)`` all-gathers the scores
+    and selects the q-hats.  A per-cell std needs all samples but only its own cell, and a
+    per-sample max composes across slabs, so one sweep over the data suffices.
+    """
+
+    def __init__(self, n_local, device, eps=0.0, group=None, ops=None):
+        self.ops = ops or HipOps
+        self.group, self.eps, self.n_local, self.device = group, eps, n_local, device
+        self.world = torch.distributed.get_world_size(group) if group is not None else 1
+        self.n_total = n_local * self.world
+        self.scores = self.ops.zeros_scores(n_local, device)
+        self.modulation = []           # one [T_slab, X, Y] array per slab, in call order
+
+    def add_slab(self, res, crop=(1, 1, 1)):
+        ops = self.ops
+        M = res[0].numel() if hasattr(res[0], "numel") else res[0].size
+        mom = ops.zeros_moments(M, self.device)
+        ops.add_moments(res, mom)
+        if self.group is not None:
+            torch.distributed.all_reduce(mom, group=self.group)          # RCCL: sum of (sum, sumsq) per cell
+        mod = ops.std_from_moments(mom, self.n_total, tuple(res.shape[1:]), self.eps)
+        ops.max_scores(res, mod, crop, self.scores)
+        self.modulation.append(mod)
+        return mod
+
+    def finish(self, alphas):
+        scores = self.scores
+        if self.group is not None:
+            gathered = [torch.empty_like(scores) for _ in range(self.world)]
+            torch.distributed.all_gather(gathered, scores, group=self.group)   # RCCL: n_local floats per rank
+            scores = torch.cat(gathered)
+        self.all_scores = scores
+        return self.ops.kth(scores, _ranks(self.n_total, alphas))
+
+
+def marginal_qhat(scores, alphas, group=None, ops=None):
+    """Per-cell q-hat [len(alphas), *cells] of |residual| scores [n_local, *cells].
+
+    Single rank: one multi-rank radix select.  Sharded: all-to-all (batch-sharded ->
+    cell-sharded), local select over all ``n_local * world`` samples, all-gather of the result."""
+    ops = ops or HipOps
+    n_local, cells = scores.shape[0], tuple(scores.shape[1:])
+    if group is None:
+        return ops.kth(scores, _ranks(n_local, alphas))
+    world = torch.distributed.get_world_size(group)
+    flat = scores.reshape(n_local, -1)
+    M = flat.shape[1]
+    per = (M + world - 1) // world
+    send = flat.new_zeros(world, n_local, per)
+    for r in range(world):                                   # rank r will own cells [r*per, (r+1)*per)
+        w = max(0, min(per, M - r * per))
+        send[r, :, :w] = flat[:, r * per:r * per + w]
+    recv = torch.empty_like(send)
+    torch.distributed.all_to_all_single(recv, send, group=group)          # RCCL: 7/8 of the local scores leave
+    mine = recv.reshape(world * n_local, per)                # every sample of my cells
+    q_local = ops.kth(mine, _ranks(n_local * world, alphas))              # [nk, per]
+    parts = [torch.empty_like(q_local) for _ in range(world)]
+    torch.distributed.all_gather(parts, q_local.contiguous(), group=group)
+    q = torch.cat(parts, dim=1)[:, :M]
+    return q.reshape((len(alphas),) + cells)

@@ -101,13 +101,18 @@ class NavierStokes(_Residual2D):
             res = _on_device((u, v), lambda u, v: self.D_x(u) + ratio * self.D_y(v))
         return _finish(res, boundary, _CROP3, absolute, done_abs)
 
-    def residual_momentum(self, vars, boundary=False, absolute=False):
+    def residual_momentum(self, vars, boundary=False, absolute=False, out=None):
+        """``out``: optional preallocated contiguous device tensor [BS,Nt,Nx,Ny] for the
+        uncropped residual (fused route only; lets a streaming driver reuse one buffer)."""
         u, v, p = vars[:, 0], vars[:, 1], vars[:, 2]
         dt, dx, dy, nu = self.dt, self.dx, self.dy, self.nu
         ks = self._k27(self.D_t, self.D_x, self.D_y, self.D_xx_yy) if self.fused else None
         if ks is not None:
             (du, dv, dp), origin = _stage((u, v, p))
-            out = torch.empty(du.shape, dtype=torch.float32, device=du.device)
+            if out is None:
+                out = torch.empty(du.shape, dtype=torch.float32, device=du.device)
+            elif not (out.is_cuda and out.is_contiguous() and out.shape == du.shape and out.dtype == torch.float32):
+                raise ValueError("out must be a contiguous fp32 device tensor of the field shape")
             fu, fv, fp = _lib.field(du), _lib.field(dv), _lib.field(dp)
             with torch.cuda.device(du.device):
                 ok = _fused_call("pre_residual_ns_momentum_f32", lambda: _lib.load().pre_residual_ns_momentum_f32(
