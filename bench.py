@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py - residual-cells/s of the PRE hot path (eval + calibrate) on MI355X.
+
+Workload (BASELINE.json configs[2], the one the north_star target is quoted on): 2-D
+Navier-Stokes momentum residual of (u, v, p) on [4096, 64, 512, 512] fp32 per rank, followed
+by conformal calibration over the 4096 samples at the reference's 10 alpha levels.
+
+One field of that shape is 275 GB, so the tensor is streamed as 8 t-slabs of
+[4096, 10, 512, 512] (8 interior planes + the 2 halo planes their stencils read); the three
+input slabs (129 GB) and the residual slab (43 GB) are resident in HBM before the timed
+region.  Synthetic data: the same resident slab stands in for each of the 8 slab positions
+(825 GB of distinct input cannot be resident; the arithmetic and traffic per slab do not
+depend on the values).  One STEP = the whole [4096,64,512,512] job = 8 slab passes of
+    fused NS-momentum residual (one HIP launch)  ->  calibration on the resident residual slab
+and the final q-hat selection.  cells/step = 4096*64*512*512 (uncropped grid).
+
+--mode joint (default; Joint/NS_Residuals_CP.py recipe): per-cell moments -> modulation ->
+    per-sample max|r|/sigma -> scalar q-hat x 10.  N>1: batch-sharded, weak scaling, one RCCL
+    all-reduce of the moments per slab and ONE all-gather of the per-sample scores.
+--mode marginal (Marginal/NS_Residuals_CP.py recipe): |r| -> per-cell q-hat x 10 by radix
+    select over the batch axis.  N>1: all-to-all (batch-sharded -> cell-sharded) per slab.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (fused
+residual kernel, HIP events on its stream) and `cpu_baseline` (the CPU oracle = the
+reference's own F.conv3d arithmetic, timed on this box's host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+NS_BYTES_PER_CELL = 16         # 3 fields read + 1 residual written, fp32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=["joint", "marginal"], default="joint")
+    ap.add_argument("--batch", type=int, default=4096, help="samples per rank (BASELINE C3: 4096)")
+    ap.add_argument("--nt", type=int, default=64)
+    ap.add_argument("--nx", type=int, default=512)
+    ap.add_argument("--ny", type=int, default=512)
+    ap.add_argument("--slab", type=int, default=8, help="interior planes per t-slab")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, alphas):
+    """The oracle (reference arithmetic: F.conv3d per operator + torch elementwise + numpy
+    calibration) on a bounded sample of the same workload, on this box's host cores."""
+    import numpy as np
+    from oracle import conformal as oc
+    from oracle import residuals as orr
+    T = args.slab + 2
+    dt, dx, dy = 1e-2, 1.0 / args.nx, 1.0 / args.ny
+    threads = torch.get_num_threads()
+
+    def run(nb):
+        g = torch.Generator().manual_seed(0)
+        v = torch.rand(nb, 3, T, args.nx, args.ny, generator=g) + 0.5
+        t0 = time.perf_counter()
+        res = orr.ns_momentum(v, dt, dx, dy, boundary=False).contiguous().numpy()
+        if args.mode == "joint":
+            mod = oc.modulation_func(res, np.zeros_like(res))
+            sc = oc.ncf_metric_joint(res, np.zeros_like(res), mod)
+            [oc.calibrate(sc, nb, a) for a in alphas if oc.quantile_level(nb, a) <= 1]
+        else:
+            s = np.abs(res)
+            [oc.calibrate(s, nb, a) for a in alphas if oc.quantile_level(nb, a) <= 1]
+        return time.perf_counter() - t0
+
+    t_probe = run(4)
+    nb = int(max(4, min(256, 4 * args.cpu_seconds / max(t_probe, 1e-3))))
+    t = run(nb)
+    cells = nb * args.slab * args.nx * args.ny            # useful (interior-plane) cells, as in `value`
+    return {"value": cells / t, "unit": "cells/s", "cores": threads, "kind": "port",
+            "sample": f"oracle NS-momentum + {args.mode} calibrate on [{nb},{T},{args.nx},{args.ny}] x3 fields "
+                      f"(one slab, {nb}/{args.batch} of the batch), {t:.1f} s on {threads} torch threads"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        group = dist.group.WORLD
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    from cp_pre_amd.residuals import NavierStokes
+
+    B, T, X, Y = args.batch, args.slab + 2, args.nx, args.ny
+    n_slabs = max(1, args.nt // args.slab)
+    alphas = [float(a) for a in icp.ALPHA_LEVELS]
+    dt, dx, dy = 1e-2, 1.0 / X, 1.0 / Y
+    ns = NavierStokes(dt, dx, dy, nu=1e-3)
+
+    # resident synthetic slab: vars[:, i] views of one [B,3,T,X,Y] tensor, like the reference's `vars`
+    torch.manual_seed(1234 + rank)
+    vars_ = torch.empty(B, 3, T, X, Y, dtype=torch.float32, device=dev)
+    for i in range(3):
+        vars_[:, i].uniform_(0.5, 1.5)
+    res = torch.empty(B, T, X, Y, dtype=torch.float32, device=dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(n_slabs * (args.steps + args.warmup))]
+    ev_used = []
+
+    def step(k):
+        jc = pipeline.JointCalibration(B, dev, group=group) if args.mode == "joint" else None
+        q = None
+        for s in range(n_slabs):
+            e0, e1 = ev[k * n_slabs + s]
+            e0.record()
+            ns.residual_momentum(vars_, boundary=True, absolute=(args.mode == "marginal"), out=res)
+            e1.record()
+            ev_used.append((k, e0, e1))
+            if jc is not None:
+                jc.add_slab(res, crop=(1, 1, 1))
+            else:
+                q = pipeline.marginal_qhat(res, alphas, group=group)     # [10, T, X, Y]; caller keeps planes 1..T-2
+        return jc.finish(alphas) if jc is not None else q
+
+    def sync():
+        torch.cuda.synchronize()
+        if group is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        qhat = step(k)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if group is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    cells_per_step = B * n_slabs * args.slab * X * Y * world          # whole job, all ranks
+    value = cells_per_step * args.steps / elapsed
+
+    if rank == 0:
+        durs = [e0.elapsed_time(e1) for (k, e0, e1) in ev_used if k >= args.warmup]     # ms, this rank
+        kms = sum(durs) / len(durs)
+        launch_bytes = NS_BYTES_PER_CELL * B * T * X * Y
+        achieved = launch_bytes / (kms * 1e-3) / 1e9
+        out = {
+            "metric": "residual-cells/s (PRE eval+calibrate)",
+            "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic U(0.5,1.5) fields; one resident t-slab reused for the 8 slab positions",
+            "config": {"workload": f"C3 2D Navier-Stokes momentum residual [{B},{args.nt},{X},{Y}] x3 fields per rank, "
+                                   f"{args.mode} CP, 10 alpha levels; streamed as {n_slabs} t-slabs of [{B},{T},{X},{Y}]",
+                       "mode": args.mode, "batch_per_rank": B, "parallelism": f"batch-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "march_kernel<NSMomentum<0>,8,64>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_ms": kms, "algorithmic_bytes_per_launch": launch_bytes},
+            "qhat_first_last": [float(qhat.reshape(len(alphas), -1)[0, 0]), float(qhat.reshape(len(alphas), -1)[-1, 0])],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del vars_, res
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args, alphas)
+        print(json.dumps(out), flush=True)
+    if group is not None:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
