@@ -320,3 +320,38 @@ def test_scalar_kth_large_and_absdiff(gpu):
     out = torch.empty_like(a)
     _lib.check(_lib.load().pre_absdiff_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), _lib.stream()), "absdiff")
     assert torch.equal(out, (a - b).abs())
+
+
+# ---------------------------------------------------------------- streaming pipeline (HipOps)
+def test_pipeline_slabs_equal_whole_tensor(gpu):
+    """t-slab streaming (what bench.py runs) == whole-tensor recipe: NS residual -> joint CP and
+    marginal CP, every stage on the HIP path, against the oracle on the full tensor."""
+    from cp_pre_amd import pipeline
+    from cp_pre_amd.residuals import NavierStokes
+    from oracle import conformal as oc
+    from oracle import residuals as orr
+    g = torch.Generator().manual_seed(21)
+    n, T, X, Y = 40, 14, 12, 64
+    v = torch.rand(n, 3, T, X, Y, generator=g) + 0.5
+    dt, dx, dy = 0.01, 1 / 64, 1 / 64
+    ref = orr.ns_momentum(v, dt, dx, dy, boundary=False).contiguous().numpy()         # [n,T-2,X-2,Y-2]
+    ns = NavierStokes(dt, dx, dy)
+    vd = v.to(gpu)
+    alphas = [0.1, 0.5, 0.9]
+    jc = pipeline.JointCalibration(n, gpu)
+    qm_parts = []
+    for t0 in range(0, T - 2, 4):                         # slabs of 4 interior planes + 2 halo planes
+        slab = vd[:, :, t0:t0 + 6]
+        res = ns.residual_momentum(slab, boundary=True)
+        jc.add_slab(res, crop=(1, 1, 1))
+        qm_parts.append(pipeline.marginal_qhat(res.abs(), alphas)[:, 1:-1, 1:-1, 1:-1])
+    q = jc.finish(alphas).cpu().numpy()
+    mod_ref = oc.modulation_func(ref.astype(np.float64), np.zeros(ref.shape))
+    sc_ref = oc.ncf_metric_joint(ref, np.zeros(ref.shape), mod_ref)
+    for j, a in enumerate(alphas):
+        qr = oc.calibrate(sc_ref, n, a)
+        assert abs(q[j] - qr) <= 1e-5 * abs(qr)          # residual tolerance (1e-5) propagates into the score
+    qm = torch.cat(qm_parts, dim=1).cpu().numpy()
+    qm_ref = np.stack([oc.calibrate(np.abs(ref), n, a) for a in alphas])
+    assert qm.shape == qm_ref.shape
+    assert rel_err(qm, qm_ref) <= RES_TOL
