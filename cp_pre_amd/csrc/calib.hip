@@ -106,8 +106,22 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// grid (row-chunks, n); one block reduces RB rows (t,x) of sample blockIdx.y
-constexpr int JS_RB = 8;
+// grid (row-chunks, n); one block reduces JS_RB rows (t,x) of sample blockIdx.y.
+// max_i |v_i|/s_i with IEEE division on every element would make the pass VALU-bound (a
+// correctly rounded fp32 divide is ~10 instructions).  Each lane keeps its exact running
+// maximum m and first tests |v| > m(1-2^-20)*s (one multiply, one compare): a quotient that
+// rounds above m always passes (|v|/s >= q(1-2^-24) > m(1-2^-24)), so only the few candidates
+// that can raise the maximum pay for the exact divide, and the result is bit-identical to
+// dividing everything.
+constexpr int JS_RB = 32;
+__device__ __forceinline__ void js_update(float av, float sv, float &m, float &thr)
+{
+    if (av > thr * sv || sv == 0.f) {
+        const float q = av / sv;
+        if (q > m) { m = q; thr = m * 0.99999905f; }
+    }
+}
+
 __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                           const float *__restrict__ mod, int T, int X, int Y,
                                                           int ct, int cx, int cy, float *__restrict__ scores)
@@ -117,36 +131,57 @@ __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restric
     const float *pa = a + smp * vol, *pb = b ? b + smp * vol : nullptr;
     const long long r0 = (long long)blockIdx.x * JS_RB, nrows = (long long)T * X;
     const bool vec = (Y % 4 == 0) && !(((uintptr_t)a | (uintptr_t)mod | (uintptr_t)(b ? b : a)) & 15);
-    float m = 0.f;
-    for (int rr = 0; rr < JS_RB; ++rr) {
-        const long long r = r0 + rr;
-        if (r >= nrows) break;
-        const int t = (int)(r / X), x = (int)(r % X);
-        if (t < ct || t >= T - ct || x < cx || x >= X - cx) continue;
-        const long long ro = r * Y;
-        if (vec) {
-            for (int y = threadIdx.x * 4; y < Y; y += blockDim.x * 4) {
-                float4 v = *reinterpret_cast<const float4 *>(pa + ro + y);
-                if (pb) { const float4 w = *reinterpret_cast<const float4 *>(pb + ro + y); v = make_float4(v.x - w.x, v.y - w.y, v.z - w.z, v.w - w.w); }
-                const float4 s = *reinterpret_cast<const float4 *>(mod + ro + y);
-                const float e[4] = {fabsf(v.x) / s.x, fabsf(v.y) / s.y, fabsf(v.z) / s.z, fabsf(v.w) / s.w};
+    __shared__ unsigned int rowmask;
+    __shared__ float red[4];
+    if (threadIdx.x < 64) {      // which of this block's rows survive the (t, x) crop
+        const long long r = r0 + threadIdx.x;
+        bool ok = threadIdx.x < JS_RB && r < nrows;
+        if (ok) {
+            const int t = (int)(r / X), x = (int)(r % X);
+            ok = !(t < ct || t >= T - ct || x < cx || x >= X - cx);
+        }
+        const unsigned long long bm = __ballot(ok);
+        if (threadIdx.x == 0) rowmask = (unsigned int)bm;
+    }
+    __syncthreads();
+    const unsigned int rows = rowmask;
+    float m = 0.f, thr = 0.f;
+    if (rows && vec) {
+        // the block's rows are one contiguous span: walk it as float4 items, all 256 lanes busy
+        const int Y4 = Y / 4, dr = 256 / Y4, dy = 256 % Y4;
+        int row = threadIdx.x / Y4, y4 = threadIdx.x % Y4;
+        while (row < JS_RB) {
+            if ((rows >> row) & 1u) {
+                const long long o = (r0 + row) * Y + 4 * y4;
+                float4 v = *reinterpret_cast<const float4 *>(pa + o);
+                if (pb) { const float4 w = *reinterpret_cast<const float4 *>(pb + o); v = make_float4(v.x - w.x, v.y - w.y, v.z - w.z, v.w - w.w); }
+                const float4 sg = *reinterpret_cast<const float4 *>(mod + o);
+                const float av[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+                const float sv[4] = {sg.x, sg.y, sg.z, sg.w};
+                const int y = 4 * y4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (y + k >= cy && y + k < Y - cy) m = fmaxf(m, e[k]);
+                    if (y + k >= cy && y + k < Y - cy) js_update(av[k], sv[k], m, thr);
             }
-        } else {
+            y4 += dy;
+            row += dr;
+            if (y4 >= Y4) { y4 -= Y4; ++row; }
+        }
+    } else if (rows) {
+        for (int rr = 0; rr < JS_RB; ++rr) {
+            if (!((rows >> rr) & 1u)) continue;
+            const long long ro = (r0 + rr) * Y;
             for (int y = cy + threadIdx.x; y < Y - cy; y += blockDim.x) {
                 float v = pa[ro + y];
                 if (pb) v -= pb[ro + y];
-                m = fmaxf(m, fabsf(v) / mod[ro + y]);
+                js_update(fabsf(v), mod[ro + y], m, thr);
             }
         }
     }
-    __shared__ float red[4];
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && rows) {
         m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         // non-negative floats order like their bit patterns
         atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, __float_as_uint(m));
@@ -193,92 +228,133 @@ __global__ void __launch_bounds__(1024) kth_kernel(const float *__restrict__ s, 
 }
 
 // ------------------------------------------------------------------ per-cell k-th over axis 0
-// MSD radix select, 8-bit digits, 4 passes over [n, M], ALL requested ranks at once.
-// One workgroup (1024 threads) owns 16 adjacent cells (64 B of every sample row); lane&15 is
-// the cell, the other thread bits walk the batch axis 64 rows at a time.  Per pass, one LDS
-// histogram per *distinct* prefix among the ranks of a cell ("slot"; ranks are ascending, so
-// equal prefixes are adjacent): [slot][256 bins][16 cells] of 16-bit counters packed two cells
-// to a word (counts <= n < 65536).  After the pass one wave per (rank, cell) pair scans its
-// 256 bins with a wave prefix sum and narrows prefix and rank.
-constexpr int KA_W = 16, KA_MAXK = 10, KA_ROWS = 64;
+// MSD radix select over [n, M] for ALL requested ranks at once, one launch per digit:
+// 9 + 6 + 6 + 6 + 5 bits = 5 passes (20 B per element).  A 1024-thread workgroup owns 64
+// adjacent cells (256 B of every sample row): lane = cell, one wave = one row, so the 64 LDS
+// atomics of a wave-instruction never hit the same counter.  Counters are 16 bit (n < 65536),
+// two cells per word; histogram row r (= slot*bins + bin) is 32 words, rotated by r so that
+// both the cell-parallel updates and the later bin-parallel scan spread over the banks.
+// Per cell there is one histogram per *distinct* prefix among its ranks ("slot"; ranks are
+// ascending, so equal prefixes are adjacent and the first rank of a run leads it); pass 1 has
+// one slot and spends the LDS on 512 bins.  <= 80 KiB of LDS: two workgroups per CU, so one
+// streams while the other zeroes / scans.  Per-(rank, cell) prefix and residual rank live in
+// a caller workspace between launches.
+constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16;
 struct KAList { int nk; int k[KA_MAXK]; };
 
-__global__ void __launch_bounds__(1024) kth_axis0_kernel(const float *__restrict__ s, int n, long long M, const KAList kl,
-                                                         float *__restrict__ out)
+__device__ __forceinline__ int ka_word(int row, int half) { return row * 32 + ((half + row) & 31); }
+
+template <int BITS, int SLOTS>
+__global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restrict__ s, int n, long long M, const KAList kl,
+                                                          int shift, unsigned int *__restrict__ ws_prefix,
+                                                          unsigned int *__restrict__ ws_rank, float *__restrict__ out)
 {
-    __shared__ unsigned int hist[KA_MAXK * 256 * (KA_W / 2)];     // 80 KiB
-    __shared__ unsigned int s_prefix[KA_MAXK][KA_W];
-    __shared__ unsigned int s_rank[KA_MAXK][KA_W];
-    __shared__ int s_slot[KA_MAXK][KA_W];
+    constexpr int NB = 1 << BITS, PER = (NB + 63) / 64;
+    __shared__ unsigned int hist[SLOTS * NB * 32];
 
-    const int tid = threadIdx.x, cell = tid & (KA_W - 1), rsub = tid >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nk = kl.nk;
-    const long long c0 = (long long)blockIdx.x * KA_W, c = c0 + cell;
+    const long long c0 = (long long)blockIdx.x * KA_W, c = c0 + lane;
     const bool cok = c < M;
-    const int lane = tid & 63, wave = tid >> 6;
+    const bool first = (shift + BITS == 32);
+    const unsigned int mask = first ? 0u : ~0u << (shift + BITS);
 
-    if (tid < nk * KA_W) { s_prefix[tid / KA_W][tid % KA_W] = 0u; s_rank[tid / KA_W][tid % KA_W] = (unsigned)kl.k[tid / KA_W]; }
-    unsigned int mask = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        __syncthreads();
-        for (int i = tid; i < nk * 256 * (KA_W / 2); i += 1024) hist[i] = 0u;
-        if (tid < KA_W) {            // slot = first rank index carrying the same prefix
-            int lead = 0;
-            for (int j = 0; j < nk; ++j) {
-                if (j > 0 && s_prefix[j][tid] != s_prefix[j - 1][tid]) lead = j;
-                s_slot[j][tid] = lead;
-            }
-        }
-        __syncthreads();
-        unsigned int pf[KA_MAXK];
-        unsigned int leaders = 0;
+    for (int i = tid; i < SLOTS * NB * 32; i += 1024) hist[i] = 0u;
+
+    // my cell's run-leading prefixes; 1 (low bit set) can never equal a masked key
+    unsigned int pf[KA_MAXK];
+    if (SLOTS > 1) {
+        unsigned int prev = 0;
 #pragma unroll
         for (int j = 0; j < KA_MAXK; ++j) {
-            pf[j] = j < nk ? s_prefix[j][cell] : 0u;
-            if (j < nk && s_slot[j][cell] == j) leaders |= 1u << j;
+            const unsigned int p = (j < nk && cok) ? ws_prefix[(long long)j * M + c] : 0u;
+            pf[j] = (j < nk && (j == 0 || p != prev)) ? p : 1u;
+            prev = p;
         }
-        const unsigned int inc = 1u << (16 * (cell & 1));
-        unsigned int *hcol = hist + (cell >> 1);
-        if (cok) {
-#pragma unroll 4
-            for (int i = rsub; i < n; i += KA_ROWS) {
-                const unsigned int key = f2key(s[(long long)i * M + c]);
-                const unsigned int dig = (key >> shift) & 255u, hi = key & mask;
-#pragma unroll
-                for (int j = 0; j < KA_MAXK; ++j)
-                    if (((leaders >> j) & 1u) && hi == pf[j]) atomicAdd(hcol + (j * 256 + dig) * (KA_W / 2), inc);
-            }
-        }
-        __syncthreads();
-        // narrow: pair p = (rank index j, cell cc); 16 waves share the pairs
-        for (int p = wave; p < nk * KA_W; p += 16) {
-            const int j = p / KA_W, cc = p % KA_W;
-            const int slot = s_slot[j][cc];
-            const unsigned int r = s_rank[j][cc];
-            const unsigned int *h = hist + (slot * 256) * (KA_W / 2) + (cc >> 1);
-            const int sh16 = 16 * (cc & 1);
-            unsigned int b4[4], tot = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { b4[u] = (h[(lane * 4 + u) * (KA_W / 2)] >> sh16) & 0xffffu; tot += b4[u]; }
-            unsigned int incl = tot;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-            const unsigned long long crossed = __ballot(incl > r);
-            const int win = __ffsll((long long)crossed) - 1;      // first lane whose inclusive sum exceeds r
-            if (lane == win) {
-                unsigned int cum = incl - tot;
-                int u = 0;
-                for (; u < 3; ++u) { if (cum + b4[u] > r) break; cum += b4[u]; }
-                s_prefix[j][cc] |= (unsigned)(lane * 4 + u) << shift;
-                s_rank[j][cc] = r - cum;
-            }
-        }
-        mask |= 255u << shift;
     }
     __syncthreads();
-    if (tid < nk * KA_W) {
-        const int j = tid / KA_W, cc = tid % KA_W;
-        if (c0 + cc < M) out[(long long)j * M + c0 + cc] = key2f(s_prefix[j][cc]);
+
+    const unsigned int inc = 1u << (16 * (lane & 1));
+    const int half = lane >> 1;
+    auto count = [&](float v) __attribute__((always_inline)) {
+        const unsigned int key = f2key(v);
+        const int dig = (int)((key >> shift) & (NB - 1));
+        int m = 1;
+        if (SLOTS > 1) {
+            const unsigned int hi = key & mask;
+            m = 0;
+#pragma unroll
+            for (int j = 0; j < KA_MAXK; ++j) m = (hi == pf[j]) ? j + 1 : m;
+        }
+        if (m) atomicAdd(&hist[ka_word((m - 1) * NB + dig, half)], inc);
+    };
+    if (cok) {
+        const float *col = s + c;
+        int i = wave;
+        for (; i + 7 * KA_WAVES < n; i += 8 * KA_WAVES) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(long long)(i + u * KA_WAVES) * M];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) count(v[u]);
+        }
+        for (; i < n; i += KA_WAVES) count(col[(long long)i * M]);
+    }
+    __syncthreads();
+
+    // narrow: one wave per cell; lanes over bins (bin = u*64 + lane), ranks resolved slot by slot
+    for (int cc = wave; cc < KA_W; cc += KA_WAVES) {
+        if (c0 + cc >= M) break;
+        const long long cg = c0 + cc;
+        const bool mine = lane < nk;
+        const unsigned int myp = (mine && !first) ? ws_prefix[(long long)lane * M + cg] : 0u;
+        const unsigned int myr = mine ? (first ? (unsigned)kl.k[lane] : ws_rank[(long long)lane * M + cg]) : 0u;
+        const unsigned int upp = __shfl_up(myp, 1);
+        unsigned long long lead = __ballot(mine && (lane == 0 || myp != upp));
+        if (SLOTS == 1) lead = 1ull;
+        unsigned int newp = myp, newr = myr;
+        const int sh16 = 16 * (cc & 1), hcc = cc >> 1;
+        while (lead) {
+            const int sl = __ffsll((long long)lead) - 1;
+            lead &= lead - 1;
+            const int nxt = lead ? __ffsll((long long)lead) - 1 : nk;
+            // inclusive prefix sums of this slot's bins, PER blocks of 64 bins
+            unsigned int b[PER], incl[PER], carry = 0;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int bin = u * 64 + lane;
+                b[u] = bin < NB ? (hist[ka_word((SLOTS == 1 ? 0 : sl) * NB + bin, hcc)] >> sh16) & 0xffffu : 0u;
+                unsigned int x = b[u];
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(x, o); if (lane >= o) x += y; }
+                incl[u] = x + carry;
+                carry = __shfl(incl[u], 63);
+            }
+            for (int j = sl; j < nxt; ++j) {
+                const unsigned int r = __shfl(myr, j);
+                unsigned int digit = NB - 1, before = 0;
+                bool found = false;
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    const unsigned long long crossed = __ballot(incl[u] > r);
+                    if (!found && crossed) {
+                        const int win = __ffsll((long long)crossed) - 1;
+                        digit = (unsigned)(u * 64 + win);
+                        before = __shfl(incl[u] - b[u], win);
+                        found = true;
+                    }
+                }
+                if (lane == j) { newp = myp | (digit << shift); newr = r - before; }
+            }
+        }
+        if (mine) {
+            if (shift == 0) {
+                out[(long long)lane * M + cg] = key2f(newp);
+            } else {
+                ws_prefix[(long long)lane * M + cg] = newp;
+                ws_rank[(long long)lane * M + cg] = newr;
+            }
+        }
     }
 }
 
@@ -407,22 +483,39 @@ int pre_kth_f32(const float *scores, int64_t N, const int64_t *ks, int nk, float
     return PRE_OK;
 }
 
-int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks, int nk, float *out, void *stream)
+int64_t pre_kth_axis0_workspace_bytes(int64_t M, int nk)
 {
-    if (!scores || !ks || !out || n <= 0 || M <= 0 || nk <= 0) return PRE_E_NULL;
-    if (n >= 65536 || nk > 16) return PRE_E_SHAPE;
+    if (M <= 0 || nk <= 0) return 0;
+    const int64_t g = nk < KA_MAXK ? nk : KA_MAXK;
+    return 2 * g * M * (int64_t)sizeof(unsigned int);
+}
+
+int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks, int nk, float *out,
+                      void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!scores || !ks || !out || !workspace || n <= 0 || M <= 0 || nk <= 0) return PRE_E_NULL;
+    if (n >= 65536 || nk > 64) return PRE_E_SHAPE;
+    if (workspace_bytes < pre_kth_axis0_workspace_bytes(M, nk)) return PRE_E_RANGE;
     for (int j = 0; j < nk; ++j) {
         if (ks[j] < 0 || ks[j] >= n) return PRE_E_RANGE;
         if (j > 0 && ks[j] < ks[j - 1]) return PRE_E_RANGE;      // ascending (slots rely on it)
     }
     const long long tiles = (M + KA_W - 1) / KA_W;
     if (tiles > 0x7fffffffLL) return PRE_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    unsigned int *wp = static_cast<unsigned int *>(workspace);
     for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < kl.nk; ++j) kl.k[j] = ks[j0 + j];
-        hipLaunchKernelGGL(kth_axis0_kernel, dim3((unsigned)tiles), dim3(1024), 0, as_stream(stream), scores, (int)n,
-                           (long long)M, kl, out + (long long)j0 * M);
+        unsigned int *wr = wp + (long long)kl.nk * M;
+        float *o = out + (long long)j0 * M;
+        const dim3 grid((unsigned)tiles), block(1024);
+        hipLaunchKernelGGL((kth_axis0_pass<9, 1>), grid, block, 0, st, scores, (int)n, (long long)M, kl, 23, wp, wr, o);
+        hipLaunchKernelGGL((kth_axis0_pass<6, KA_MAXK>), grid, block, 0, st, scores, (int)n, (long long)M, kl, 17, wp, wr, o);
+        hipLaunchKernelGGL((kth_axis0_pass<6, KA_MAXK>), grid, block, 0, st, scores, (int)n, (long long)M, kl, 11, wp, wr, o);
+        hipLaunchKernelGGL((kth_axis0_pass<6, KA_MAXK>), grid, block, 0, st, scores, (int)n, (long long)M, kl, 5, wp, wr, o);
+        hipLaunchKernelGGL((kth_axis0_pass<5, KA_MAXK>), grid, block, 0, st, scores, (int)n, (long long)M, kl, 0, wp, wr, o);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;

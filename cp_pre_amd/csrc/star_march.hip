@@ -279,8 +279,11 @@ __global__ void __launch_bounds__(NR *TYQ) march_kernel(const Geom g, const type
             lds[bi][i][ty + 1][q] = C[i];
             if (top || bot) lds[bi][i][hslot][q] = hc.row[i];
         }
-        load_own(t + 2, D);
+        // halo first: it is consumed first (next plane's LDS staging), and vmcnt retires in
+        // issue order, so the own-cell loads of plane t+2 stay in flight behind it
+        // (measured +7 % on NS momentum vs the other order; non-temporal stores: -25 %)
         load_halo(t + 1, hn);
+        load_own(t + 2, D);
         lds_barrier();
 
         Nbr n[F];
@@ -300,7 +303,10 @@ __global__ void __launch_bounds__(NR *TYQ) march_kernel(const Geom g, const type
         }
         float4 r = Fn::eval(n, prm);
         if (g.flags & PRE_FLAG_ABS) r = fabs4(r);
-        if (inb) *reinterpret_cast<float4 *>(outp + (long long)t * oT) = r;
+        if (inb) {
+            float4 *dst = reinterpret_cast<float4 *>(outp + (long long)t * oT);
+            *dst = r;
+        }
     };
 
     float4 w0[F], w1[F], w2[F], w3[F];
@@ -368,6 +374,8 @@ bool fast_layout_ok(const pre_field_t *const *fs, int nf, int64_t Y, const float
 template <class Fn, int NR, int TYQ>
 int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st)
 {
+    static_assert(2 * Fn::F * (NR + 2) * TYQ * 16 <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    {
     g.nXT = (g.X + NR - 1) / NR;
     g.nYT = (g.Y + 4 * TYQ - 1) / (4 * TYQ);
     // split long T axes so the grid fills the chip (>= ~4 workgroups per CU) without
@@ -382,12 +390,14 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st)
     hipLaunchKernelGGL((march_kernel<Fn, NR, TYQ>), dim3((unsigned)tiles), dim3(TYQ, NR), 0, st, g, prm);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
+    }
 }
 
 template <class Fn>
 int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st)
 {
     // 512 threads per workgroup; rows of the tile trade halo re-reads (2/NR) against columns covered
+    // 8 rows x 256 columns: measured best of {4,8,16} rows (16 rows = 1024 threads, one workgroup per CU: -5 %)
     if (g.Y >= 192) return launch_tiled<Fn, 8, 64>(g, prm, st);
     if (g.Y >= 96) return launch_tiled<Fn, 16, 32>(g, prm, st);
     return launch_tiled<Fn, 32, 16>(g, prm, st);

@@ -24,7 +24,7 @@ def _parse(key):
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "cp_pre_hip.h")).read()
-    declared = set(re.findall(r"\bint\s+(pre_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(?:int|int64_t)\s+(pre_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()
     for name in declared:

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Per-kernel timings on the MI355X (HIP events on torch's current stream).
+    python tools/microbench.py [eval] [calib] [select]
+Prints algorithmic GB/s per kernel; used to steer optimisation, not a contract output."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cp_pre_amd import _lib, inductive_cp as icp, pipeline
+from cp_pre_amd import residuals as R
+from cp_pre_amd.convops_2d import ConvOperator
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def report(name, ms, nbytes):
+    print(f"{name:58s} {ms:9.3f} ms  {nbytes / ms / 1e6:8.1f} GB/s  ({nbytes / ms / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
+
+
+def bench_eval():
+    for (B, T, X, Y) in [(512, 10, 512, 512), (512, 32, 256, 256), (256, 64, 256, 256)]:
+        cells = B * T * X * Y
+        v = torch.empty(B, 6, T, X, Y, device=dev).uniform_(0.5, 1.5)
+        out = torch.empty(B, T, X, Y, device=dev)
+        ns = R.NavierStokes(0.01, 1 / X, 1 / Y)
+        report(f"ns_momentum [{B},{T},{X},{Y}] 16B/cell", timeit(lambda: ns.residual_momentum(v[:, :3], True, out=out)), 16 * cells)
+        report(f"ns_continuity (linear2) 12B/cell", timeit(lambda: ns.residual_continuity(v[:, :2], True)), 12 * cells)
+        w = R.PRE_Wave(0.01, 0.02)
+        report(f"wave additive kernel (linear1) 8B/cell", timeit(lambda: w.residual(v[:, 0], True)), 8 * cells)
+        mhd = R.MHD()
+        report(f"mhd_continuity 16B/cell", timeit(lambda: mhd.residual_continuity(v, True)), 16 * cells)
+        report(f"mhd_induction 20B/cell", timeit(lambda: mhd.residual_induction(v, True)), 20 * cells)
+        report(f"mhd_momentum 28B/cell", timeit(lambda: mhd.residual_momentum(v, True)), 28 * cells)
+        report(f"mhd_energy 28B/cell", timeit(lambda: mhd.residual_energy(v, True)), 28 * cells)
+        del v, out
+    B, T, X = 8192, 200, 512
+    u = torch.empty(B, T, X, device=dev).uniform_(0.5, 1.5)
+    bur = R.Burgers(2 / 512, 1.25 / 200, 0.002)
+    report(f"burgers [{B},{T},{X}] 8B/cell", timeit(lambda: bur.residual(u, True)), 8 * B * T * X)
+    adv = R.Advection(1.0, 0.005, 0.01)
+    report(f"advection additive kernel [{B},{T},{X}] 8B/cell", timeit(lambda: adv.residual(u, True)), 8 * B * T * X)
+    D = ConvOperator(("x", "y"), 2, taylor_order=4)
+    x = torch.randn(64, 10, 512, 512, device=dev)
+    report("generic kernel 5^3 taylor-4 [64,10,512,512] 8B/cell", timeit(lambda: D(x)), 8 * x.numel())
+
+
+def bench_calib():
+    for (n, T, X, Y) in [(1024, 10, 512, 512), (8192, 1, 200, 512)]:
+        res = torch.randn(n, T, X, Y, device=dev)
+        M = T * X * Y
+        mom = pipeline.HipOps.zeros_moments(M, dev)
+        report(f"moments_axis0_f64 [{n},{M}] 4B", timeit(lambda: pipeline.HipOps.add_moments(res, mom)), 4 * n * M)
+        mod = pipeline.HipOps.std_from_moments(mom, n * 7, (T, X, Y), 0.0)
+        sc = pipeline.HipOps.zeros_scores(n, dev)
+        report(f"joint_score crop1 [{n},{T},{X},{Y}] 4B", timeit(lambda: pipeline.HipOps.max_scores(res, mod, (1, 1, 1) if T > 2 else (0, 1, 1), sc)), 4 * n * M)
+        report(f"std_axis0 numpy-order [{n},{M}] 8B", timeit(lambda: icp.modulation_func(res, None)), 8 * n * M)
+        report(f"absdiff [{n * M}] 12B", timeit(lambda: _lib.load().pre_absdiff_f32(_lib.ptr(res), _lib.ptr(res), _lib.ptr(res), n * M, _lib.stream())), 12 * n * M)
+        del res
+
+
+def bench_select():
+    alphas = [float(a) for a in icp.ALPHA_LEVELS]
+    for (n, M) in [(256, 10 * 512 * 512), (1024, 10 * 512 * 512), (4096, 2 * 512 * 512), (512, 32 * 256 * 256), (8192, 254 * 254)]:
+        s = torch.randn(n, M, device=dev).abs_()
+        ks = [icp.kth_index(n, n, a) for a in alphas]
+        ms = timeit(lambda: icp.kth_axis0(s, ks), reps=3, warm=1)
+        report(f"kth_axis0 10 ranks [{n},{M}] 5 passes=20B", ms, 20 * n * M)
+        del s
+    s = torch.randn(65536 * 8, device=dev)
+    report("kth scalar 10 ranks N=524288", timeit(lambda: icp.kth_axis0(s, [icp.kth_index(s.numel(), s.numel(), a) for a in alphas])), 4 * s.numel())
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["eval", "calib", "select"]
+    if "eval" in what: bench_eval()
+    if "calib" in what: bench_calib()
+    if "select" in what: bench_select()
