@@ -244,12 +244,25 @@ struct KAList { int nk; int k[KA_MAXK]; };
 
 __device__ __forceinline__ int ka_word(int row, int half) { return row * 32 + ((half + row) & 31); }
 
+// Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (VALU only; the
+// __shfl_up form goes through ds_bpermute and made the narrowing step latency-bound).
+__device__ __forceinline__ unsigned int wave_incl_scan(unsigned int x)
+{
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return x;
+}
+
 template <int BITS, int SLOTS>
 __global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restrict__ s, int n, long long M, const KAList kl,
                                                           int shift, unsigned int *__restrict__ ws_prefix,
                                                           unsigned int *__restrict__ ws_rank, float *__restrict__ out)
 {
-    constexpr int NB = 1 << BITS, PER = (NB + 63) / 64;
+    constexpr int NB = 1 << BITS, PER = (NB + 63) / 64, CPW = KA_W / KA_WAVES;
     __shared__ unsigned int hist[SLOTS * NB * 32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -259,19 +272,41 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restric
     const bool first = (shift + BITS == 32);
     const unsigned int mask = first ? 0u : ~0u << (shift + BITS);
 
-    for (int i = tid; i < SLOTS * NB * 32; i += 1024) hist[i] = 0u;
+    // state of the CPW cells this wave will narrow after the sweep (lane j <-> rank j); fetched
+    // now so its latency hides under the sweep
+    unsigned int cp[CPW], cr[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+        const long long cg = c0 + wave + q * KA_WAVES;
+        const bool ok = lane < nk && cg < M;
+        cp[q] = (ok && !first) ? ws_prefix[(long long)lane * M + cg] : 0u;
+        cr[q] = ok ? (first ? (unsigned)kl.k[lane] : ws_rank[(long long)lane * M + cg]) : 0u;
+    }
 
-    // my cell's run-leading prefixes; 1 (low bit set) can never equal a masked key
+    // my cell's DISTINCT prefixes, compacted to the front (slot i = i-th distinct prefix); the
+    // sentinel 1 (low bit set) never equals a masked key.  lmax = most slots any cell of this wave
+    // has: the match loop below runs to that wave-uniform bound instead of KA_MAXK.
     unsigned int pf[KA_MAXK];
+    int lmax = 1;
     if (SLOTS > 1) {
+        unsigned int *scr = hist + wave * (KA_MAXK * 64);        // per-wave scratch, before hist is zeroed
         unsigned int prev = 0;
+        int L = 0;
 #pragma unroll
         for (int j = 0; j < KA_MAXK; ++j) {
             const unsigned int p = (j < nk && cok) ? ws_prefix[(long long)j * M + c] : 0u;
-            pf[j] = (j < nk && (j == 0 || p != prev)) ? p : 1u;
+            if (j < nk && (j == 0 || p != prev)) { scr[L * 64 + lane] = p; ++L; }
             prev = p;
         }
+#pragma unroll
+        for (int j = 0; j < KA_MAXK; ++j) pf[j] = j < L ? scr[j * 64 + lane] : 1u;
+        int m = L;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+        lmax = __builtin_amdgcn_readfirstlane(m);
+        __syncthreads();
     }
+    for (int i = tid; i < SLOTS * NB * 32; i += 1024) hist[i] = 0u;
     __syncthreads();
 
     const unsigned int inc = 1u << (16 * (lane & 1));
@@ -284,7 +319,8 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restric
             const unsigned int hi = key & mask;
             m = 0;
 #pragma unroll
-            for (int j = 0; j < KA_MAXK; ++j) m = (hi == pf[j]) ? j + 1 : m;
+            for (int j = 0; j < KA_MAXK; ++j)
+                if (j < lmax) m = (hi == pf[j]) ? j + 1 : m;
         }
         if (m) atomicAdd(&hist[ka_word((m - 1) * NB + dig, half)], inc);
     };
@@ -303,17 +339,19 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restric
     __syncthreads();
 
     // narrow: one wave per cell; lanes over bins (bin = u*64 + lane), ranks resolved slot by slot
-    for (int cc = wave; cc < KA_W; cc += KA_WAVES) {
-        if (c0 + cc >= M) break;
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+        const int cc = wave + q * KA_WAVES;
         const long long cg = c0 + cc;
+        if (cg >= M) break;
         const bool mine = lane < nk;
-        const unsigned int myp = (mine && !first) ? ws_prefix[(long long)lane * M + cg] : 0u;
-        const unsigned int myr = mine ? (first ? (unsigned)kl.k[lane] : ws_rank[(long long)lane * M + cg]) : 0u;
+        const unsigned int myp = cp[q], myr = cr[q];
         const unsigned int upp = __shfl_up(myp, 1);
         unsigned long long lead = __ballot(mine && (lane == 0 || myp != upp));
         if (SLOTS == 1) lead = 1ull;
         unsigned int newp = myp, newr = myr;
         const int sh16 = 16 * (cc & 1), hcc = cc >> 1;
+        int slot = 0;
         while (lead) {
             const int sl = __ffsll((long long)lead) - 1;
             lead &= lead - 1;
@@ -323,15 +361,12 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restric
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 const int bin = u * 64 + lane;
-                b[u] = bin < NB ? (hist[ka_word((SLOTS == 1 ? 0 : sl) * NB + bin, hcc)] >> sh16) & 0xffffu : 0u;
-                unsigned int x = b[u];
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(x, o); if (lane >= o) x += y; }
-                incl[u] = x + carry;
-                carry = __shfl(incl[u], 63);
+                b[u] = bin < NB ? (hist[ka_word(slot * NB + bin, hcc)] >> sh16) & 0xffffu : 0u;
+                incl[u] = wave_incl_scan(b[u]) + carry;
+                carry = (unsigned)__builtin_amdgcn_readlane((int)incl[u], 63);
             }
             for (int j = sl; j < nxt; ++j) {
-                const unsigned int r = __shfl(myr, j);
+                const unsigned int r = (unsigned)__builtin_amdgcn_readlane((int)myr, j);
                 unsigned int digit = NB - 1, before = 0;
                 bool found = false;
 #pragma unroll
@@ -340,12 +375,13 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restric
                     if (!found && crossed) {
                         const int win = __ffsll((long long)crossed) - 1;
                         digit = (unsigned)(u * 64 + win);
-                        before = __shfl(incl[u] - b[u], win);
+                        before = (unsigned)__builtin_amdgcn_readlane((int)(incl[u] - b[u]), win);
                         found = true;
                     }
                 }
                 if (lane == j) { newp = myp | (digit << shift); newr = r - before; }
             }
+            ++slot;
         }
         if (mine) {
             if (shift == 0) {
