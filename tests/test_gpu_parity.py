@@ -355,3 +355,71 @@ def test_pipeline_slabs_equal_whole_tensor(gpu):
     qm_ref = np.stack([oc.calibrate(np.abs(ref), n, a) for a in alphas])
     assert qm.shape == qm_ref.shape
     assert rel_err(qm, qm_ref) <= RES_TOL
+
+
+# ---------------------------------------------------------------- edge cases
+def test_edge_shapes_and_layouts(gpu):
+    """Empty batch, single-plane / single-row / single-column grids, Y not a multiple of 4,
+    misaligned (offset-by-one) views, batch-1 huge plane: every route must agree with the oracle."""
+    from cp_pre_amd.convops_1d import ConvOperator as C1
+    from cp_pre_amd.convops_2d import ConvOperator as C2
+    from oracle.cstencil import xcorr_c
+    g = torch.Generator().manual_seed(77)
+    L = C2(("x", "y"), 2)
+    Dt = C2("t", 2)
+    assert L(torch.empty(0, 3, 4, 8, device=gpu)).shape == (0, 3, 4, 8)
+    for shape in [(1, 1, 1, 4), (2, 1, 1, 1), (1, 3, 1, 8), (1, 2, 5, 1), (2, 3, 4, 7), (1, 1, 1, 1024), (1, 2, 1030, 4)]:
+        x = torch.randn(*shape, generator=g)
+        for D in (L, Dt):
+            got = D(x.to(gpu)).cpu().numpy()
+            assert rel_err(got, xcorr_c(x.numpy(), D.kernel.numpy())) <= RES_TOL, shape
+    # a view whose base pointer is 4 bytes off a 16-byte boundary, and one with a padded row pitch
+    big = torch.randn(2, 4, 6, 40, generator=g).to(gpu)
+    off = big[..., 1:33]
+    assert rel_err(L(off).cpu().numpy(), xcorr_c(off.cpu().contiguous().numpy(), L.kernel.numpy())) <= RES_TOL
+    pitched = big[..., :32]
+    assert rel_err(L(pitched).cpu().numpy(), xcorr_c(pitched.cpu().contiguous().numpy(), L.kernel.numpy())) <= RES_TOL
+    # 1-D: [BS,1,Nt,Nx] channel form and tiny extents
+    D1 = C1("x", 2)
+    x3 = torch.randn(3, 1, 9, 16, generator=g)
+    assert rel_err(D1(x3.to(gpu)).cpu().numpy(), xcorr_c(x3[:, 0].numpy(), D1.kernel.numpy())) <= RES_TOL
+    for shape in [(1, 1, 1), (4, 1, 5), (2, 7, 1), (0, 4, 4)]:
+        x = torch.randn(*shape, generator=g)
+        got = D1(x.to(gpu)).cpu().numpy()
+        if x.numel():
+            assert rel_err(got, xcorr_c(x.numpy(), D1.kernel.numpy())) <= RES_TOL, shape
+        assert got.shape == shape
+    # zero kernel / operator with no taps
+    Z = C2()
+    Z.kernel = torch.zeros(3, 3, 3)
+    assert Z(torch.randn(1, 2, 3, 4, generator=g).to(gpu)).abs().max().item() == 0.0
+
+
+def test_calibration_edge_cases(gpu):
+    """n=1, all-equal scores (ties everywhere), M not a multiple of the 64-cell tile, ranks 0 and n-1,
+    more ranks than one launch group (12 > 10), negative and mixed-sign scores."""
+    from cp_pre_amd import inductive_cp as icp
+    rng = np.random.default_rng(5)
+    one = torch.from_numpy(rng.standard_normal((1, 7)).astype(np.float32)).to(gpu)
+    assert torch.equal(icp.kth_axis0(one, [0]).cpu()[0], one.cpu()[0])
+    ties = torch.full((300, 130), 2.5, device=gpu)
+    assert (icp.kth_axis0(ties, [0, 150, 299]) == 2.5).all()
+    s = rng.standard_normal((777, 193)).astype(np.float32)
+    ks = [0, 1, 5, 77, 100, 200, 388, 500, 600, 700, 775, 776]
+    got = icp.kth_axis0(torch.from_numpy(s).to(gpu), ks).cpu().numpy()
+    assert np.array_equal(got, np.sort(s, axis=0)[ks])
+    unordered = [500, 0, 776, 77]
+    got = icp.kth_axis0(torch.from_numpy(s).to(gpu), unordered).cpu().numpy()
+    assert np.array_equal(got, np.sort(s, axis=0)[unordered])
+    with pytest.raises(RuntimeError):
+        icp.kth_axis0(torch.from_numpy(s).to(gpu), [777])
+    with pytest.raises(ValueError):
+        icp.calibrate(s, 777, 0.0001)                      # level above 1, like numpy
+    # coverage with scalar, per-cell and per-sample bounds
+    from oracle import conformal as oc
+    y = rng.standard_normal((50, 6, 7)).astype(np.float32)
+    q = np.abs(rng.standard_normal((6, 7))).astype(np.float32)
+    assert icp.emp_cov([-q, q], y) == pytest.approx(oc.emp_cov([-q, q], y), abs=1e-12)
+    assert icp.emp_cov([y - 0.5, y + q], y * 1.2) == pytest.approx(oc.emp_cov([y - 0.5, y + q], y * 1.2), abs=1e-12)
+    assert icp.emp_cov_joint([-3 * q, 3 * q], y) == pytest.approx(oc.emp_cov_joint([-3 * q, 3 * q], y), abs=1e-12)
+    assert icp.emp_cov([np.float32(-1.0), np.float32(1.0)], y) == pytest.approx(oc.emp_cov([-1.0, 1.0], y), abs=1e-12)
