@@ -63,11 +63,18 @@ def taps_of(karr):
 
 
 def to_device(t):
-    """(device tensor, original device).  Raises without a GPU: no CPU fallback."""
+    """(device tensor, original device).  Raises without a GPU: no CPU fallback.
+
+    Views whose last axis is not contiguous (the surrogate's native [BS,F,Nx,Ny,Nt] layout seen
+    through ``permute(0,1,4,2,3)``, Marginal/Wave_Residuals_CP.py:216) are re-laid out once by
+    a device copy (8 B/cell, counted against the roofline in DESIGN.md) so they take the
+    streaming kernels; small ones go straight to the generic strided kernel."""
     if t.is_cuda:
+        if t.dim() >= 3 and t.stride(-1) != 1 and t.numel() >= (1 << 16):
+            t = t.contiguous()
         return t, None
     _lib.require_gpu()
-    return t.cuda(), t.device
+    return t.contiguous().cuda(), t.device
 
 
 def from_device(out, origin):
@@ -81,11 +88,58 @@ def _check_field(field):
         raise _dtype_error(field.dtype)
 
 
+class _XCorrFn(torch.autograd.Function):
+    """Autograd wrapper (``Physics_Informed/Wave_FNO_PI.py:202-228,257-269`` puts
+    ``D(y_out)`` in a loss on device).  The adjoint of a zero-padded cross-correlation is the
+    cross-correlation with the kernel flipped along every axis - the same HIP kernel with
+    mirrored taps.  The kernel gradient (only if ``kernel.requires_grad``) is k^nd shifted
+    inner products, composed from torch device ops."""
+
+    @staticmethod
+    def forward(ctx, field, kernel, nd):
+        ctx.save_for_backward(field, kernel)
+        ctx.nd = nd
+        return _xcorr_impl(field, kernel, nd, 0)
+
+    @staticmethod
+    def backward(ctx, gout):
+        field, kernel = ctx.saved_tensors
+        nd = ctx.nd
+        gf = gk = None
+        if ctx.needs_input_grad[0]:
+            gf = _xcorr_impl(gout.contiguous(), torch.flip(kernel.detach(), dims=tuple(range(nd))), nd, 0)
+        if ctx.needs_input_grad[1]:
+            g = gout.to(field.device) if gout.device != field.device else gout
+            x = field[:, 0] if field.dim() == nd + 2 else field
+            gk = torch.zeros_like(kernel, dtype=torch.float32, device=g.device)
+            ext = x.shape[1:]
+            for idx in torch.cartesian_prod(*[torch.arange(s) for s in kernel.shape]).tolist():
+                off = [i - s // 2 for i, s in zip(idx, kernel.shape)]
+                src = tuple(slice(max(0, o), e + min(0, o)) for o, e in zip(off, ext))
+                dst = tuple(slice(max(0, -o), e - max(0, o)) for o, e in zip(off, ext))
+                if all(sl.stop > sl.start for sl in src):
+                    gk[tuple(idx)] = (g[(slice(None),) + dst] * x[(slice(None),) + src]).sum()
+            gk = gk.to(kernel.device)
+        return gf, gk, None
+
+
 def xcorr(field, kernel, nd, flags=0):
     """Zero-padded single-channel cross-correlation of ``field`` with ``kernel``.
 
     nd=3: field [BS,Nt,Nx,Ny], kernel k*k*k.   nd=2: field [BS,Nt,Nx] (or [BS,1,Nt,Nx]), kernel k*k.
+    Differentiable w.r.t. both arguments when either requires grad.
     """
+    if flags == 0 and torch.is_grad_enabled() and isinstance(field, torch.Tensor) and isinstance(kernel, torch.Tensor) \
+            and (field.requires_grad or kernel.requires_grad):
+        return _XCorrFn.apply(field, kernel, nd)
+    return _xcorr_impl(field, kernel, nd, flags)
+
+
+def needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+def _xcorr_impl(field, kernel, nd, flags=0):
     _check_field(field)
     karr = host_kernel(kernel)
     if karr.ndim != nd:

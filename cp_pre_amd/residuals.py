@@ -74,6 +74,11 @@ class _Residual2D:
         ks = [_dispatch.dense27(o.kernel) for o in ops]
         return None if any(k is None for k in ks) else ks
 
+    def _want_fused(self, *tensors):
+        """Fused kernels have no backward; a caller that needs gradients gets the composed route."""
+        return self.fused and not _dispatch.needs_grad(*tensors, *[getattr(o, "kernel", None) for o in
+                                                                   (self.D_t, self.D_x, self.D_y, self.D_xx_yy)])
+
 
 def _finish(res, boundary, crop, absolute, already_abs):
     if absolute and not already_abs:
@@ -93,7 +98,7 @@ class NavierStokes(_Residual2D):
         u, v = vars[:, 0], vars[:, 1]
         ratio = self.dx / self.dy
         res = None
-        if self.fused:
+        if self._want_fused(vars):
             from .vector_convops import linear2
             res = linear2(u, self.D_x.kernel, v, self.D_y.kernel, ratio, _lib.PRE_FLAG_ABS if absolute else 0)
         done_abs = res is not None and absolute
@@ -106,7 +111,7 @@ class NavierStokes(_Residual2D):
         uncropped residual (fused route only; lets a streaming driver reuse one buffer)."""
         u, v, p = vars[:, 0], vars[:, 1], vars[:, 2]
         dt, dx, dy, nu = self.dt, self.dx, self.dy, self.nu
-        ks = self._k27(self.D_t, self.D_x, self.D_y, self.D_xx_yy) if self.fused else None
+        ks = self._k27(self.D_t, self.D_x, self.D_y, self.D_xx_yy) if self._want_fused(vars) else None
         if ks is not None:
             (du, dv, dp), origin = _stage((u, v, p))
             if out is None:
@@ -158,7 +163,7 @@ class MHD(_Residual2D):
         self.gamma = gamma
 
     def _fused(self, eq, vars, absolute):
-        ks = self._k27(self.D_t, self.D_x, self.D_y) if self.fused else None
+        ks = self._k27(self.D_t, self.D_x, self.D_y) if self._want_fused(vars) else None
         if ks is None or vars.shape[1] < 6:
             return None
         fields, origin = _stage([vars[:, i] for i in range(6)])
@@ -221,7 +226,7 @@ class MHD(_Residual2D):
     def residual_gauss(self, vars, boundary=False, absolute=False):
         Bx, By = vars[:, 4], vars[:, 5]
         res = None
-        if self.fused:
+        if self._want_fused(vars):
             from .vector_convops import linear2
             res = linear2(Bx, self.D_x.kernel, By, self.D_y.kernel, 1.0, _lib.PRE_FLAG_ABS if absolute else 0)
         done_abs = res is not None and absolute
@@ -288,7 +293,8 @@ class Burgers:
 
     def residual(self, uu, boundary=False, absolute=False):
         dx, dt, nu = self.dx, self.dt, self.nu
-        ks = [_dispatch.dense9(o.kernel) for o in (self.D_t, self.D_x, self.D_xx)] if self.fused else [None]
+        fused = self.fused and not _dispatch.needs_grad(uu, self.D_t.kernel, self.D_x.kernel, self.D_xx.kernel)
+        ks = [_dispatch.dense9(o.kernel) for o in (self.D_t, self.D_x, self.D_xx)] if fused else [None]
         if all(k is not None for k in ks) and uu.dim() == 3:
             (du,), origin = _stage((uu,))
             out = torch.empty(du.shape, dtype=torch.float32, device=du.device)

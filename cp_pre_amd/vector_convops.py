@@ -32,6 +32,8 @@ def vectorize(a, b):
 
 def linear2(f0, k0, f1, k1, ratio=1.0, flags=0):
     """``K0(f0) + ratio*K1(f1)`` in one streaming pass; None if the fused kernel declines."""
+    if _dispatch.needs_grad(f0, f1, k0, k1):
+        return None                     # fused kernels have no backward: compose
     d0, d1 = _dispatch.dense27(k0), _dispatch.dense27(k1)
     if d0 is None or d1 is None or f0.shape != f1.shape or f0.dim() != 4:
         return None

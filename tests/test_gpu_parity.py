@@ -423,3 +423,56 @@ def test_calibration_edge_cases(gpu):
     assert icp.emp_cov([y - 0.5, y + q], y * 1.2) == pytest.approx(oc.emp_cov([y - 0.5, y + q], y * 1.2), abs=1e-12)
     assert icp.emp_cov_joint([-3 * q, 3 * q], y) == pytest.approx(oc.emp_cov_joint([-3 * q, 3 * q], y), abs=1e-12)
     assert icp.emp_cov([np.float32(-1.0), np.float32(1.0)], y) == pytest.approx(oc.emp_cov([-1.0, 1.0], y), abs=1e-12)
+
+
+# ---------------------------------------------------------------- autograd
+def test_autograd_matches_torch_conv(gpu):
+    """D(u) inside a loss on device (Physics_Informed/Wave_FNO_PI.py:202-228): gradients w.r.t. the
+    field (adjoint stencil = flipped taps, same HIP kernel) and w.r.t. D.kernel, against
+    torch autograd through the oracle's F.conv3d / F.conv2d on CPU."""
+    from cp_pre_amd.convops_1d import ConvOperator as C1
+    from cp_pre_amd.convops_2d import ConvOperator as C2
+    from cp_pre_amd.residuals import NavierStokes
+    from oracle import residuals as orr
+    from oracle.convops import xcorr_torch
+    g = torch.Generator().manual_seed(4)
+    for C, shape, dom, kw in [(C2, (2, 5, 6, 8), ("x", "y"), {}), (C2, (2, 6, 7, 8), ("x", "y"), {"taylor_order": 4}),
+                              (C2, (1, 4, 4, 16), "t", {}), (C1, (3, 6, 8), "x", {})]:
+        x = torch.randn(*shape, generator=g)
+        w = torch.randn(*shape, generator=g)
+        D = C(dom, 2, **kw)
+        k_ref = D.kernel.clone().requires_grad_(True)
+        x_ref = x.clone().requires_grad_(True)
+        (xcorr_torch(x_ref, k_ref) * w).sum().backward()
+        D.kernel = D.kernel.to(gpu).requires_grad_(True)
+        xd = x.to(gpu).requires_grad_(True)
+        out = D(xd)
+        assert out.requires_grad
+        (out * w.to(gpu)).sum().backward()
+        assert rel_err(xd.grad.cpu().numpy(), x_ref.grad.numpy()) <= RES_TOL
+        assert rel_err(D.kernel.grad.cpu().numpy(), k_ref.grad.numpy()) <= 1e-4      # k^nd long fp32 sums
+    # a residual used as a physics loss: fused route steps aside, gradients flow through the composition
+    v = (torch.rand(2, 3, 5, 6, 16, generator=g) + 0.5)
+    v_ref = v.clone().requires_grad_(True)
+    orr.ns_momentum(v_ref, 0.01, 1 / 16, 1 / 16, boundary=False).pow(2).mean().backward()
+    vd = v.to(gpu).requires_grad_(True)
+    NavierStokes(0.01, 1 / 16, 1 / 16).residual_momentum(vd).pow(2).mean().backward()
+    assert rel_err(vd.grad.cpu().numpy(), v_ref.grad.numpy()) <= 1e-4
+    with torch.no_grad():                                   # and no graph is built when not asked for
+        assert not C2("x", 1)(vd[:, 0]).requires_grad
+
+
+def test_permuted_surrogate_layout_large(gpu):
+    """[BS,F,Nx,Ny,Nt] surrogate output seen through permute(0,1,4,2,3): large views are re-laid
+    out on the device and take the streaming kernels; results equal the oracle on the same view."""
+    from cp_pre_amd.residuals import NavierStokes, PRE_Wave
+    from oracle import residuals as orr
+    g = torch.Generator().manual_seed(8)
+    sur = torch.rand(5, 3, 24, 64, 10, generator=g) + 0.5               # [BS,F,Nx,Ny,Nt]
+    view = sur.permute(0, 1, 4, 2, 3)
+    assert view.stride(-1) != 1 and view[:, 0].numel() >= 1 << 16
+    got = NavierStokes(0.01, 1 / 24, 1 / 64).residual_momentum(sur.to(gpu).permute(0, 1, 4, 2, 3))
+    ref = orr.ns_momentum(view, 0.01, 1 / 24, 1 / 64, boundary=False)
+    assert rel_err(got.cpu().numpy(), ref.numpy()) <= RES_TOL
+    w = PRE_Wave(0.01, 0.02).residual(sur.to(gpu).permute(0, 1, 4, 2, 3)[:, :1])
+    assert rel_err(w.cpu().numpy(), orr.wave_residual(view[:, 0], 1.0, 0.01, 0.02).numpy()) <= RES_TOL
