@@ -55,6 +55,24 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the fused residual kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN/pmc_hbm_c3.json, written by tools/distill_profiles.py).  Counters cannot be
+    read from inside this process; the file is used only when it was collected on this exact
+    workload, otherwise `traffic` stays null."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_c3.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("batch"), w.get("slab"), w.get("nx"), w.get("ny")) == (args.batch, args.slab, args.nx, args.ny):
+            best = d
+    return best
+
+
 def cpu_baseline(args, alphas):
     """The oracle (reference arithmetic: F.conv3d per operator + torch elementwise + numpy
     calibration) on a bounded sample of the same workload, on this box's host cores."""
@@ -94,12 +112,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    # PRE_BENCH_REHEARSE=1: several ranks on ONE GPU over gloo - a plumbing rehearsal of the N>1
+    # path on a single-GPU box (RCCL refuses two ranks per device); never a measurement.
+    rehearse = os.environ.get("PRE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
         group = dist.group.WORLD
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
@@ -166,6 +192,7 @@ def main():
         kms = sum(durs) / len(durs)
         launch_bytes = NS_BYTES_PER_CELL * B * T * X * Y
         achieved = launch_bytes / (kms * 1e-3) / 1e9
+        pmc = pmc_traffic(args)
         out = {
             "metric": "residual-cells/s (PRE eval+calibrate)",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -177,7 +204,9 @@ def main():
                        "mode": args.mode, "batch_per_rank": B, "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "march_kernel<NSMomentum<0>,8,64>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": kms, "algorithmic_bytes_per_launch": launch_bytes},
+                         "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                         "traffic_source": pmc["source"] if pmc else None,
+                         "avg_launch_ms": kms, "algorithmic_bytes_per_launch": launch_bytes},
             "qhat_first_last": [float(qhat.reshape(len(alphas), -1)[0, 0]), float(qhat.reshape(len(alphas), -1)[-1, 0])],
         }
         if world == 1 and not args.no_cpu_baseline:
