@@ -20,6 +20,10 @@ and the final q-hat selection.  cells/step = 4096*64*512*512 (uncropped grid, SU
 --mode marginal (Marginal/NS_Residuals_CP.py recipe): |r| -> per-cell q-hat x 10 by radix
     select over the batch axis.  N>1: all-to-all (batch-sharded -> cell-sharded) per slab.
 
+--config c1|c2|c4|c5 run the other BASELINE.json configurations (per-rank shard sizes, whole
+tensor resident, no slabs); they are secondary measurements quoted in DESIGN.md, not the
+contract line.  Default: c3.
+
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (fused
 residual kernel, HIP events on its stream) and `cpu_baseline` (the CPU oracle = the
 reference's own F.conv3d arithmetic, timed on this box's host cores; N=1 only).
@@ -39,20 +43,120 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 NS_BYTES_PER_CELL = 16         # 3 fields read + 1 residual written, fp32
 
 
+# BASELINE.json configs: per-rank shapes (C4/C5 are quoted sharded over 8 GPUs), the fused kernel
+# that evaluates them, its algorithmic bytes per cell and the script's CP flavour.
+CONFIGS = {
+    "c1": dict(kind="advection", shape=(256, 100, 200), bpc=8, mode="marginal", kernel="march_kernel<Linear1,8,64>",
+               title="C1 1D advection additive kernel (Marginal/Advection_Residuals_CP.py)"),
+    "c2": dict(kind="wave", shape=(512, 32, 256, 256), bpc=8, mode="marginal", kernel="march_kernel<Linear1,8,64>",
+               title="C2 2D wave additive kernel (Marginal/Wave_Residuals_CP.py)"),
+    "c3": dict(kind="ns", shape=(4096, 64, 512, 512), bpc=16, mode="joint", kernel="march_kernel<NSMomentum<0>,8,64>",
+               title="C3 2D Navier-Stokes momentum residual"),
+    "c4": dict(kind="mhd", shape=(1024, 64, 256, 256), bpc=20, mode="joint", kernel="march_kernel<MHDInduction<0>,8,64>",
+               title="C4 2D MHD induction residual (Marginal/MHD_Residuals_CP.py:323), 8192/8 samples per rank"),
+    "c5": dict(kind="burgers", shape=(8192, 200, 512), bpc=8, mode="joint", kernel="march_kernel<Burgers<0>,8,64>",
+               title="C5 1D Burgers residual (Joint/Burgers_Residuals_CP.py), 65536/8 samples per rank"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", choices=["joint", "marginal"], default="joint")
-    ap.add_argument("--batch", type=int, default=4096, help="samples per rank (BASELINE C3: 4096)")
-    ap.add_argument("--nt", type=int, default=64)
-    ap.add_argument("--nx", type=int, default=512)
-    ap.add_argument("--ny", type=int, default=512)
+    ap.add_argument("--mode", choices=["joint", "marginal"], default=None, help="default: the config's own flavour")
+    ap.add_argument("--batch", type=int, default=None, help="samples per rank (default: the config's)")
+    ap.add_argument("--nt", type=int, default=None)
+    ap.add_argument("--nx", type=int, default=None)
+    ap.add_argument("--ny", type=int, default=None)
     ap.add_argument("--slab", type=int, default=8, help="interior planes per t-slab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
-    return ap.parse_args()
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    shp = cfg["shape"]
+    args.mode = args.mode or cfg["mode"]
+    args.batch = args.batch or shp[0]
+    args.nt = args.nt or shp[1]
+    args.nx = args.nx or shp[2]
+    args.ny = args.ny or (shp[3] if len(shp) == 4 else 0)
+    return args
+
+
+def run_secondary(args, cfg, dev, group, rank, world):
+    """c1/c2/c4/c5: whole per-rank tensor resident; one step = fused residual + calibration."""
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    from cp_pre_amd import residuals as R
+    B, T, X, Y = args.batch, args.nt, args.nx, args.ny
+    alphas = [float(a) for a in icp.ALPHA_LEVELS]
+    absolute = args.mode == "marginal"
+    torch.manual_seed(1234 + rank)
+    kind = cfg["kind"]
+    if kind in ("advection", "burgers"):
+        u = torch.empty(B, T, X, device=dev).uniform_(0.5, 1.5)
+        op = R.Advection(1.0, 0.005, 0.01, disc=2) if kind == "advection" else R.Burgers(2.0 / X, 1.25 / T, 0.002)
+        evaluate = lambda: op.residual(u, boundary=True, absolute=absolute).unsqueeze(1)      # [B,1,T,X]
+        crop, cells = (0, 1, 1), B * T * X
+    elif kind == "wave":
+        u = torch.empty(B, T, X, Y, device=dev).uniform_(0.5, 1.5)
+        op = R.PRE_Wave(dt=0.005, dx=0.01, c=1.0)
+        evaluate = lambda: op.residual(u, boundary=True, absolute=absolute)
+        crop, cells = (1, 1, 1), B * T * X * Y
+    else:
+        v = torch.empty(B, 6, T, X, Y, device=dev).uniform_(0.5, 1.5)
+        op = R.MHD()
+        evaluate = lambda: op.residual_induction(v, boundary=True, absolute=absolute)
+        crop, cells = (1, 1, 1), B * T * X * Y
+    ev = []
+
+    def step():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        res = evaluate()
+        e1.record()
+        ev.append((e0, e1))
+        if args.mode == "joint":
+            jc = pipeline.JointCalibration(B, dev, group=group)
+            jc.add_slab(res, crop=crop)
+            return jc.finish(alphas)
+        return pipeline.marginal_qhat(res, alphas, group=group)
+
+    def sync():
+        torch.cuda.synchronize()
+        if group is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ev.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        q = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if group is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        kms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        launch_bytes = cfg["bpc"] * cells
+        achieved = launch_bytes / (kms * 1e-3) / 1e9
+        shape = [B, T, X] + ([Y] if Y else [])
+        print(json.dumps({
+            "metric": "residual-cells/s (PRE eval+calibrate)", "value": cells * world * args.steps / elapsed,
+            "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic U(0.5,1.5) fields, whole per-rank tensor resident",
+            "config": {"workload": f"{cfg['title']} {shape} per rank, {args.mode} CP, 10 alpha levels", "mode": args.mode,
+                       "parallelism": f"batch-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": cfg["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": kms,
+                         "algorithmic_bytes_per_launch": launch_bytes}}), flush=True)
 
 
 def pmc_traffic(args):
@@ -128,6 +232,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
         group = dist.group.WORLD
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    if args.config != "c3":
+        run_secondary(args, CONFIGS[args.config], dev, group, rank, world)
+        if group is not None:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
 
     from cp_pre_amd import inductive_cp as icp
     from cp_pre_amd import pipeline

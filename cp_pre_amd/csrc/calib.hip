@@ -193,38 +193,38 @@ struct KList { int nk; long long k[16]; };
 
 __global__ void __launch_bounds__(1024) kth_kernel(const float *__restrict__ s, long long N, const KList kl, float *__restrict__ out)
 {
+    // one workgroup per requested rank (N per-sample scores fit L2: the re-reads are cache hits)
     __shared__ unsigned int hist[256];
     __shared__ unsigned int sh_prefix;
     __shared__ long long sh_rank;
-    for (int j = 0; j < kl.nk; ++j) {
-        unsigned int prefix = 0, mask = 0;
-        long long rank = kl.k[j];
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-            __syncthreads();
-            for (long long i = threadIdx.x; i < N; i += blockDim.x) {
-                const unsigned int key = f2key(s[i]);
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                long long cum = 0;
-                unsigned int d = 0;
-                for (; d < 255; ++d) {
-                    if (cum + hist[d] > rank) break;
-                    cum += hist[d];
-                }
-                sh_prefix = prefix | (d << shift);
-                sh_rank = rank - cum;
-            }
-            __syncthreads();
-            prefix = sh_prefix;
-            rank = sh_rank;
-            mask |= 255u << shift;
-            __syncthreads();
+    const int j = blockIdx.x;
+    unsigned int prefix = 0, mask = 0;
+    long long rank = kl.k[j];
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (long long i = threadIdx.x; i < N; i += blockDim.x) {
+            const unsigned int key = f2key(s[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
-        if (threadIdx.x == 0) out[j] = key2f(prefix);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long cum = 0;
+            unsigned int d = 0;
+            for (; d < 255; ++d) {
+                if (cum + hist[d] > rank) break;
+                cum += hist[d];
+            }
+            sh_prefix = prefix | (d << shift);
+            sh_rank = rank - cum;
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        rank = sh_rank;
+        mask |= 255u << shift;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) out[j] = key2f(prefix);
 }
 
 // ------------------------------------------------------------------ per-cell k-th over axis 0
@@ -429,6 +429,25 @@ __global__ void __launch_bounds__(256) cov_joint_kernel(const float *__restrict_
     if (__any(bad) && (threadIdx.x & 63) == 0) inside[smp] = 0;
 }
 
+// grid (chunks, n): counts[i] += #cells of sample i inside [lo,hi] (outside == 0) or with
+// y <= lo || y >= hi (outside != 0)   (Active_Learning/Advection_AL_Marginal.py:190-193)
+__global__ void __launch_bounds__(256) cov_rowcount_kernel(const float *__restrict__ y, const float *__restrict__ lo,
+                                                           const float *__restrict__ hi, long long M, int per_sample,
+                                                           int outside, unsigned int *__restrict__ counts)
+{
+    const int smp = blockIdx.y;
+    const float *py = y + smp * M;
+    const float *plo = lo + (per_sample ? smp * M : 0), *phi = hi + (per_sample ? smp * M : 0);
+    unsigned int local = 0;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < M; c += (long long)gridDim.x * blockDim.x) {
+        const float v = py[c];
+        local += outside ? ((v <= plo[c]) || (v >= phi[c])) : ((v >= plo[c]) && (v <= phi[c]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(counts + smp, local);
+}
+
 inline unsigned grid_for(long long items, int block, long long cap = 256LL * 32)
 {
     long long g = (items + block - 1) / block;
@@ -513,7 +532,7 @@ int pre_kth_f32(const float *scores, int64_t N, const int64_t *ks, int nk, float
         KList kl;
         kl.nk = (nk - j0) < 16 ? (nk - j0) : 16;
         for (int j = 0; j < kl.nk; ++j) kl.k[j] = ks[j0 + j];
-        hipLaunchKernelGGL(kth_kernel, dim3(1), dim3(1024), 0, as_stream(stream), scores, (long long)N, kl, out + j0);
+        hipLaunchKernelGGL(kth_kernel, dim3(kl.nk), dim3(1024), 0, as_stream(stream), scores, (long long)N, kl, out + j0);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
@@ -564,6 +583,21 @@ int pre_cov_count_f32(const float *y, const float *lo, const float *hi, int64_t 
     hipLaunchKernelGGL(cov_count_kernel, dim3(grid_for(n * M, 256)), dim3(256), 0, as_stream(stream), y, lo, hi,
                        (long long)(n * M), (long long)M, per_sample_bounds, count);
     PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
+
+int pre_cov_rowcount_f32(const float *y, const float *lo, const float *hi, int64_t n, int64_t M, int per_sample_bounds,
+                         int outside, uint32_t *counts, void *stream)
+{
+    if (!y || !lo || !hi || !counts || n <= 0 || M <= 0) return PRE_E_NULL;
+    const unsigned gx = grid_for(M, 256, 64);
+    for (int64_t s0 = 0; s0 < n; s0 += 65535) {
+        const int64_t ns = (n - s0) < 65535 ? (n - s0) : 65535;
+        hipLaunchKernelGGL(cov_rowcount_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, as_stream(stream), y + s0 * M,
+                           per_sample_bounds ? lo + s0 * M : lo, per_sample_bounds ? hi + s0 * M : hi, (long long)M,
+                           per_sample_bounds, outside, counts + s0);
+        PRE_LAUNCH_CHECK();
+    }
     return PRE_OK;
 }
 

@@ -206,6 +206,18 @@ def filter_sims_joint(pred_sets, y):
     return flags if isinstance(y, torch.Tensor) else flags.cpu().numpy()
 
 
+def filter_sims_within_bounds(lower_bound, upper_bound, samples, threshold, within=False):
+    """``Active_Learning/Advection_AL_Marginal.py:169-198``: bool [n], True where at least
+    ``threshold`` of a sample's cells lie inside [lo,hi] (``within``) or on/outside the bounds."""
+    dy, lo, hi, n, M, ps = _bounds([lower_bound, upper_bound], samples)
+    counts = torch.zeros(n, dtype=torch.int32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.load().pre_cov_rowcount_f32(_lib.ptr(dy), _lib.ptr(lo), _lib.ptr(hi), n, M, ps, 0 if within else 1,
+                                                    _lib.ptr(counts), _lib.stream()), "pre_cov_rowcount_f32")
+    flags = (counts.double() / float(M)) >= threshold          # numpy: mean of bools in float64
+    return flags if isinstance(samples, torch.Tensor) else flags.cpu().numpy()
+
+
 def emp_cov_joint(pred_sets, y):
     f = filter_sims_joint(pred_sets, y)
     return float(f.float().mean().item()) if isinstance(f, torch.Tensor) else float(f.mean())

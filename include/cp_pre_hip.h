@@ -135,6 +135,11 @@ int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *
  * pre_cov_joint_f32:  inside[i] = all_cells(lo <= y[i] <= hi)  (uint8 per sample; caller fills with 1) */
 int pre_cov_count_f32(const float *y, const float *lo, const float *hi, int64_t n, int64_t M,
                       int per_sample_bounds, unsigned long long *count, void *stream);
+/* filter_sims_within_bounds (Active_Learning/Advection_AL_Marginal.py:169-198): counts[i] +=
+ * #cells of sample i with lo <= y <= hi (outside == 0) or y <= lo || y >= hi (outside != 0);
+ * uint32 per sample, caller zeroes; the caller divides by M and compares with the threshold. */
+int pre_cov_rowcount_f32(const float *y, const float *lo, const float *hi, int64_t n, int64_t M,
+                         int per_sample_bounds, int outside, uint32_t *counts, void *stream);
 int pre_cov_joint_f32(const float *y, const float *lo, const float *hi, int64_t n, int64_t M,
                       int per_sample_bounds, uint8_t *inside, void *stream);
 

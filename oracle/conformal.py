@@ -55,6 +55,15 @@ def filter_sims_joint(pred_sets, y):
     return (y >= pred_sets[0]).all(axis=axes) & (y <= pred_sets[1]).all(axis=axes)
 
 
+def filter_sims_within_bounds(lower_bound, upper_bound, samples, threshold, within=False):
+    """Active_Learning/Advection_AL_Marginal.py:169-198 (in the reference itself; pinned by
+    tests/golden/filters.npz): per-sample fraction of cells inside [lo,hi] (within) or on/outside
+    the bounds (not within), compared with ``threshold``."""
+    lo, hi, y = np.array(lower_bound), np.array(upper_bound), np.array(samples)
+    hit = ((y >= lo) & (y <= hi)) if within else ((y <= lo) | (y >= hi))
+    return hit.mean(axis=tuple(range(1, y.ndim))) >= threshold
+
+
 def emp_cov_joint(pred_sets, y):
     return filter_sims_joint(pred_sets, y).mean()
 

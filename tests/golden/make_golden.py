@@ -15,6 +15,9 @@ What is executed from the reference (nothing of it is copied into this repo):
     imported (top-level ``from Neural_PDE...``), so the defs are located with ``ast`` at
     generation time, compiled from the reference file itself and executed against the
     reference's own ConvOperator instances -> residuals.npz
+  * ``filter_sims_joint`` (Joint/Burgers_Residuals_CP.py:298-300) and ``filter_sims_within_bounds``
+    (Active_Learning/Advection_AL_Marginal.py:169-198) - defined inside the reference tree -
+    compiled from it the same way -> filters.npz
   * conformal.npz is BUILD-DEFINED (numpy, oracle/conformal.py): the reference's
     ``Neural_PDE.UQ.inductive_cp`` is absent, so these vectors pin the oracle to numpy,
     not to the reference ("parity unpinned").
@@ -199,11 +202,35 @@ def gen_conformal():
     np.savez_compressed(os.path.join(HERE, "conformal.npz"), **out)
 
 
+def gen_filters():
+    """The two coverage filters that ARE defined inside the reference tree, compiled from it:
+    ``filter_sims_joint`` (Joint/Burgers_Residuals_CP.py:298-300) and
+    ``filter_sims_within_bounds`` (Active_Learning/Advection_AL_Marginal.py:169-198)."""
+    ns = {"np": np}
+    exec(ref_defs("Joint/Burgers_Residuals_CP.py", ["filter_sims_joint"]), ns)
+    exec(ref_defs("Active_Learning/Advection_AL_Marginal.py", ["filter_sims_within_bounds"]), ns)
+    rng = np.random.default_rng(11)
+    y = rng.standard_normal((40, 9, 13)).astype(np.float32)
+    q = np.abs(rng.standard_normal((9, 13))).astype(np.float32) + 0.5
+    y[3] = np.clip(y[3], -q, q)                       # one sample fully inside, edges exactly on the bound
+    out = {"y": y, "q": q}
+    for scale in (1.0, 2.0, 3.5):
+        out[f"joint|{scale}"] = ns["filter_sims_joint"]([-scale * q, scale * q], y)
+        for thr in (0.25, 0.5, 0.9):
+            for within in (False, True):
+                out[f"within|{scale}|{thr}|{int(within)}"] = ns["filter_sims_within_bounds"](-scale * q, scale * q, y, thr, within=within)
+    np.savez_compressed(os.path.join(HERE, "filters.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "filters" in sys.argv[1:]:
+        gen_filters()
+        sys.exit(0)
     ks = gen_kernels()
     gen_apply(ks)
     gen_residuals()
     gen_conformal()
+    gen_filters()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -476,3 +476,23 @@ def test_permuted_surrogate_layout_large(gpu):
     assert rel_err(got.cpu().numpy(), ref.numpy()) <= RES_TOL
     w = PRE_Wave(0.01, 0.02).residual(sur.to(gpu).permute(0, 1, 4, 2, 3)[:, :1])
     assert rel_err(w.cpu().numpy(), orr.wave_residual(view[:, 0], 1.0, 0.01, 0.02).numpy()) <= RES_TOL
+
+
+def test_reference_defined_filters_on_gpu(gpu):
+    """filter_sims_joint (Joint/Burgers_Residuals_CP.py:298-300) and filter_sims_within_bounds
+    (Active_Learning/Advection_AL_Marginal.py:169-198) against outputs of the reference's own functions."""
+    from conftest import load_golden
+    from cp_pre_amd import inductive_cp as icp
+    g = load_golden("filters.npz")
+    y, q = g["y"], g["q"]
+    for key in g.files:
+        parts = key.split("|")
+        if parts[0] == "joint":
+            sc = float(parts[1])
+            assert np.array_equal(icp.filter_sims_joint([-sc * q, sc * q], y), g[key]), key
+        elif parts[0] == "within":
+            sc, thr, within = float(parts[1]), float(parts[2]), bool(int(parts[3]))
+            got = icp.filter_sims_within_bounds(-sc * q, sc * q, y, thr, within=within)
+            assert got.dtype == bool and np.array_equal(got, g[key]), key
+    yt = torch.from_numpy(y).to(gpu)
+    assert icp.filter_sims_within_bounds(-q, q, yt, 0.5, within=True).is_cuda

@@ -147,3 +147,23 @@ def test_inline_joint_recipe_of_reference_tests():
     sets = [-q * modulation, q * modulation]
     cov = ((cal >= sets[0]).all(axis=(1, 2)) & (cal <= sets[1]).all(axis=(1, 2))).mean()
     assert oc.emp_cov_joint(sets, cal) == cov
+
+
+def test_reference_defined_filters(golden_filters=None):
+    """filter_sims_joint / filter_sims_within_bounds are defined in the reference tree itself:
+    the oracle is pinned to outputs of those very functions (tests/golden/filters.npz)."""
+    from conftest import load_golden
+    g = load_golden("filters.npz")
+    y, q = g["y"], g["q"]
+    n = 0
+    for key in g.files:
+        parts = key.split("|")
+        if parts[0] == "joint":
+            sc = float(parts[1])
+            assert np.array_equal(oc.filter_sims_joint([-sc * q, sc * q], y), g[key]), key
+            n += 1
+        elif parts[0] == "within":
+            sc, thr, within = float(parts[1]), float(parts[2]), bool(int(parts[3]))
+            assert np.array_equal(oc.filter_sims_within_bounds(-sc * q, sc * q, y, thr, within=within), g[key]), key
+            n += 1
+    assert n == 3 + 18
