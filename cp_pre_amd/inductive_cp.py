@@ -162,10 +162,24 @@ def ncf_metric_joint(a, b, modulation, crop=0):
     return res.astype(np.float64) if _wide(a, b, modulation) else res
 
 
-def _bounds(pred_sets, y):
+def _directed_f32(a, up):
+    """float64 bound -> float32 rounded towards +inf (``up``) or -inf, so that comparing a float32
+    sample with the float32 bound decides exactly like numpy's float64 comparison
+    (``y >= lo64``  <=>  ``y >= ceil32(lo64)``;  ``y <= hi64``  <=>  ``y <= floor32(hi64)``)."""
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float64) and not isinstance(a, float):
+        return a
+    a64 = np.asarray(a, np.float64)
+    a32 = a64.astype(np.float32)
+    wrong = (a32 < a64) if up else (a32 > a64)
+    fixed = np.nextafter(a32, np.float32(np.inf if up else -np.inf), dtype=np.float32)
+    return np.where(wrong, fixed, a32).astype(np.float32)
+
+
+def _bounds(pred_sets, y, outside=False):
     dy, _ = _dev(y)
-    lo, _ = _dev(pred_sets[0])
-    hi, _ = _dev(pred_sets[1])
+    # inside test: y >= lo & y <= hi; outside test: y <= lo | y >= hi  (opposite rounding directions)
+    lo, _ = _dev(_directed_f32(pred_sets[0], up=not outside))
+    hi, _ = _dev(_directed_f32(pred_sets[1], up=outside))
     n, M = dy.shape[0], dy.numel() // dy.shape[0]
     per_sample = []
     for t in (lo, hi):
@@ -209,7 +223,7 @@ def filter_sims_joint(pred_sets, y):
 def filter_sims_within_bounds(lower_bound, upper_bound, samples, threshold, within=False):
     """``Active_Learning/Advection_AL_Marginal.py:169-198``: bool [n], True where at least
     ``threshold`` of a sample's cells lie inside [lo,hi] (``within``) or on/outside the bounds."""
-    dy, lo, hi, n, M, ps = _bounds([lower_bound, upper_bound], samples)
+    dy, lo, hi, n, M, ps = _bounds([lower_bound, upper_bound], samples, outside=not within)
     counts = torch.zeros(n, dtype=torch.int32, device=dy.device)
     with torch.cuda.device(dy.device):
         _lib.check(_lib.load().pre_cov_rowcount_f32(_lib.ptr(dy), _lib.ptr(lo), _lib.ptr(hi), n, M, ps, 0 if within else 1,

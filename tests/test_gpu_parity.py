@@ -496,3 +496,66 @@ def test_reference_defined_filters_on_gpu(gpu):
             assert got.dtype == bool and np.array_equal(got, g[key]), key
     yt = torch.from_numpy(y).to(gpu)
     assert icp.filter_sims_within_bounds(-q, q, yt, 0.5, within=True).is_cuda
+
+
+def test_reference_script_shaped_usage_through_compat_shims(gpu):
+    """The lines a Marginal/ or Joint/ script executes, with the reference's own import paths
+    (cp_pre_amd/compat on sys.path) and CPU tensors / numpy arrays exactly as the scripts pass them:
+    Marginal/Wave_Residuals_CP.py:168-184,280-290 and Joint/Burgers_Residuals_CP.py:171-187,272-285."""
+    import importlib
+    import os
+    import sys
+    from conftest import ROOT
+    from oracle import conformal as oc
+    from oracle import residuals as orr
+    sys.path.insert(0, os.path.join(ROOT, "cp_pre_amd", "compat"))
+    try:
+        for m in [k for k in sys.modules if k == "Utils" or k.startswith("Utils.") or k.startswith("Neural_PDE")]:
+            del sys.modules[m]
+        ConvOperator = importlib.import_module("Utils.ConvOps_2d").ConvOperator
+        cp = importlib.import_module("Neural_PDE.UQ.inductive_cp")
+        g = torch.Generator().manual_seed(13)
+        c, dt, dx = 1.0, 0.01, 0.02
+        D_tt = ConvOperator('t', 2)
+        D_xx_yy = ConvOperator(('x', 'y'), 2)
+        D = ConvOperator()
+        cc = torch.tensor(c, dtype=torch.float32)
+        D.kernel = D_tt.kernel - (cc * dt / dx) ** 2 * D_xx_yy.kernel
+        uu = torch.randn(30, 8, 12, 16, generator=g)                    # CPU tensor, like cal_pred.permute(...)[:,0]
+        res = D(uu)[..., 1:-1, 1:-1, 1:-1]
+        assert not res.is_cuda
+        ref = orr.wave_residual(uu, c, dt, dx)
+        assert rel_err(res.numpy(), ref.numpy()) <= RES_TOL
+        ncf_scores = np.abs(res.numpy())
+        for alpha in np.arange(0.05, 0.95 + 0.1, 0.1):
+            qhat = cp.calibrate(scores=ncf_scores, n=len(ncf_scores), alpha=alpha)
+            assert np.array_equal(qhat, oc.calibrate(np.abs(res.numpy()), len(ncf_scores), alpha))
+            cov = cp.emp_cov([-qhat, +qhat], res.numpy())
+            assert cov == pytest.approx(oc.emp_cov([-qhat, qhat], res.numpy()), abs=1e-12)
+        # joint flavour on a 1-D problem
+        ConvOperator1 = importlib.import_module("Utils.ConvOps_1d").ConvOperator
+        D_t, D_x, D_xx = ConvOperator1(domain='t', order=1), ConvOperator1(domain='x', order=1), ConvOperator1(domain='x', order=2)
+        bdx, bdt, nu = (torch.tensor(v, dtype=torch.float32) for v in (2 / 64, 1.25 / 20, 0.002))
+        u1 = torch.rand(40, 20, 64, generator=g) + 0.5
+        r1 = (bdx * D_t(u1) + bdt * u1 * D_x(u1) - nu * D_xx(u1) * (2 * bdt / bdx))[..., 1:-1, 1:-1]
+        assert rel_err(r1.numpy(), orr.burgers_residual(u1, 2 / 64, 1.25 / 20, 0.002).numpy()) <= RES_TOL
+        rn = r1.numpy()
+        modulation = cp.modulation_func(rn, np.zeros(rn.shape))
+        scores = cp.ncf_metric_joint(rn, np.zeros(rn.shape), modulation)
+        mref = oc.modulation_func(rn, np.zeros(rn.shape))
+        sref = oc.ncf_metric_joint(rn, np.zeros(rn.shape), mref)
+        assert np.max(np.abs(scores - sref) / sref) <= QHAT_TOL
+        q = cp.calibrate(scores=scores, n=len(scores), alpha=0.5)
+        assert abs(q - oc.calibrate(sref, len(sref), 0.5)) <= QHAT_TOL * abs(q)
+        sets = [-q * modulation, +q * modulation]
+        assert cp.emp_cov_joint(sets, rn) == pytest.approx(oc.emp_cov_joint(sets, rn), abs=1e-12)
+        assert np.array_equal(cp.filter_sims_joint(sets, rn), oc.filter_sims_joint(sets, rn))
+    finally:
+        sys.path.remove(os.path.join(ROOT, "cp_pre_amd", "compat"))
+        for m in [k for k in sys.modules if k == "Utils" or k.startswith("Utils.") or k.startswith("Neural_PDE")]:
+            del sys.modules[m]
+
+
+def test_graft_smoke(gpu):
+    import __graft_entry__ as ge
+    ge.smoke()
