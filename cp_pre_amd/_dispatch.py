@@ -65,16 +65,17 @@ def taps_of(karr):
 def to_device(t):
     """(device tensor, original device).  Raises without a GPU: no CPU fallback.
 
-    Views whose last axis is not contiguous (the surrogate's native [BS,F,Nx,Ny,Nt] layout seen
-    through ``permute(0,1,4,2,3)``, Marginal/Wave_Residuals_CP.py:216) are re-laid out once by
-    a device copy (8 B/cell, counted against the roofline in DESIGN.md) so they take the
-    streaming kernels; small ones go straight to the generic strided kernel."""
+    Views with a unit-stride axis - the reference layout, and the surrogate's native
+    [BS,F,Nx,Ny,Nt] layout seen through ``permute(0,1,4,2,3)`` (Marginal/Wave_Residuals_CP.py:216),
+    whose fastest axis is Nt - are consumed in place: the library relabels its axes and the result
+    gets the same memory layout.  Only large views with NO unit-stride axis (e.g. ``x[..., ::2]``)
+    are re-laid out by a device copy first; small ones go to the generic strided kernel."""
     if t.is_cuda:
-        if t.dim() >= 3 and t.stride(-1) != 1 and t.numel() >= (1 << 16):
+        if t.dim() >= 3 and t.numel() >= (1 << 16) and not _lib.streamable(t):
             t = t.contiguous()
         return t, None
     _lib.require_gpu()
-    return t.contiguous().cuda(), t.device
+    return t.cuda(), t.device
 
 
 def from_device(out, origin):
@@ -154,19 +155,19 @@ def _xcorr_impl(field, kernel, nd, flags=0):
         raise RuntimeError(f"expected a {nd + 1}-D field [BS,Nt,Nx{',Ny' if nd == 3 else ''}], got {tuple(field.shape)}")
     lib = _lib.load()
     dev, origin = to_device(field)
-    out = torch.empty(dev.shape, dtype=torch.float32, device=dev.device)
+    out = _lib.empty_like_layout(dev)
     if out.numel() == 0:
         return from_device(out, origin)
     wv = _lib.farr(w) if len(w) else (ctypes.c_float * 1)()
     ov = _lib.iarr32(off.reshape(-1)) if len(w) else (ctypes.c_int32 * 1)()
     with torch.cuda.device(dev.device):
         if nd == 3:
-            f = _lib.field(dev)
-            rc = lib.pre_stencil3d_f32(ctypes.byref(f), _lib.ptr(out), wv, ov, len(w), *dev.shape, flags, _lib.stream())
+            f, o = _lib.field(dev), _lib.field(out)
+            rc = lib.pre_stencil3d_f32(ctypes.byref(f), ctypes.byref(o), wv, ov, len(w), *dev.shape, flags, _lib.stream())
             _lib.check(rc, "pre_stencil3d_f32")
         else:
-            rc = lib.pre_stencil2d_f32(_lib.ptr(dev), _lib.iarr64(dev.stride()), _lib.ptr(out), wv, ov, len(w),
-                                       *dev.shape, flags, _lib.stream())
+            rc = lib.pre_stencil2d_f32(_lib.ptr(dev), _lib.iarr64(dev.stride()), _lib.ptr(out), _lib.iarr64(out.stride()),
+                                       wv, ov, len(w), *dev.shape, flags, _lib.stream())
             _lib.check(rc, "pre_stencil2d_f32")
     return from_device(out, origin)
 

@@ -23,7 +23,7 @@ _ERR = {PRE_E_NULL: "null pointer / bad size", PRE_E_SHAPE: "unsupported shape",
 
 
 class PreField(ctypes.Structure):
-    """``pre_field_t``: a strided [B,T,X,Y] view (element strides)."""
+    """``pre_field_t`` / ``pre_out_t`` (same layout): a strided [B,T,X,Y] view (element strides)."""
     _fields_ = [("ptr", c_void_p), ("sB", c_int64), ("sT", c_int64), ("sX", c_int64), ("sY", c_int64)]
 
 
@@ -31,12 +31,12 @@ _fp, _fld = c_void_p, POINTER(PreField)
 # name -> argtypes; every symbol include/cp_pre_hip.h declares
 SIGNATURES = {
     "pre_abi_version": [],
-    "pre_stencil3d_f32": [_fld, _fp, POINTER(c_float), POINTER(c_int32), c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p],
-    "pre_stencil2d_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_float), POINTER(c_int32), c_int, c_int64, c_int64, c_int64, c_int, c_void_p],
-    "pre_residual_ns_momentum_f32": [_fld, _fld, _fld, _fp] + [POINTER(c_float)] * 4 + [c_float] * 4 + [c_int64] * 4 + [c_int, c_void_p],
-    "pre_residual_linear2_f32": [_fld, _fld, _fp, POINTER(c_float), POINTER(c_float), c_float] + [c_int64] * 4 + [c_int, c_void_p],
-    "pre_residual_burgers_f32": [_fp, POINTER(c_int64), _fp] + [POINTER(c_float)] * 3 + [c_float] * 4 + [c_int64] * 3 + [c_int, c_void_p],
-    "pre_residual_mhd_f32": [c_int, POINTER(PreField), _fp] + [POINTER(c_float)] * 3 + [c_double] + [c_int64] * 4 + [c_int, c_void_p],
+    "pre_stencil3d_f32": [_fld, _fld, POINTER(c_float), POINTER(c_int32), c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p],
+    "pre_stencil2d_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_int64), POINTER(c_float), POINTER(c_int32), c_int, c_int64, c_int64, c_int64, c_int, c_void_p],
+    "pre_residual_ns_momentum_f32": [_fld, _fld, _fld, _fld] + [POINTER(c_float)] * 4 + [c_float] * 4 + [c_int64] * 4 + [c_int, c_void_p],
+    "pre_residual_linear2_f32": [_fld, _fld, _fld, POINTER(c_float), POINTER(c_float), c_float] + [c_int64] * 4 + [c_int, c_void_p],
+    "pre_residual_burgers_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_int64)] + [POINTER(c_float)] * 3 + [c_float] * 4 + [c_int64] * 3 + [c_int, c_void_p],
+    "pre_residual_mhd_f32": [c_int, POINTER(PreField), _fld] + [POINTER(c_float)] * 3 + [c_double] + [c_int64] * 4 + [c_int, c_void_p],
     "pre_absdiff_f32": [_fp, _fp, _fp, c_int64, c_void_p],
     "pre_std_axis0_f32": [_fp, _fp, c_int64, c_int64, c_float, _fp, c_void_p],
     "pre_moments_axis0_f64": [_fp, _fp, c_int64, c_int64, _fp, _fp, c_void_p],
@@ -97,6 +97,25 @@ def field(t):
     assert t.dim() == 4
     s = t.stride()
     return PreField(t.data_ptr(), s[0], s[1], s[2], s[3])
+
+
+def empty_like_layout(t):
+    """Uninitialised fp32 tensor with ``t``'s shape and ``t``'s axis order in memory (dense): a
+    [BS,Nt,Nx,Ny] view of a [BS,Nx,Ny,Nt] buffer gets an output laid out the same way, so the
+    streaming kernels read and write along the same contiguous axis."""
+    if t.is_contiguous():
+        return torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    order = sorted(range(t.dim()), key=lambda d: (-t.stride(d), d))         # slowest axis first
+    strides, acc = [0] * t.dim(), 1
+    for d in reversed(order):
+        strides[d] = acc
+        acc *= t.shape[d]
+    return torch.empty_strided(tuple(t.shape), tuple(strides), dtype=torch.float32, device=t.device)
+
+
+def streamable(*views):
+    """True if one of the last three axes has unit stride in every view (library relabels axes)."""
+    return any(all(v.stride(ax) == 1 for v in views) for ax in (-1, -2, -3) if views[0].dim() >= -ax)
 
 
 def farr(values):

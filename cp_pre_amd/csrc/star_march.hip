@@ -26,6 +26,7 @@ struct Geom {
     const float *f[MAXF];
     long long sB[MAXF], sT[MAXF], sX[MAXF];
     float *out;
+    long long oB, oT, oX;        // output strides (elements); the marched-to axis is contiguous
     int B, T, X, Y;
     int tSeg, nTSeg, nXT, nYT;
     int flags;
@@ -39,7 +40,7 @@ struct Nbr { float4 c, tm, tp, xm, xp, ym, yp; };
 __device__ __forceinline__ float4 f4(float s) { return make_float4(s, s, s, s); }
 __device__ __forceinline__ float4 fabs4(const float4 &a) { return make_float4(fabsf(a.x), fabsf(a.y), fabsf(a.z), fabsf(a.w)); }
 
-enum Kind { K_T3, K_X3, K_Y3, K_XY5, K_STAR7 };
+enum Kind { K_T3, K_X3, K_Y3, K_XY5, K_TX5, K_STAR7 };
 
 template <int KIND>
 __device__ __forceinline__ float4 apply(const Star &w, const Nbr &n)
@@ -48,6 +49,7 @@ __device__ __forceinline__ float4 apply(const Star &w, const Nbr &n)
     if (KIND == K_X3) return w.xm * n.xm + w.c * n.c + w.xp * n.xp;
     if (KIND == K_Y3) return w.ym * n.ym + w.c * n.c + w.yp * n.yp;
     if (KIND == K_XY5) return w.xm * n.xm + w.ym * n.ym + w.c * n.c + w.yp * n.yp + w.xp * n.xp;
+    if (KIND == K_TX5) return w.tm * n.tm + w.xm * n.xm + w.c * n.c + w.xp * n.xp + w.tp * n.tp;
     return w.tm * n.tm + w.xm * n.xm + w.ym * n.ym + w.c * n.c + w.yp * n.yp + w.xp * n.xp + w.tp * n.tp;
 }
 
@@ -55,11 +57,14 @@ __device__ __forceinline__ float4 apply(const Star &w, const Nbr &n)
 // MODE 0: the tap structure the reference constructs (D_t,D_y along Nt; D_x along Nx;
 //         Laplacian on the (Nx,Ny) cross).  MODE 1: D_y along Ny (the physically intended
 //         stencil).  MODE 2: every operator a general 7-point star.
+// MODE 3 / 4: MODE 0 / 1 after the axis relabelling for Nt-fastest views (kernel axes =
+//         logical (Nx, Ny, Nt)): logical t-taps sit on the kernel's y axis, x-taps on its t axis,
+//         y-taps on its x axis.
 template <int MODE> struct OpKinds {
-    static constexpr int DT = MODE == 2 ? K_STAR7 : K_T3;
-    static constexpr int DX = MODE == 2 ? K_STAR7 : K_X3;
-    static constexpr int DY = MODE == 2 ? K_STAR7 : (MODE == 1 ? K_Y3 : K_T3);
-    static constexpr int LAP = MODE == 2 ? K_STAR7 : K_XY5;
+    static constexpr int DT = MODE == 2 ? K_STAR7 : (MODE >= 3 ? K_Y3 : K_T3);
+    static constexpr int DX = MODE == 2 ? K_STAR7 : (MODE >= 3 ? K_T3 : K_X3);
+    static constexpr int DY = MODE == 2 ? K_STAR7 : (MODE == 0 ? K_T3 : MODE == 1 ? K_Y3 : MODE == 3 ? K_Y3 : K_X3);
+    static constexpr int LAP = MODE == 2 ? K_STAR7 : (MODE >= 3 ? K_TX5 : K_XY5);
 };
 
 struct Linear1 {       // out = S(f0): any single ConvOperator / additive kernel (README.md:47-54)
@@ -110,7 +115,8 @@ struct Burgers {       // Joint/Burgers_Residuals_CP.py:182-187
     using Params = BurgersParams;
     static __device__ __forceinline__ float4 eval(const Nbr (&n)[1], const Params &p)
     {
-        constexpr int KT = MODE == 2 ? K_STAR7 : K_X3, KX = MODE == 2 ? K_STAR7 : K_Y3;
+        // MODE 0: Nx fastest (D_t on the kernel's x axis, D_x on y); MODE 3: Nt fastest (swapped)
+        constexpr int KT = MODE == 0 ? K_X3 : MODE == 3 ? K_Y3 : K_STAR7, KX = MODE == 0 ? K_Y3 : MODE == 3 ? K_X3 : K_STAR7;
         const Nbr &u = n[0];
         float4 r = p.dx * apply<KT>(p.Dt, u);
         r = r + (p.dt * u.c) * apply<KX>(p.Dx, u);
@@ -250,8 +256,8 @@ __global__ void __launch_bounds__(NR *TYQ) march_kernel(const Geom g, const type
         own[i] = base + (long long)x * g.sX[i] + y;
         hal[i] = base + (long long)hx * g.sX[i] + y;
     }
-    float *outp = g.out + (((long long)b * g.T) * g.X + x) * (long long)g.Y + y;
-    const long long oT = (long long)g.X * g.Y;
+    float *outp = g.out + (long long)b * g.oB + (long long)x * g.oX + y;
+    const long long oT = g.oT;
 
     auto load_own = [&](int t, float4(&dst)[F]) __attribute__((always_inline)) {
         const bool ok = inb && (t >= 0) && (t < g.T);
@@ -359,18 +365,6 @@ int pick_mode(const Star &Dt, const Star &Dx, const Star &Dy, const Star *L)
     return 2;
 }
 
-bool fast_layout_ok(const pre_field_t *const *fs, int nf, int64_t Y, const float *out)
-{
-    if (Y % 4 != 0) return false;
-    if (((uintptr_t)out) & 15) return false;
-    for (int i = 0; i < nf; ++i) {
-        const pre_field_t *f = fs[i];
-        if (f->sY != 1) return false;
-        if ((((uintptr_t)f->ptr) & 15) || (f->sB % 4) || (f->sT % 4) || (f->sX % 4)) return false;
-    }
-    return true;
-}
-
 template <class Fn, int NR, int TYQ>
 int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st)
 {
@@ -398,114 +392,168 @@ int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st)
 {
     // 512 threads per workgroup; rows of the tile trade halo re-reads (2/NR) against columns covered
     // 8 rows x 256 columns: measured best of {4,8,16} rows (16 rows = 1024 threads, one workgroup per CU: -5 %)
+    // (also measured: 16x128 and 32x64 tiles at 512 threads, -2..-7 % on every functor)
     if (g.Y >= 192) return launch_tiled<Fn, 8, 64>(g, prm, st);
     if (g.Y >= 96) return launch_tiled<Fn, 16, 32>(g, prm, st);
     return launch_tiled<Fn, 32, 16>(g, prm, st);
 }
 
-int fill_geom(Geom &g, const pre_field_t *const *fs, int nf, float *out, int64_t B, int64_t T, int64_t X, int64_t Y, int flags)
+// Fill the kernel geometry from the caller's views and RELABEL the axes so that the kernel's
+// contiguous "y" axis is whichever of (T, X, Y) has unit stride in every view:
+//   Y contiguous (reference layout [BS,Nt,Nx,Ny])            -> identity
+//   T contiguous (surrogate output [BS,F,Nx,Ny,Nt] seen through permute(0,1,4,2,3),
+//                 Marginal/Wave_Residuals_CP.py:216)          -> kernel axes (X, Y, T)
+//   X contiguous                                              -> kernel axes (T, Y, X)
+// The star weights are permuted with the axes, the output view must share the layout, and the
+// arithmetic is unchanged - zero-copy for the layouts real callers hand in.  Returns
+// PRE_E_UNSUPPORTED when no common unit-stride axis / alignment exists.
+int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const pre_out_t *out,
+            int64_t B, int64_t T, int64_t X, int64_t Y, int flags, Star *const *stars, int nstars)
 {
-    if (!out || B <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
+    if (!out || !out->ptr || B <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
     if (B > 0x7fffffff || T > 0x7fffffff || X > 0x7fffffff || Y > 0x7fffffff) return PRE_E_SHAPE;
-    for (int i = 0; i < nf; ++i) {
+    for (int i = 0; i < nf; ++i)
         if (!fs[i] || !fs[i]->ptr) return PRE_E_NULL;
-        g.f[i] = fs[i]->ptr; g.sB[i] = fs[i]->sB; g.sT[i] = fs[i]->sT; g.sX[i] = fs[i]->sX;
+    const int64_t D[3] = {T, X, Y};
+    auto stride = [](const pre_field_t *f, int ax) { return ax == 0 ? f->sT : ax == 1 ? f->sX : f->sY; };
+    auto ostride = [&](int ax) { return ax == 0 ? out->sT : ax == 1 ? out->sX : out->sY; };
+    auto all_unit = [&](int ax) {
+        if (ostride(ax) != 1) return false;
+        for (int i = 0; i < nf; ++i)
+            if (stride(fs[i], ax) != 1) return false;
+        return true;
+    };
+    int p[3];
+    if (all_unit(2)) { p[0] = 0; p[1] = 1; p[2] = 2; }
+    else if (all_unit(0)) { p[0] = 1; p[1] = 2; p[2] = 0; }
+    else if (all_unit(1)) { p[0] = 0; p[1] = 2; p[2] = 1; }
+    else return PRE_E_UNSUPPORTED;
+    relabeled = p[2] == 2 ? 0 : (p[2] == 0 ? 1 : 2);      // 0 identity, 1 kernel axes (X,Y,T), 2 kernel axes (T,Y,X)
+    if (D[p[2]] % 4 != 0) return PRE_E_UNSUPPORTED;
+    auto aligned = [](const void *ptr, int64_t a, int64_t b2, int64_t c) {
+        return !(((uintptr_t)ptr) & 15) && a % 4 == 0 && b2 % 4 == 0 && c % 4 == 0;
+    };
+    if (!aligned(out->ptr, out->sB, ostride(p[0]), ostride(p[1]))) return PRE_E_UNSUPPORTED;
+    for (int i = 0; i < nf; ++i) {
+        if (!aligned(fs[i]->ptr, fs[i]->sB, stride(fs[i], p[0]), stride(fs[i], p[1]))) return PRE_E_UNSUPPORTED;
+        g.f[i] = fs[i]->ptr; g.sB[i] = fs[i]->sB; g.sT[i] = stride(fs[i], p[0]); g.sX[i] = stride(fs[i], p[1]);
     }
     for (int i = nf; i < MAXF; ++i) { g.f[i] = nullptr; g.sB[i] = g.sT[i] = g.sX[i] = 0; }
-    g.out = out; g.B = (int)B; g.T = (int)T; g.X = (int)X; g.Y = (int)Y; g.flags = flags;
+    g.out = out->ptr; g.oB = out->sB; g.oT = ostride(p[0]); g.oX = ostride(p[1]);
+    g.B = (int)B; g.T = (int)D[p[0]]; g.X = (int)D[p[1]]; g.Y = (int)D[p[2]]; g.flags = flags;
+    if (relabeled)
+        for (int k = 0; k < nstars; ++k) {
+            const Star o = *stars[k];
+            const float m[3] = {o.tm, o.xm, o.ym}, q[3] = {o.tp, o.xp, o.yp};
+            stars[k]->tm = m[p[0]]; stars[k]->tp = q[p[0]];
+            stars[k]->xm = m[p[1]]; stars[k]->xp = q[p[1]];
+            stars[k]->ym = m[p[2]]; stars[k]->yp = q[p[2]];
+        }
     return PRE_OK;
 }
+
+// tap structure after the relabelling: the Nt-fastest permutation maps modes 0/1 to 3/4,
+// every other permuted layout runs the general-star instantiation
+inline int relabeled_mode(int mode, int rel) { return rel == 0 ? mode : (rel == 1 && mode < 2 ? mode + 3 : 2); }
 
 template <template <int> class FnT, class P>
 int launch_mode(int mode, Geom &g, const P &prm, hipStream_t st)
 {
     if (mode == 0) return launch<FnT<0>>(g, prm, st);
     if (mode == 1) return launch<FnT<1>>(g, prm, st);
+    if (mode == 3) return launch<FnT<3>>(g, prm, st);
+    if (mode == 4) return launch<FnT<4>>(g, prm, st);
     return launch<FnT<2>>(g, prm, st);
 }
 
 }  // namespace
 
 // Internal: called by stencil_generic.hip when a tap list is star-shaped and the layout allows it.
-int pre_star_try_linear1(const pre_field_t *in, float *out, const float star7[7],
+int pre_star_try_linear1(const pre_field_t *in, const pre_out_t *out, const float star7[7],
                          int64_t B, int64_t T, int64_t X, int64_t Y, int flags, hipStream_t st)
 {
     const pre_field_t *fs[1] = {in};
-    if (!fast_layout_ok(fs, 1, Y, out)) return PRE_E_UNSUPPORTED;
-    Geom g;
-    int rc = fill_geom(g, fs, 1, out, B, T, X, Y, flags);
-    if (rc) return rc;
     Linear1::Params p;
     p.s = Star{star7[0], star7[1], star7[2], star7[3], star7[4], star7[5], star7[6]};
+    Star *stars[1] = {&p.s};
+    Geom g;
+    int rel;
+    int rc = prepare(g, rel, fs, 1, out, B, T, X, Y, flags, stars, 1);
+    if (rc) return rc;
     return launch<Linear1>(g, p, st);
 }
 
 extern "C" {
 
-int pre_residual_ns_momentum_f32(const pre_field_t *u, const pre_field_t *v, const pre_field_t *p, float *out,
+int pre_residual_ns_momentum_f32(const pre_field_t *u, const pre_field_t *v, const pre_field_t *p, const pre_out_t *out,
                                  const float *K_t, const float *K_x, const float *K_y, const float *K_xx_yy,
                                  float dt, float dx, float dy, float nu,
                                  int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)
 {
     if (!K_t || !K_x || !K_y || !K_xx_yy) return PRE_E_NULL;
     const pre_field_t *fs[3] = {u, v, p};
-    Geom g;
-    int rc = fill_geom(g, fs, 3, out, B, T, X, Y, flags);
-    if (rc) return rc;
     NSParams prm;
     if (!star_from_dense27(K_t, &prm.Dt) || !star_from_dense27(K_x, &prm.Dx) ||
         !star_from_dense27(K_y, &prm.Dy) || !star_from_dense27(K_xx_yy, &prm.L))
         return PRE_E_UNSUPPORTED;
-    if (!fast_layout_ok(fs, 3, Y, out)) return PRE_E_UNSUPPORTED;
+    const int mode = pick_mode(prm.Dt, prm.Dx, prm.Dy, &prm.L);      // on the caller's axes
+    Star *stars[4] = {&prm.Dt, &prm.Dx, &prm.Dy, &prm.L};
+    Geom g;
+    int rel;
+    int rc = prepare(g, rel, fs, 3, out, B, T, X, Y, flags, stars, 4);
+    if (rc) return rc;
     prm.dt = dt; prm.dx = dx; prm.dy = dy; prm.nu = nu;
-    return launch_mode<NSMomentum>(pick_mode(prm.Dt, prm.Dx, prm.Dy, &prm.L), g, prm, as_stream(stream));
+    return launch_mode<NSMomentum>(relabeled_mode(mode, rel), g, prm, as_stream(stream));
 }
 
-int pre_residual_linear2_f32(const pre_field_t *f0, const pre_field_t *f1, float *out,
+int pre_residual_linear2_f32(const pre_field_t *f0, const pre_field_t *f1, const pre_out_t *out,
                              const float *K_a, const float *K_b, float ratio,
                              int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)
 {
     if (!K_a || !K_b) return PRE_E_NULL;
     const pre_field_t *fs[2] = {f0, f1};
-    Geom g;
-    int rc = fill_geom(g, fs, 2, out, B, T, X, Y, flags);
-    if (rc) return rc;
     Linear2::Params prm;
     if (!star_from_dense27(K_a, &prm.a) || !star_from_dense27(K_b, &prm.b)) return PRE_E_UNSUPPORTED;
-    if (!fast_layout_ok(fs, 2, Y, out)) return PRE_E_UNSUPPORTED;
+    Star *stars[2] = {&prm.a, &prm.b};
+    Geom g;
+    int rel;
+    int rc = prepare(g, rel, fs, 2, out, B, T, X, Y, flags, stars, 2);
+    if (rc) return rc;
     prm.ratio = ratio;
     return launch<Linear2>(g, prm, as_stream(stream));
 }
 
-int pre_residual_burgers_f32(const float *u, const int64_t in_strides[3], float *out,
+int pre_residual_burgers_f32(const float *u, const int64_t in_strides[3], float *out, const int64_t out_strides[3],
                              const float *K_t, const float *K_x, const float *K_xx,
                              float dx, float dt, float nu, float c3,
                              int64_t B, int64_t T, int64_t X, int flags, void *stream)
 {
-    if (!u || !in_strides || !K_t || !K_x || !K_xx) return PRE_E_NULL;
+    if (!u || !in_strides || !out || !out_strides || !K_t || !K_x || !K_xx) return PRE_E_NULL;
     // [B,T,X] -> [1, B, T, X]; 3x3 kernel (a over Nt, b over Nx) -> dense27 index (1, a, b)
     pre_field_t f{u, 0, in_strides[0], in_strides[1], in_strides[2]};
+    pre_out_t o{out, 0, out_strides[0], out_strides[1], out_strides[2]};
     const pre_field_t *fs[1] = {&f};
-    Geom g;
-    int rc = fill_geom(g, fs, 1, out, 1, B, T, X, flags);
-    if (rc) return rc;
     float d27[3][27] = {};
     const float *k9[3] = {K_t, K_x, K_xx};
-    for (int o = 0; o < 3; ++o)
+    for (int op = 0; op < 3; ++op)
         for (int a = 0; a < 3; ++a)
-            for (int c = 0; c < 3; ++c) d27[o][(1 * 3 + a) * 3 + c] = k9[o][a * 3 + c];
+            for (int c = 0; c < 3; ++c) d27[op][(1 * 3 + a) * 3 + c] = k9[op][a * 3 + c];
     BurgersParams prm;
     if (!star_from_dense27(d27[0], &prm.Dt) || !star_from_dense27(d27[1], &prm.Dx) || !star_from_dense27(d27[2], &prm.Dxx))
         return PRE_E_UNSUPPORTED;
-    if (!fast_layout_ok(fs, 1, X, out)) return PRE_E_UNSUPPORTED;
-    prm.dx = dx; prm.dt = dt; prm.nu = nu; prm.c3 = c3;
     // mode 0 needs D_t purely along Nt (our x) and D_x, D_xx purely along Nx (our y)
     const Shape a = shape_of(prm.Dt), b2 = shape_of(prm.Dx), c2 = shape_of(prm.Dxx);
     const int mode = (!a.y && !b2.x && !c2.x) ? 0 : 2;
-    return launch_mode<Burgers>(mode, g, prm, as_stream(stream));
+    Star *stars[3] = {&prm.Dt, &prm.Dx, &prm.Dxx};
+    Geom g;
+    int rel;
+    int rc = prepare(g, rel, fs, 1, &o, 1, B, T, X, flags, stars, 3);
+    if (rc) return rc;
+    prm.dx = dx; prm.dt = dt; prm.nu = nu; prm.c3 = c3;
+    return launch_mode<Burgers>(rel == 0 ? mode : (rel == 2 && mode == 0 ? 3 : 2), g, prm, as_stream(stream));
 }
 
-int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], float *out,
+int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], const pre_out_t *out,
                          const float *K_t, const float *K_x, const float *K_y, double gamma,
                          int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)
 {
@@ -516,29 +564,28 @@ int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], float *out,
         return PRE_E_UNSUPPORTED;
     prm.gamma = (float)gamma;
     prm.gm2 = (float)(gamma - 2.0);   // "(gamma-2)" is a float64 Python scalar in the reference
-    const int mode = pick_mode(prm.Dt, prm.Dx, prm.Dy, nullptr);
+    int mode = pick_mode(prm.Dt, prm.Dx, prm.Dy, nullptr);
     const pre_field_t *all[6] = {&fields[0], &fields[1], &fields[2], &fields[3], &fields[4], &fields[5]};
+    Star *stars[3] = {&prm.Dt, &prm.Dx, &prm.Dy};
     Geom g;
+    int rel;
     hipStream_t st = as_stream(stream);
     if (eq == 0) {
         const pre_field_t *fs[3] = {all[0], all[1], all[2]};
-        int rc = fill_geom(g, fs, 3, out, B, T, X, Y, flags);
+        int rc = prepare(g, rel, fs, 3, out, B, T, X, Y, flags, stars, 3);
         if (rc) return rc;
-        if (!fast_layout_ok(fs, 3, Y, out)) return PRE_E_UNSUPPORTED;
-        return launch_mode<MHDContinuity>(mode, g, prm, st);
+        return launch_mode<MHDContinuity>(relabeled_mode(mode, rel), g, prm, st);
     }
     if (eq == 3) {
         const pre_field_t *fs[4] = {all[1], all[2], all[4], all[5]};
-        int rc = fill_geom(g, fs, 4, out, B, T, X, Y, flags);
+        int rc = prepare(g, rel, fs, 4, out, B, T, X, Y, flags, stars, 3);
         if (rc) return rc;
-        if (!fast_layout_ok(fs, 4, Y, out)) return PRE_E_UNSUPPORTED;
-        return launch_mode<MHDInduction>(mode, g, prm, st);
+        return launch_mode<MHDInduction>(relabeled_mode(mode, rel), g, prm, st);
     }
-    int rc = fill_geom(g, all, 6, out, B, T, X, Y, flags);
+    int rc = prepare(g, rel, all, 6, out, B, T, X, Y, flags, stars, 3);
     if (rc) return rc;
-    if (!fast_layout_ok(all, 6, Y, out)) return PRE_E_UNSUPPORTED;
-    if (eq == 1) return launch_mode<MHDMomentum>(mode, g, prm, st);
-    return launch_mode<MHDEnergy>(mode, g, prm, st);
+    if (eq == 1) return launch_mode<MHDMomentum>(relabeled_mode(mode, rel), g, prm, st);
+    return launch_mode<MHDEnergy>(relabeled_mode(mode, rel), g, prm, st);
 }
 
 }  // extern "C"

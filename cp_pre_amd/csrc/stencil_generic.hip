@@ -9,7 +9,7 @@
 // it is not on the benchmarked path.
 #include "common.h"
 
-int pre_star_try_linear1(const pre_field_t *in, float *out, const float star7[7],
+int pre_star_try_linear1(const pre_field_t *in, const pre_out_t *out, const float star7[7],
                          int64_t B, int64_t T, int64_t X, int64_t Y, int flags, hipStream_t st);
 
 namespace {
@@ -24,6 +24,7 @@ struct TapList {
 
 __global__ void __launch_bounds__(256) generic_kernel(const float *__restrict__ in, long long sB, long long sT,
                                                       long long sX, long long sY, float *__restrict__ out,
+                                                      long long oB, long long oT, long long oX, long long oY,
                                                       int B, int T, int X, int Y, int flags, const TapList taps)
 {
     const long long plane = (long long)X * Y;
@@ -42,7 +43,7 @@ __global__ void __launch_bounds__(256) generic_kernel(const float *__restrict__ 
             if (tt >= 0 && tt < T && xx >= 0 && xx < X && yy >= 0 && yy < Y)
                 acc += taps.w[i] * base[tt * sT + xx * sX + yy * sY];
         }
-        out[idx] = (flags & PRE_FLAG_ABS) ? fabsf(acc) : acc;
+        out[b * oB + t * oT + x * oX + y * oY] = (flags & PRE_FLAG_ABS) ? fabsf(acc) : acc;
     }
 }
 
@@ -50,12 +51,12 @@ __global__ void __launch_bounds__(256) generic_kernel(const float *__restrict__ 
 
 extern "C" {
 
-int pre_abi_version(void) { return 1; }
+int pre_abi_version(void) { return 2; }
 
-int pre_stencil3d_f32(const pre_field_t *in, float *out, const float *tap_w, const int32_t *tap_off, int ntaps,
+int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *tap_w, const int32_t *tap_off, int ntaps,
                       int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)
 {
-    if (!in || !in->ptr || !out || (ntaps > 0 && (!tap_w || !tap_off))) return PRE_E_NULL;
+    if (!in || !in->ptr || !out || !out->ptr || (ntaps > 0 && (!tap_w || !tap_off))) return PRE_E_NULL;
     if (B <= 0 || T <= 0 || X <= 0 || Y <= 0 || ntaps < 0) return PRE_E_NULL;
     if (ntaps > MAX_TAPS) return PRE_E_SHAPE;
     if (B > 0x7fffffff || T > 0x7fffffff || X > 0x7fffffff || Y > 0x7fffffff) return PRE_E_SHAPE;
@@ -87,16 +88,17 @@ int pre_stencil3d_f32(const pre_field_t *in, float *out, const float *tap_w, con
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in->ptr, (long long)in->sB,
-                       (long long)in->sT, (long long)in->sX, (long long)in->sY, out, (int)B, (int)T, (int)X, (int)Y,
-                       flags, taps);
+                       (long long)in->sT, (long long)in->sX, (long long)in->sY, out->ptr, (long long)out->sB,
+                       (long long)out->sT, (long long)out->sX, (long long)out->sY, (int)B, (int)T, (int)X, (int)Y, flags, taps);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }
 
-int pre_stencil2d_f32(const float *in, const int64_t in_strides[3], float *out, const float *tap_w,
-                      const int32_t *tap_off, int ntaps, int64_t B, int64_t T, int64_t X, int flags, void *stream)
+int pre_stencil2d_f32(const float *in, const int64_t in_strides[3], float *out, const int64_t out_strides[3],
+                      const float *tap_w, const int32_t *tap_off, int ntaps, int64_t B, int64_t T, int64_t X, int flags,
+                      void *stream)
 {
-    if (!in || !in_strides || (ntaps > 0 && !tap_off)) return PRE_E_NULL;
+    if (!in || !in_strides || !out || !out_strides || (ntaps > 0 && !tap_off)) return PRE_E_NULL;
     if (ntaps < 0 || ntaps > MAX_TAPS) return PRE_E_SHAPE;
     // [B,T,X] with taps (dt,dx)  ==  [1,B,T,X] with taps (0,dt,dx): the batch axis becomes the
     // (tap-free) marching axis, Nt the row axis and Nx the contiguous axis.
@@ -107,7 +109,8 @@ int pre_stencil2d_f32(const float *in, const int64_t in_strides[3], float *out, 
         off3[3 * i + 2] = tap_off[2 * i + 1];
     }
     pre_field_t f{in, 0, in_strides[0], in_strides[1], in_strides[2]};
-    return pre_stencil3d_f32(&f, out, tap_w, off3, ntaps, 1, B, T, X, flags, stream);
+    pre_out_t o{out, 0, out_strides[0], out_strides[1], out_strides[2]};
+    return pre_stencil3d_f32(&f, &o, tap_w, off3, ntaps, 1, B, T, X, flags, stream);
 }
 
 }  // extern "C"

@@ -29,13 +29,43 @@ from . import _dispatch, _lib
 
 
 # ------------------------------------------------------------------ marshalling
+def canon(d):
+    """(contiguous view [n, *cells in MEMORY order], order) of a dense tensor whose cell axes are
+    permuted in memory (e.g. a residual computed in the surrogate's [BS,Nx,Ny,Nt] layout): the
+    calibration kernels only need "n rows of M cells", so they run on the data where it lies.
+    ``order`` is None for an already-contiguous tensor; non-dense views are copied."""
+    if d.is_contiguous():
+        return d, None
+    if d.dim() >= 3:
+        order = sorted(range(1, d.dim()), key=lambda k: (-d.stride(k), k))
+        v = d.permute(0, *order)
+        if v.is_contiguous():
+            return v, order
+    return d.contiguous(), None
+
+
+def canon_cells(m, order):
+    """A per-cell array (no batch axis) in the memory order ``order`` chosen by :func:`canon`."""
+    return m.contiguous() if order is None else m.permute(*[o - 1 for o in order]).contiguous()
+
+
+def uncanon(r, order, lead):
+    """Inverse of the cell permutation on a result with ``lead`` leading non-cell axes."""
+    if order is None:
+        return r
+    inv = [0] * len(order)
+    for pos, o in enumerate(order):
+        inv[o - 1] = pos
+    return r.permute(*range(lead), *[lead + i for i in inv])
+
+
 def _dev(x, like=None):
-    """fp32 contiguous device tensor + a function that converts results back."""
+    """fp32 device tensor (layout untouched) + a function that converts results back."""
     if isinstance(x, torch.Tensor):
         if x.dtype != torch.float32:
             raise RuntimeError("cp_pre_amd.inductive_cp works on float32 tensors")
         d, origin = _dispatch.to_device(x)
-        return d.contiguous(), (lambda r: _dispatch.from_device(r, origin))
+        return d, (lambda r: _dispatch.from_device(r, origin))
     arr = np.asarray(x)
     if arr.dtype != np.float32:
         arr = arr.astype(np.float32)
@@ -69,6 +99,7 @@ def kth_axis0(scores, ks):
     """Order statistics ``ks`` (0-based ranks, any order) along axis 0 of a device tensor
     [n, ...] -> [len(ks), ...].  1-D scores use the scalar radix select."""
     lib = _lib.load()
+    scores, cell_order = canon(scores)
     n = scores.shape[0]
     order = sorted(range(len(ks)), key=lambda i: ks[i])
     sk = [int(ks[i]) for i in order]
@@ -87,7 +118,8 @@ def kth_axis0(scores, ks):
     inv = [0] * len(ks)
     for pos, i in enumerate(order):
         inv[i] = pos
-    return out[inv] if inv != list(range(len(ks))) else out
+    out = out[inv] if inv != list(range(len(ks))) else out
+    return uncanon(out, cell_order, 1)
 
 
 # ------------------------------------------------------------------ the five functions
@@ -109,6 +141,11 @@ def calibrate_multi(scores, n, alphas):
     return back(kth_axis0(d, ks))
 
 
+def _same_layout(t, order):
+    """``t`` ([n, *cells]) as a contiguous tensor in the memory order ``order`` of its partner."""
+    return t.contiguous() if order is None else t.permute(0, *order).contiguous()
+
+
 def _wide(*xs):
     """numpy promotes float32 - float64 to float64 (``modulation_func(res, np.zeros(res.shape))``,
     Joint/Burgers_Residuals_CP.py:274): such calls get the fp64-accumulated route and a float64 result."""
@@ -122,7 +159,8 @@ def modulation_func(a, b=None, eps=0.0):
     (bit-identical to ``np.std(a-b, axis=0)`` on float32).  If an argument is a float64 numpy
     array (numpy would then compute in float64) the sums are accumulated in fp64 on the device."""
     da, back = _dev(a)
-    db = None if _is_zero_like(b) else _dev(b)[0]
+    da, order = canon(da)
+    db = None if _is_zero_like(b) else _same_layout(_dev(b)[0], order)
     n, M = da.shape[0], da.numel() // da.shape[0]
     mod = torch.empty(da.shape[1:], dtype=torch.float32, device=da.device)
     lib = _lib.load()
@@ -133,10 +171,10 @@ def modulation_func(a, b=None, eps=0.0):
                                                  _lib.stream()), "pre_moments_axis0_f64")
             _lib.check(lib.pre_std_from_moments_f32(_lib.ptr(mom[0]), _lib.ptr(mom[1]), n, M, float(eps), _lib.ptr(mod),
                                                     _lib.stream()), "pre_std_from_moments_f32")
-            return back(mod).astype(np.float64)
+            return back(uncanon(mod, order, 0)).astype(np.float64)
         _lib.check(lib.pre_std_axis0_f32(_lib.ptr(da), _lib.ptr(db), n, M, float(eps), _lib.ptr(mod), _lib.stream()),
                    "pre_std_axis0_f32")
-    return back(mod)
+    return back(uncanon(mod, order, 0))
 
 
 def ncf_metric_joint(a, b, modulation, crop=0):
@@ -144,13 +182,14 @@ def ncf_metric_joint(a, b, modulation, crop=0):
     the interior of the last three axes of UNCROPPED [n,T,X,Y] inputs (fusing the reference's
     ``[...,1:-1,1:-1,1:-1]``)."""
     da, back = _dev(a)
-    db = None if _is_zero_like(b) else _dev(b)[0]
-    dm, _ = _dev(modulation)
+    da, order = canon(da)
+    db = None if _is_zero_like(b) else _same_layout(_dev(b)[0], order)
+    dm = canon_cells(_dev(modulation)[0], order)
     n = da.shape[0]
     if crop:
         if da.dim() != 4:
             raise ValueError("crop needs [n,T,X,Y] inputs")
-        T, X, Y = da.shape[1:]
+        T, X, Y = da.shape[1:]                      # extents in memory order; the crop is the same on each axis
         ct = cx = cy = int(crop)
     else:
         T, X, Y, ct, cx, cy = 1, 1, da.numel() // n, 0, 0, 0
@@ -176,10 +215,10 @@ def _directed_f32(a, up):
 
 
 def _bounds(pred_sets, y, outside=False):
-    dy, _ = _dev(y)
+    dy = _dev(y)[0].contiguous()
     # inside test: y >= lo & y <= hi; outside test: y <= lo | y >= hi  (opposite rounding directions)
-    lo, _ = _dev(_directed_f32(pred_sets[0], up=not outside))
-    hi, _ = _dev(_directed_f32(pred_sets[1], up=outside))
+    lo = _dev(_directed_f32(pred_sets[0], up=not outside))[0].contiguous()
+    hi = _dev(_directed_f32(pred_sets[1], up=outside))[0].contiguous()
     n, M = dy.shape[0], dy.numel() // dy.shape[0]
     per_sample = []
     for t in (lo, hi):

@@ -36,19 +36,24 @@ class HipOps:
 
     @staticmethod
     def add_moments(res, mom):
+        res, _ = icp.canon(res)                 # cells in memory order; mom is indexed the same way
         n, M = res.shape[0], res.numel() // res.shape[0]
         with torch.cuda.device(res.device):
             _lib.check(_lib.load().pre_moments_axis0_f64(_lib.ptr(res), None, n, M, _lib.ptr(mom[0]), _lib.ptr(mom[1]),
                                                          _lib.stream()), "pre_moments_axis0_f64")
 
     @staticmethod
-    def std_from_moments(mom, n_total, shape, eps):
+    def std_from_moments(mom, n_total, shape, eps, like=None):
+        """``like``: the residual slab the moments came from; the modulation is returned as a
+        logical [T,X,Y] view with that slab's memory order."""
         M = mom.shape[1]
-        mod = torch.empty(shape, dtype=torch.float32, device=mom.device)
+        order = icp.canon(like)[1] if like is not None else None
+        mshape = tuple(shape) if order is None else tuple(shape[o - 1] for o in order)
+        mod = torch.empty(mshape, dtype=torch.float32, device=mom.device)
         with torch.cuda.device(mom.device):
             _lib.check(_lib.load().pre_std_from_moments_f32(_lib.ptr(mom[0]), _lib.ptr(mom[1]), n_total, M, float(eps),
                                                             _lib.ptr(mod), _lib.stream()), "pre_std_from_moments_f32")
-        return mod
+        return icp.uncanon(mod, order, 0)
 
     @staticmethod
     def zeros_scores(n, device):
@@ -57,8 +62,10 @@ class HipOps:
     @staticmethod
     def max_scores(res, mod, crop, scores):
         """scores[i] = max(scores[i], max_cells |res[i]|/mod) over the cropped interior."""
+        res, order = icp.canon(res)
+        mod = icp.canon_cells(mod, order)
         n, (T, X, Y) = res.shape[0], res.shape[1:]
-        ct, cx, cy = crop
+        ct, cx, cy = crop if order is None else tuple(crop[o - 1] for o in order)
         with torch.cuda.device(res.device):
             _lib.check(_lib.load().pre_joint_score_f32(_lib.ptr(res), None, _lib.ptr(mod), n, T, X, Y, ct, cx, cy,
                                                        _lib.ptr(scores), _lib.stream()), "pre_joint_score_f32")
@@ -97,7 +104,7 @@ class JointCalibration:
         ops.add_moments(res, mom)
         if self.group is not None:
             torch.distributed.all_reduce(mom, group=self.group)          # RCCL: sum of (sum, sumsq) per cell
-        mod = ops.std_from_moments(mom, self.n_total, tuple(res.shape[1:]), self.eps)
+        mod = ops.std_from_moments(mom, self.n_total, tuple(res.shape[1:]), self.eps, like=res)
         ops.max_scores(res, mod, crop, self.scores)
         self.modulation.append(mod)
         return mod

@@ -33,7 +33,8 @@ _CROP2 = (Ellipsis, slice(1, -1), slice(1, -1))
 
 
 def _stage(fields):
-    """Device views of the fields (+ where the result has to go back to)."""
+    """Device views of the fields (+ where the result has to go back to).  Views that do not
+    share a unit-stride axis are made contiguous so the fused kernels can stream them."""
     origin = None
     out = []
     for f in fields:
@@ -41,6 +42,8 @@ def _stage(fields):
         d, o = _dispatch.to_device(f)
         origin = origin or o
         out.append(d)
+    if len(out) > 1 and not _lib.streamable(*out):
+        out = [d.contiguous() for d in out]
     return out, origin
 
 
@@ -115,13 +118,13 @@ class NavierStokes(_Residual2D):
         if ks is not None:
             (du, dv, dp), origin = _stage((u, v, p))
             if out is None:
-                out = torch.empty(du.shape, dtype=torch.float32, device=du.device)
-            elif not (out.is_cuda and out.is_contiguous() and out.shape == du.shape and out.dtype == torch.float32):
-                raise ValueError("out must be a contiguous fp32 device tensor of the field shape")
-            fu, fv, fp = _lib.field(du), _lib.field(dv), _lib.field(dp)
+                out = _lib.empty_like_layout(du)
+            elif not (out.is_cuda and out.shape == du.shape and out.dtype == torch.float32):
+                raise ValueError("out must be an fp32 device tensor of the field shape")
+            fu, fv, fp, fo = _lib.field(du), _lib.field(dv), _lib.field(dp), _lib.field(out)
             with torch.cuda.device(du.device):
                 ok = _fused_call("pre_residual_ns_momentum_f32", lambda: _lib.load().pre_residual_ns_momentum_f32(
-                    ctypes.byref(fu), ctypes.byref(fv), ctypes.byref(fp), _lib.ptr(out), *ks,
+                    ctypes.byref(fu), ctypes.byref(fv), ctypes.byref(fp), ctypes.byref(fo), *ks,
                     float(dt), float(dx), float(dy), float(nu), *du.shape,
                     _lib.PRE_FLAG_ABS if absolute else 0, _lib.stream()))
             if ok:
@@ -167,11 +170,12 @@ class MHD(_Residual2D):
         if ks is None or vars.shape[1] < 6:
             return None
         fields, origin = _stage([vars[:, i] for i in range(6)])
-        out = torch.empty(fields[0].shape, dtype=torch.float32, device=fields[0].device)
+        out = _lib.empty_like_layout(fields[0])
         arr = (_lib.PreField * 6)(*[_lib.field(f) for f in fields])
+        fo = _lib.field(out)
         with torch.cuda.device(out.device):
             ok = _fused_call("pre_residual_mhd_f32", lambda: _lib.load().pre_residual_mhd_f32(
-                _MHD_EQ[eq], arr, _lib.ptr(out), *ks, float(self.gamma), *out.shape,
+                _MHD_EQ[eq], arr, ctypes.byref(fo), *ks, float(self.gamma), *out.shape,
                 _lib.PRE_FLAG_ABS if absolute else 0, _lib.stream()))
         return _dispatch.from_device(out, origin) if ok else None
 
@@ -297,11 +301,12 @@ class Burgers:
         ks = [_dispatch.dense9(o.kernel) for o in (self.D_t, self.D_x, self.D_xx)] if fused else [None]
         if all(k is not None for k in ks) and uu.dim() == 3:
             (du,), origin = _stage((uu,))
-            out = torch.empty(du.shape, dtype=torch.float32, device=du.device)
+            out = _lib.empty_like_layout(du)
             c3 = float(2 * dt / dx)                       # evaluated in fp32 like the reference
             with torch.cuda.device(du.device):
                 ok = _fused_call("pre_residual_burgers_f32", lambda: _lib.load().pre_residual_burgers_f32(
-                    _lib.ptr(du), _lib.iarr64(du.stride()), _lib.ptr(out), *ks, float(dx), float(dt), float(nu), c3,
+                    _lib.ptr(du), _lib.iarr64(du.stride()), _lib.ptr(out), _lib.iarr64(out.stride()), *ks,
+                    float(dx), float(dt), float(nu), c3,
                     *du.shape, _lib.PRE_FLAG_ABS if absolute else 0, _lib.stream()))
             if ok:
                 res = _dispatch.from_device(out, origin)

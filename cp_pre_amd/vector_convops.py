@@ -41,10 +41,12 @@ def linear2(f0, k0, f1, k1, ratio=1.0, flags=0):
     _dispatch._check_field(f1)
     a, origin = _dispatch.to_device(f0)
     b, _ = _dispatch.to_device(f1)
-    out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
-    fa, fb = _lib.field(a), _lib.field(b)
+    if not _lib.streamable(a, b):
+        a, b = a.contiguous(), b.contiguous()
+    out = _lib.empty_like_layout(a)
+    fa, fb, fo = _lib.field(a), _lib.field(b), _lib.field(out)
     with torch.cuda.device(a.device):
-        rc = _lib.load().pre_residual_linear2_f32(ctypes.byref(fa), ctypes.byref(fb), _lib.ptr(out), d0, d1,
+        rc = _lib.load().pre_residual_linear2_f32(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(fo), d0, d1,
                                                   float(ratio), *a.shape, flags, _lib.stream())
     if rc == _lib.PRE_E_UNSUPPORTED:
         return None

@@ -37,22 +37,33 @@ typedef struct {
     int64_t sB, sT, sX, sY;
 } pre_field_t;
 
-int pre_abi_version(void);
+/* A strided OUTPUT view [B,T,X,Y].  The library writes exactly the B*T*X*Y addressed elements.
+ * The streaming kernels need the input views and the output view to share one unit-stride axis
+ * (any of T, X, Y - the axes are relabelled internally, so the surrogate's native
+ * [BS,F,Nx,Ny,Nt] layout seen through permute(0,1,4,2,3) is consumed without a copy);
+ * otherwise the entry returns PRE_E_UNSUPPORTED (fused residuals) or runs the generic kernel
+ * (pre_stencil*). */
+typedef struct {
+    float *ptr;
+    int64_t sB, sT, sX, sY;
+} pre_out_t;
+
+int pre_abi_version(void);     /* 2 */
 
 /* ---- a4/a5/a6: ConvOperator.convolution ---------------------------------------------
  * Utils/ConvOps_2d.py:135-150  F.conv3d(field[:,None], K[None,None], padding=k//2)
  * Utils/ConvOps_1d.py:130-150  F.conv2d(...)
  * Zero-padded single-channel cross-correlation given as a tap list (host arrays):
  *   out[b,t,x,y] = sum_i w[i] * in[b, t+off[3i], x+off[3i+1], y+off[3i+2]]   (0 outside)
- * `out` is contiguous [B,T,X,Y]; `in` may be any strided view.  |off| <= 3, ntaps <= 343.
+ * `in` and `out` may be any strided views.  |off| <= 3, ntaps <= 343.
  * Star-shaped 3x3x3 tap sets on a y-contiguous 16-byte aligned view take the streaming
  * kernel; everything else takes the generic kernel.  Same result either way. */
-int pre_stencil3d_f32(const pre_field_t *in, float *out,
+int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out,
                       const float *tap_w /*host*/, const int32_t *tap_off /*host, 3*ntaps*/, int ntaps,
                       int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream);
 
-/* [B,T,X] fields with a 2-D kernel; tap_off is 2*ntaps (dt,dx); in_strides = {sB,sT,sX}. */
-int pre_stencil2d_f32(const float *in, const int64_t in_strides[3], float *out,
+/* [B,T,X] fields with a 2-D kernel; tap_off is 2*ntaps (dt,dx); strides = {sB,sT,sX}. */
+int pre_stencil2d_f32(const float *in, const int64_t in_strides[3], float *out, const int64_t out_strides[3],
                       const float *tap_w /*host*/, const int32_t *tap_off /*host*/, int ntaps,
                       int64_t B, int64_t T, int64_t X, int flags, void *stream);
 
@@ -61,27 +72,27 @@ int pre_stencil2d_f32(const float *in, const int64_t in_strides[3], float *out,
  * (27 floats each, host, axes (Nt,Nx,Ny)), so every construction quirk of the reference
  * (D_y == D_t, Utils/ConvOps_2d.py:72-73) is inherited.  Returns PRE_E_UNSUPPORTED if a
  * kernel has a tap off the 7-point star; the caller then composes pre_stencil3d_f32 calls.
- * `out` is contiguous [B,T,X,Y] (uncropped; the caller crops [...,1:-1,1:-1,1:-1]). */
+ * `out` is the UNCROPPED residual view (the caller crops [...,1:-1,1:-1,1:-1]). */
 
 /* Marginal/NS_Residuals_CP.py:231-240; Other_UQ/Evaluation/PRE_estimations.py:40-50 */
-int pre_residual_ns_momentum_f32(const pre_field_t *u, const pre_field_t *v, const pre_field_t *p, float *out,
+int pre_residual_ns_momentum_f32(const pre_field_t *u, const pre_field_t *v, const pre_field_t *p, const pre_out_t *out,
                                  const float *K_t, const float *K_x, const float *K_y, const float *K_xx_yy,
                                  float dt, float dx, float dy, float nu,
                                  int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream);
 /* Marginal/NS_Residuals_CP.py:222-228   res = D_x(u) + ratio*D_y(v)   (also Divergence/Curl/gauss:
  * out = Ka(f0) + ratio*Kb(f1), Utils/VectorConvOps.py:38,65; Marginal/MHD_Residuals_CP.py:272-278) */
-int pre_residual_linear2_f32(const pre_field_t *f0, const pre_field_t *f1, float *out,
+int pre_residual_linear2_f32(const pre_field_t *f0, const pre_field_t *f1, const pre_out_t *out,
                              const float *K_a, const float *K_b, float ratio,
                              int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream);
 /* Joint/Burgers_Residuals_CP.py:171-187   [B,T,X]; 3x3 kernels (9 floats, host), axes (Nt,Nx);
  * res = dx*D_t(u) + dt*u*D_x(u) - nu*D_xx(u)*c3   with c3 = 2*dt/dx evaluated by the caller in fp32 */
-int pre_residual_burgers_f32(const float *u, const int64_t in_strides[3], float *out,
+int pre_residual_burgers_f32(const float *u, const int64_t in_strides[3], float *out, const int64_t out_strides[3],
                              const float *K_t, const float *K_x, const float *K_xx,
                              float dx, float dt, float nu, float c3,
                              int64_t B, int64_t T, int64_t X, int flags, void *stream);
 /* Marginal/MHD_Residuals_CP.py:225-278; eq: 0 continuity, 1 momentum, 2 energy, 3 induction.
  * fields = {rho,u,v,p,Bx,By} (all six views must be valid even if the equation skips some). */
-int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], float *out,
+int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], const pre_out_t *out,
                          const float *K_t, const float *K_x, const float *K_y, double gamma,
                          int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream);
 

@@ -32,7 +32,7 @@ class CpuOps:
         mom[1] += (r * r).sum(0)
 
     @staticmethod
-    def std_from_moments(mom, n_total, shape, eps):
+    def std_from_moments(mom, n_total, shape, eps, like=None):
         mean = mom[0] / n_total
         var = (mom[1] / n_total - mean * mean).clamp_min(0)
         return (var.sqrt().float() + eps).reshape(shape)

@@ -559,3 +559,64 @@ def test_reference_script_shaped_usage_through_compat_shims(gpu):
 def test_graft_smoke(gpu):
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_zero_copy_surrogate_layout_end_to_end(gpu):
+    """[BS,F,Nx,Ny,Nt] surrogate output through permute(0,1,4,2,3) (Marginal/NS_Residuals_CP.py:282):
+    the library relabels its axes, the residual keeps the Nt-fastest memory layout (no copy), and
+    scores / modulation / q-hat computed on that layout equal the oracle on the logical tensors.
+    Also the X-fastest layout and the 1-D [BS,F,Nx,Nt] case."""
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    from cp_pre_amd.residuals import MHD, Burgers, NavierStokes, PRE_Wave
+    from cp_pre_amd.convops_2d import ConvOperator
+    from oracle import conformal as oc
+    from oracle import residuals as orr
+    g = torch.Generator().manual_seed(31)
+    sur = torch.rand(48, 6, 20, 24, 16, generator=g) + 0.5                 # [BS,F,Nx,Ny,Nt]
+    view = sur.permute(0, 1, 4, 2, 3)                                      # [BS,F,Nt,Nx,Ny], Nt fastest
+    dview = sur.to(gpu).permute(0, 1, 4, 2, 3)
+    dt, dx, dy = 0.01, 1 / 20, 1 / 24
+    res = NavierStokes(dt, dx, dy).residual_momentum(dview[:, :3], boundary=True)
+    assert res.stride(1) == 1 and not res.is_contiguous()                 # stayed in the surrogate's layout
+    ref = orr.ns_momentum(view[:, :3], dt, dx, dy, boundary=True)
+    assert rel_err(res.cpu().numpy(), ref.numpy()) <= RES_TOL
+    for name, got, want in [
+        ("mhd_induction", MHD().residual_induction(dview, True), orr.mhd_induction(view, boundary=True)),
+        ("mhd_energy", MHD().residual_energy(dview, True), orr.mhd_energy(view, boundary=True)),
+        ("wave", PRE_Wave(0.01, 0.02).residual(dview[:, 0], True), orr.wave_residual(view[:, 0], 1.0, 0.01, 0.02, boundary=True)),
+        ("laplace", ConvOperator(("x", "y"), 2)(dview[:, 1]), __import__("oracle.convops", fromlist=["x"]).ConvOperator2D(("x", "y"), 2)(view[:, 1])),
+    ]:
+        assert got.stride(1) == 1, name
+        assert rel_err(got.cpu().numpy(), want.numpy()) <= RES_TOL, name
+    # calibration directly on the permuted residual
+    rn = ref.numpy()
+    alphas = [0.1, 0.5, 0.9]
+    q = icp.calibrate_multi(res.abs(), res.shape[0], alphas)
+    assert q.shape == (3,) + tuple(res.shape[1:])
+    assert rel_err(q.cpu().numpy(), np.stack([oc.calibrate(np.abs(rn), len(rn), a) for a in alphas])) <= RES_TOL
+    exact = torch.from_numpy(rn).to(gpu).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)     # same values, permuted layout
+    assert not exact.is_contiguous()
+    assert np.array_equal(icp.calibrate(exact.abs(), len(rn), 0.1).cpu().numpy(), oc.calibrate(np.abs(rn), len(rn), 0.1))
+    assert np.array_equal(icp.modulation_func(exact, None).cpu().numpy(), oc.modulation_func(rn, np.zeros_like(rn)))
+    mod = icp.modulation_func(exact, None)
+    inner = rn[:, 1:-1, 1:-1, 1:-1]
+    want = oc.ncf_metric_joint(inner, np.zeros_like(inner), oc.modulation_func(inner, np.zeros_like(inner)))
+    assert np.array_equal(icp.ncf_metric_joint(exact, None, mod, crop=1).cpu().numpy(), want)
+    jc = pipeline.JointCalibration(len(rn), gpu)
+    jc.add_slab(exact)
+    qj = jc.finish(alphas).cpu().numpy()
+    for j, a in enumerate(alphas):
+        assert abs(qj[j] - oc.calibrate(want, len(want), a)) <= 1e-6 * abs(qj[j])
+    # X-fastest layout [BS,Nt,Ny,Nx] viewed as [BS,Nt,Nx,Ny]
+    xf = torch.rand(6, 8, 16, 32, generator=g)
+    v2 = xf.permute(0, 1, 3, 2)
+    got = ConvOperator("x", 2)(xf.to(gpu).permute(0, 1, 3, 2))
+    assert got.stride(2) == 1
+    assert rel_err(got.cpu().numpy(), __import__("oracle.convops", fromlist=["x"]).ConvOperator2D("x", 2)(v2).numpy()) <= RES_TOL
+    # 1-D surrogate [BS,F,Nx,Nt] -> permute(0,1,3,2)[:,0] (Joint/Burgers_Residuals_CP.py:217)
+    s1 = torch.rand(64, 1, 128, 40, generator=g) + 0.5
+    u1 = s1.permute(0, 1, 3, 2)[:, 0]
+    got = Burgers(2 / 128, 1.25 / 40, 0.002).residual(s1.to(gpu).permute(0, 1, 3, 2)[:, 0], boundary=True)
+    assert got.stride(1) == 1
+    assert rel_err(got.cpu().numpy(), orr.burgers_residual(u1, 2 / 128, 1.25 / 40, 0.002, boundary=True).numpy()) <= RES_TOL

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pre_abi_version() == 1
+    assert lib.pre_abi_version() == 2
 
 
 def test_kernel_construction_matches_reference_bit_for_bit(golden):

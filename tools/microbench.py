@@ -87,3 +87,39 @@ if __name__ == "__main__":
     if "eval" in what: bench_eval()
     if "calib" in what: bench_calib()
     if "select" in what: bench_select()
+
+
+def bench_copy():
+    """Ceilings on this box: float4 device copy (torch) and the cost of re-laying out a permuted view."""
+    n = 1 << 30
+    a = torch.empty(n, device=dev).uniform_()
+    b = torch.empty_like(a)
+    report("torch copy_ 4 GiB (8 B/elem)", timeit(lambda: b.copy_(a)), 8 * n)
+    report("torch a*2 -> b (8 B/elem)", timeit(lambda: torch.mul(a, 2.0, out=b)), 8 * n)
+    del a, b
+    sur = torch.empty(256, 3, 256, 256, 32, device=dev).uniform_()          # [BS,F,Nx,Ny,Nt]
+    view = sur.permute(0, 1, 4, 2, 3)
+    report("torch .contiguous() of permuted [256,3,32,256,256] view (8 B/elem)", timeit(lambda: view.contiguous()), 8 * sur.numel())
+    one = view[:, 0]
+    report("torch .contiguous() of one permuted field (8 B/elem)", timeit(lambda: one.contiguous()), 8 * one.numel())
+
+
+def bench_permuted():
+    """Residuals on the surrogate's native layout [BS,F,Nx,Ny,Nt] (zero-copy axis relabelling)."""
+    for (B, T, X, Y) in [(256, 64, 256, 256), (64, 64, 512, 512)]:
+        cells = B * T * X * Y
+        sur = torch.empty(B, 6, X, Y, T, device=dev).uniform_(0.5, 1.5)
+        v = sur.permute(0, 1, 4, 2, 3)
+        ns = R.NavierStokes(0.01, 1 / X, 1 / Y)
+        report(f"ns_momentum Nt-fastest [{B},{T},{X},{Y}] 16B/cell", timeit(lambda: ns.residual_momentum(v[:, :3], True)), 16 * cells)
+        w = R.PRE_Wave(0.01, 0.02)
+        report("wave additive kernel Nt-fastest 8B/cell", timeit(lambda: w.residual(v[:, 0], True)), 8 * cells)
+        mhd = R.MHD()
+        report("mhd_induction Nt-fastest 20B/cell", timeit(lambda: mhd.residual_induction(v, True)), 20 * cells)
+        del sur, v
+
+
+if __name__ == "__main__" and "copy" in sys.argv[1:]:
+    bench_copy()
+if __name__ == "__main__" and "permuted" in sys.argv[1:]:
+    bench_permuted()
