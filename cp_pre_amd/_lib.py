@@ -17,6 +17,7 @@ SO_PATH = os.path.join(_HERE, "libcp_pre_hip.so")
 
 PRE_OK, PRE_E_NULL, PRE_E_SHAPE, PRE_E_UNSUPPORTED, PRE_E_RANGE = 0, -1, -2, -3, -4
 PRE_FLAG_ABS = 1
+PRE_FLAG_INTERIOR_T = 2
 _ERR = {PRE_E_NULL: "null pointer / bad size", PRE_E_SHAPE: "unsupported shape",
         PRE_E_UNSUPPORTED: "operator kernels not star-shaped or layout not streamable",
         PRE_E_RANGE: "rank / crop out of range"}
@@ -39,7 +40,7 @@ SIGNATURES = {
     "pre_residual_mhd_f32": [c_int, POINTER(PreField), _fld] + [POINTER(c_float)] * 3 + [c_double] + [c_int64] * 4 + [c_int, c_void_p],
     "pre_absdiff_f32": [_fp, _fp, _fp, c_int64, c_void_p],
     "pre_std_axis0_f32": [_fp, _fp, c_int64, c_int64, c_float, _fp, c_void_p],
-    "pre_moments_axis0_f64": [_fp, _fp, c_int64, c_int64, _fp, _fp, c_void_p],
+    "pre_moments_axis0_f64": [_fp, _fp, c_int64, c_int64, c_int64, _fp, _fp, c_void_p],
     "pre_std_from_moments_f32": [_fp, _fp, c_int64, c_int64, c_float, _fp, c_void_p],
     "pre_joint_score_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, _fp, c_void_p],
     "pre_kth_f32": [_fp, c_int64, POINTER(c_int64), c_int, _fp, c_void_p],

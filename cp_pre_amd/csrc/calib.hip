@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) std_axis0_kernel(const float *__restrict_
 
 // ------------------------------------------------------------------ streaming moments (fp64)
 __global__ void __launch_bounds__(256) moments_kernel(const float *__restrict__ a, const float *__restrict__ b,
-                                                      int n, long long M, int rows_per_split,
+                                                      int n, long long M, long long ld, int rows_per_split,
                                                       double *__restrict__ sum, double *__restrict__ sumsq)
 {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,8 +77,8 @@ __global__ void __launch_bounds__(256) moments_kernel(const float *__restrict__ 
     double s = 0.0, q = 0.0;
 #pragma unroll 8
     for (int i = i0; i < i1; ++i) {
-        float v = a[(long long)i * M + c];
-        if (b) v = v - b[(long long)i * M + c];
+        float v = a[(long long)i * ld + c];
+        if (b) v = v - b[(long long)i * ld + c];
         const double d = (double)v;
         s += d;
         q += d * d;
@@ -478,9 +478,10 @@ int pre_std_axis0_f32(const float *a, const float *b, int64_t n, int64_t M, floa
     return PRE_OK;
 }
 
-int pre_moments_axis0_f64(const float *a, const float *b, int64_t n, int64_t M, double *sum, double *sumsq, void *stream)
+int pre_moments_axis0_f64(const float *a, const float *b, int64_t n, int64_t M, int64_t row_stride, double *sum,
+                          double *sumsq, void *stream)
 {
-    if (!a || !sum || !sumsq || n <= 0 || M <= 0) return PRE_E_NULL;
+    if (!a || !sum || !sumsq || n <= 0 || M <= 0 || row_stride < M) return PRE_E_NULL;
     if (n > 0x7fffffff) return PRE_E_SHAPE;
     const long long bx = (M + 255) / 256;
     // enough workgroups to fill 256 CUs even when M is small: split the batch axis
@@ -489,7 +490,7 @@ int pre_moments_axis0_f64(const float *a, const float *b, int64_t n, int64_t M, 
     const int rows = (int)((n + splits - 1) / splits);
     splits = (n + rows - 1) / rows;
     hipLaunchKernelGGL(moments_kernel, dim3((unsigned)bx, (unsigned)splits), dim3(256), 0, as_stream(stream), a, b, (int)n,
-                       (long long)M, rows, sum, sumsq);
+                       (long long)M, (long long)row_stride, rows, sum, sumsq);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }

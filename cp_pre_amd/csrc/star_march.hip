@@ -240,8 +240,12 @@ __global__ void __launch_bounds__(NR *TYQ) march_kernel(const Geom g, const type
 
     const int x = xt * NR + ty, y = (yt * TYQ + q) * 4;
     const bool inb = (x < g.X) && (y < g.Y);
-    const int t0 = ts * g.tSeg;
-    const int t1 = min(t0 + g.tSeg, g.T);
+    int t0 = ts * g.tSeg;
+    int t1 = min(t0 + g.tSeg, g.T);
+    if (g.flags & PRE_FLAG_INTERIOR_T) {       // the caller crops the t rim: neither compute nor store it
+        t0 = max(t0, 1);
+        t1 = min(t1, g.T - 1);
+    }
 
     // halo-row duty: thread-row 0 fetches the row above the tile, thread-row NR-1 the row below
     const bool top = (ty == 0), bot = (ty == NR - 1);
@@ -444,7 +448,8 @@ int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const
     }
     for (int i = nf; i < MAXF; ++i) { g.f[i] = nullptr; g.sB[i] = g.sT[i] = g.sX[i] = 0; }
     g.out = out->ptr; g.oB = out->sB; g.oT = ostride(p[0]); g.oX = ostride(p[1]);
-    g.B = (int)B; g.T = (int)D[p[0]]; g.X = (int)D[p[1]]; g.Y = (int)D[p[2]]; g.flags = flags;
+    g.B = (int)B; g.T = (int)D[p[0]]; g.X = (int)D[p[1]]; g.Y = (int)D[p[2]];
+    g.flags = relabeled ? (flags & ~PRE_FLAG_INTERIOR_T) : flags;     // the skipped rim is on the LOGICAL t axis
     if (relabeled)
         for (int k = 0; k < nstars; ++k) {
             const Star o = *stars[k];

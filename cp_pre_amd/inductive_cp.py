@@ -167,7 +167,7 @@ def modulation_func(a, b=None, eps=0.0):
     with torch.cuda.device(da.device):
         if _wide(a, b):
             mom = torch.zeros(2, M, dtype=torch.float64, device=da.device)
-            _lib.check(lib.pre_moments_axis0_f64(_lib.ptr(da), _lib.ptr(db), n, M, _lib.ptr(mom[0]), _lib.ptr(mom[1]),
+            _lib.check(lib.pre_moments_axis0_f64(_lib.ptr(da), _lib.ptr(db), n, M, M, _lib.ptr(mom[0]), _lib.ptr(mom[1]),
                                                  _lib.stream()), "pre_moments_axis0_f64")
             _lib.check(lib.pre_std_from_moments_f32(_lib.ptr(mom[0]), _lib.ptr(mom[1]), n, M, float(eps), _lib.ptr(mod),
                                                     _lib.stream()), "pre_std_from_moments_f32")

@@ -30,29 +30,43 @@ from . import inductive_cp as icp
 class HipOps:
     """Device back end: every method is one or two ``libcp_pre_hip.so`` launches."""
 
+    interior_t = True      # can reduce only the interior t planes of an uncropped [n,T,X,Y] slab in place
+
     @staticmethod
     def zeros_moments(M, device):
         return torch.zeros(2, M, dtype=torch.float64, device=device)
 
     @staticmethod
-    def add_moments(res, mom):
+    def add_moments(res, mom, skip_t=0):
+        """``skip_t`` > 0 (contiguous [n,T,X,Y] only): reduce planes skip_t .. T-skip_t-1, which are one
+        contiguous run of cells per sample (row stride T*X*Y); ``mom`` then has (T-2*skip_t)*X*Y cells."""
         res, _ = icp.canon(res)                 # cells in memory order; mom is indexed the same way
         n, M = res.shape[0], res.numel() // res.shape[0]
+        a, cells = res, M
+        if skip_t:
+            plane = M // res.shape[1]
+            a, cells = res[:, skip_t:], M - 2 * skip_t * plane
         with torch.cuda.device(res.device):
-            _lib.check(_lib.load().pre_moments_axis0_f64(_lib.ptr(res), None, n, M, _lib.ptr(mom[0]), _lib.ptr(mom[1]),
+            _lib.check(_lib.load().pre_moments_axis0_f64(_lib.ptr(a), None, n, cells, M, _lib.ptr(mom[0]), _lib.ptr(mom[1]),
                                                          _lib.stream()), "pre_moments_axis0_f64")
 
     @staticmethod
-    def std_from_moments(mom, n_total, shape, eps, like=None):
+    def std_from_moments(mom, n_total, shape, eps, like=None, skip_t=0):
         """``like``: the residual slab the moments came from; the modulation is returned as a
-        logical [T,X,Y] view with that slab's memory order."""
+        logical [T,X,Y] view with that slab's memory order.  With ``skip_t`` the moments cover the
+        interior planes only; the rim planes of the result are NaN (they are cropped anyway)."""
         M = mom.shape[1]
         order = icp.canon(like)[1] if like is not None else None
         mshape = tuple(shape) if order is None else tuple(shape[o - 1] for o in order)
         mod = torch.empty(mshape, dtype=torch.float32, device=mom.device)
+        target = mod
+        if skip_t:
+            mod[:skip_t] = float("nan")
+            mod[mshape[0] - skip_t:] = float("nan")
+            target = mod[skip_t:mshape[0] - skip_t]
         with torch.cuda.device(mom.device):
             _lib.check(_lib.load().pre_std_from_moments_f32(_lib.ptr(mom[0]), _lib.ptr(mom[1]), n_total, M, float(eps),
-                                                            _lib.ptr(mod), _lib.stream()), "pre_std_from_moments_f32")
+                                                            _lib.ptr(target), _lib.stream()), "pre_std_from_moments_f32")
         return icp.uncanon(mod, order, 0)
 
     @staticmethod
@@ -98,13 +112,19 @@ class JointCalibration:
         self.modulation = []           # one [T_slab, X, Y] array per slab, in call order
 
     def add_slab(self, res, crop=(1, 1, 1)):
+        """``res``: UNCROPPED residual slab [n_local, T_slab, X, Y]; ``crop`` cells per side are excluded
+        from the score (the reference's ``[...,1:-1,1:-1,1:-1]``).  The t-rim planes may hold garbage
+        (``PRE_FLAG_INTERIOR_T``): they are neither reduced nor scored."""
         ops = self.ops
         M = res[0].numel() if hasattr(res[0], "numel") else res[0].size
-        mom = ops.zeros_moments(M, self.device)
-        ops.add_moments(res, mom)
+        skip = crop[0] if (getattr(ops, "interior_t", False) and crop[0] > 0 and res.is_contiguous()
+                           and res.shape[1] > 2 * crop[0]) else 0
+        kw = {"skip_t": skip} if skip else {}
+        mom = ops.zeros_moments(M - 2 * skip * (M // res.shape[1]), self.device)
+        ops.add_moments(res, mom, **kw)
         if self.group is not None:
             torch.distributed.all_reduce(mom, group=self.group)          # RCCL: sum of (sum, sumsq) per cell
-        mod = ops.std_from_moments(mom, self.n_total, tuple(res.shape[1:]), self.eps, like=res)
+        mod = ops.std_from_moments(mom, self.n_total, tuple(res.shape[1:]), self.eps, like=res, **kw)
         ops.max_scores(res, mod, crop, self.scores)
         self.modulation.append(mod)
         return mod

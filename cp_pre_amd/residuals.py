@@ -109,9 +109,11 @@ class NavierStokes(_Residual2D):
             res = _on_device((u, v), lambda u, v: self.D_x(u) + ratio * self.D_y(v))
         return _finish(res, boundary, _CROP3, absolute, done_abs)
 
-    def residual_momentum(self, vars, boundary=False, absolute=False, out=None):
-        """``out``: optional preallocated contiguous device tensor [BS,Nt,Nx,Ny] for the
-        uncropped residual (fused route only; lets a streaming driver reuse one buffer)."""
+    def residual_momentum(self, vars, boundary=False, absolute=False, out=None, skip_t_rim=False):
+        """``out``: optional preallocated device tensor [BS,Nt,Nx,Ny] for the uncropped residual
+        (fused route only; lets a streaming driver reuse one buffer).  ``skip_t_rim``: the caller
+        crops the first and last time plane anyway, so they need not be computed or stored
+        (``PRE_FLAG_INTERIOR_T``; their content is then unspecified)."""
         u, v, p = vars[:, 0], vars[:, 1], vars[:, 2]
         dt, dx, dy, nu = self.dt, self.dx, self.dy, self.nu
         ks = self._k27(self.D_t, self.D_x, self.D_y, self.D_xx_yy) if self._want_fused(vars) else None
@@ -126,7 +128,8 @@ class NavierStokes(_Residual2D):
                 ok = _fused_call("pre_residual_ns_momentum_f32", lambda: _lib.load().pre_residual_ns_momentum_f32(
                     ctypes.byref(fu), ctypes.byref(fv), ctypes.byref(fp), ctypes.byref(fo), *ks,
                     float(dt), float(dx), float(dy), float(nu), *du.shape,
-                    _lib.PRE_FLAG_ABS if absolute else 0, _lib.stream()))
+                    (_lib.PRE_FLAG_ABS if absolute else 0) | (_lib.PRE_FLAG_INTERIOR_T if skip_t_rim else 0),
+                    _lib.stream()))
             if ok:
                 return _finish(_dispatch.from_device(out, origin), boundary, _CROP3, absolute, True)
         D_t, D_x, D_y, D_xx_yy = self.D_t, self.D_x, self.D_y, self.D_xx_yy

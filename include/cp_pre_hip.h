@@ -29,6 +29,9 @@ extern "C" {
 #define PRE_E_RANGE       -4   /* k / crop out of range                                     */
 
 #define PRE_FLAG_ABS       1   /* store |residual| (marginal score, Marginal/Wave_Residuals_CP.py:280) */
+#define PRE_FLAG_INTERIOR_T 2  /* fused residuals / star stencils: planes t=0 and t=T-1 of `out` MAY be left
+                                  unwritten - for callers that crop the t rim anyway
+                                  (res[...,1:-1,1:-1,1:-1], Marginal/NS_Residuals_CP.py:240) */
 
 /* A strided view of one field [B,T,X,Y] (what `vars[:, i]` or a permuted surrogate
  * output is, Marginal/NS_Residuals_CP.py:282; Other_UQ/Evaluation/PRE_estimations.py:41). */
@@ -107,9 +110,11 @@ int pre_absdiff_f32(const float *a, const float *b, float *out, int64_t n, void 
  *   the exact operation order numpy uses for an axis-0 reduction, + eps (Joint/MHD_Residuals_CP.py:350).
  * pre_moments_axis0_f64: streaming / sharded form; ACCUMULATES sum and sum of squares of
  *   (a-b) over the n rows into sum[M], sumsq[M] (fp64, caller zeroes them before the first
- *   chunk, all-reduces them across ranks), then pre_std_from_moments_f32 finishes. */
+ *   chunk, all-reduces them across ranks), then pre_std_from_moments_f32 finishes.  Rows are
+ *   row_stride elements apart (>= M; M for a dense [n,M] tensor), so a contiguous sub-range of
+ *   cells - e.g. the interior t planes of an uncropped residual - can be reduced in place. */
 int pre_std_axis0_f32(const float *a, const float *b, int64_t n, int64_t M, float eps, float *mod, void *stream);
-int pre_moments_axis0_f64(const float *a, const float *b, int64_t n, int64_t M,
+int pre_moments_axis0_f64(const float *a, const float *b, int64_t n, int64_t M, int64_t row_stride,
                           double *sum, double *sumsq, void *stream);
 int pre_std_from_moments_f32(const double *sum, const double *sumsq, int64_t n_total, int64_t M,
                              float eps, float *mod, void *stream);

@@ -620,3 +620,30 @@ def test_zero_copy_surrogate_layout_end_to_end(gpu):
     got = Burgers(2 / 128, 1.25 / 40, 0.002).residual(s1.to(gpu).permute(0, 1, 3, 2)[:, 0], boundary=True)
     assert got.stride(1) == 1
     assert rel_err(got.cpu().numpy(), orr.burgers_residual(u1, 2 / 128, 1.25 / 40, 0.002, boundary=True).numpy()) <= RES_TOL
+
+
+def test_interior_t_fast_path_equals_full_path(gpu):
+    """PRE_FLAG_INTERIOR_T (rim planes neither computed nor stored) + moments over the interior planes
+    only: same q-hat, same interior residual, same modulation as the full-slab route."""
+    from cp_pre_amd import pipeline
+    from cp_pre_amd.residuals import NavierStokes
+    g = torch.Generator().manual_seed(17)
+    v = (torch.rand(30, 3, 10, 16, 64, generator=g) + 0.5).to(gpu)
+    ns = NavierStokes(0.01, 1 / 16, 1 / 64)
+    full = ns.residual_momentum(v, boundary=True)
+    out = torch.full_like(full, float("nan"))
+    fast = ns.residual_momentum(v, boundary=True, out=out, skip_t_rim=True)
+    assert torch.equal(fast[:, 1:-1], full[:, 1:-1])
+    assert torch.isnan(fast[:, 0]).all() and torch.isnan(fast[:, -1]).all()          # rim untouched
+    alphas = [0.1, 0.5, 0.9]
+    a = pipeline.JointCalibration(30, gpu)
+    a.add_slab(fast, crop=(1, 1, 1))                                                # interior-only moments
+    qa = a.finish(alphas)
+
+    class FullOps(pipeline.HipOps):
+        interior_t = False
+    b = pipeline.JointCalibration(30, gpu, ops=FullOps)
+    b.add_slab(full, crop=(1, 1, 1))
+    qb = b.finish(alphas)
+    assert torch.equal(qa, qb)
+    assert torch.equal(a.modulation[0][1:-1], b.modulation[0][1:-1]) and torch.isnan(a.modulation[0][0]).all()

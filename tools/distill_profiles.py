@@ -51,8 +51,9 @@ if pm:
             gb = avg * 1024 / 1e9 * (2 if name == 'fetch' else 1)
             o.write(f"{name.upper()+'_SIZE':11s} {k:36s} dispatches={n:3d} avg_KiB={avg:.6g} corrected_GB_per_dispatch={gb:.3f}\n")
         f = pm[('fetch', mk)][1] * 1024 * 2; w = pm[('write', mk)][1] * 1024
-        o.write(f"\n{mk} per launch [4096,10,512,512]: algorithmic read {12*cells/1e9:.3f} GB + write {4*cells/1e9:.3f} GB = {16*cells/1e9:.3f} GB\n")
-        o.write(f"   measured HBM traffic  read {f/1e9:.3f} GB + write {w/1e9:.3f} GB = {(f+w)/1e9:.3f} GB  ({(f+w)/(16*cells):.4f} x algorithmic)\n")
+        alg_r, alg_w = 12 * cells, 4 * cells * 8 // 10      # 10 planes read, 8 interior planes written
+        o.write(f"\n{mk} per launch [4096,10,512,512]: algorithmic read {alg_r/1e9:.3f} GB + write {alg_w/1e9:.3f} GB = {(alg_r+alg_w)/1e9:.3f} GB\n")
+        o.write(f"   measured HBM traffic  read {f/1e9:.3f} GB + write {w/1e9:.3f} GB = {(f+w)/1e9:.3f} GB  ({(f+w)/(alg_r+alg_w):.4f} x algorithmic)\n")
     json.dump({"workload": {"batch": 4096, "slab": 8, "nx": 512, "ny": 512}, "kernel": mk,
                "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "traffic_bytes_per_launch": f + w,
                "source": f"{out}/pmc_hbm_c3.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 gfx950 correction)"},
