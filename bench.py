@@ -40,7 +40,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-NS_BYTES_PER_CELL = 16         # 3 fields read + 1 residual written, fp32  [informative; see launch_bytes]
 
 
 # BASELINE.json configs: per-rank shapes (C4/C5 are quoted sharded over 8 GPUs), the fused kernel

@@ -146,11 +146,10 @@ def _xcorr_impl(field, kernel, nd, flags=0):
     if karr.ndim != nd:
         raise RuntimeError(f"expected a {nd}-D kernel, got shape {tuple(karr.shape)}")
     w, off = taps_of(karr)
-    squeeze = False
-    if nd == 2 and field.dim() == 4:
+    if nd == 2 and field.dim() == 4:            # [BS,1,Nt,Nx]: the reference squeezes the channel after conv2d
         if field.shape[1] != 1:
             raise RuntimeError("expected a single-channel [BS,1,Nt,Nx] field")
-        field, squeeze = field[:, 0], False
+        field = field[:, 0]
     if field.dim() != nd + 1:
         raise RuntimeError(f"expected a {nd + 1}-D field [BS,Nt,Nx{',Ny' if nd == 3 else ''}], got {tuple(field.shape)}")
     lib = _lib.load()
