@@ -228,18 +228,22 @@ __global__ void __launch_bounds__(1024) kth_kernel(const float *__restrict__ s, 
 }
 
 // ------------------------------------------------------------------ per-cell k-th over axis 0
-// MSD radix select over [n, M] for ALL requested ranks at once, one launch per digit:
-// 9 + 6 + 6 + 6 + 5 bits = 5 passes (20 B per element).  A 1024-thread workgroup owns 64
-// adjacent cells (256 B of every sample row): lane = cell, one wave = one row, so the 64 LDS
-// atomics of a wave-instruction never hit the same counter.  Counters are 16 bit (n < 65536),
-// two cells per word; histogram row r (= slot*bins + bin) is 32 words, rotated by r so that
-// both the cell-parallel updates and the later bin-parallel scan spread over the banks.
-// Per cell there is one histogram per *distinct* prefix among its ranks ("slot"; ranks are
-// ascending, so equal prefixes are adjacent and the first rank of a run leads it); pass 1 has
-// one slot and spends the LDS on 512 bins.  <= 80 KiB of LDS: two workgroups per CU, so one
-// streams while the other zeroes / scans.  Per-(rank, cell) prefix and residual rank live in
-// a caller workspace between launches.
-constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16;
+// MSD radix select over [n, M] for ALL requested ranks at once: 9 + 6 + 6 + 6 + 5 bits = 5 sweeps
+// of the tile's data, ONE launch.  A 1024-thread workgroup owns 64 adjacent cells (256 B of every
+// sample row - narrower column tiles lose DRAM efficiency fast: 128 B -> 0.7x, 64 B -> 0.3x,
+// tools/exp/colread.hip): lane = cell, one wave = one row, so the 64 LDS atomics of a
+// wave-instruction never hit the same counter.  Counters are 16 bit (n < 65536), two cells per
+// word; histogram row r (= slot*bins + bin) is 32 words, rotated by r so that both the
+// cell-parallel updates and the bin-parallel scan spread over the banks.  Per cell there is one
+// histogram per *distinct* prefix among its ranks ("slot"; ranks ascend, so equal prefixes are
+// adjacent); the first sweep has one slot and spends the LDS on 512 bins.  80 KiB of LDS: two
+// workgroups per CU, one sweeps while the other zeroes / narrows.
+// State: wave w narrows cells w, w+16, w+32, w+48 in every pass, so their (prefix, residual rank)
+// stay in its registers (lane j <-> rank j); the new prefixes reach the other waves through the
+// (then idle) histogram memory.  For small n the tile (n * 256 B) stays L2-resident between
+// sweeps, so HBM sees it about once.
+constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16, KA_CPW = KA_W / KA_WAVES;
+constexpr int KA_HIST_WORDS = KA_MAXK * 64 * 32;          // 80 KiB; also >= 512 * 32 for the first sweep
 struct KAList { int nk; int k[KA_MAXK]; };
 
 __device__ __forceinline__ int ka_word(int row, int half) { return row * 32 + ((half + row) & 31); }
@@ -257,44 +261,28 @@ __device__ __forceinline__ unsigned int wave_incl_scan(unsigned int x)
     return x;
 }
 
+// One sweep + narrowing.  cp/cr: state of this wave's KA_CPW cells (lane j <-> rank j).
 template <int BITS, int SLOTS>
-__global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restrict__ s, int n, long long M, const KAList kl,
-                                                          int shift, unsigned int *__restrict__ ws_prefix,
-                                                          unsigned int *__restrict__ ws_rank, float *__restrict__ out)
+__device__ __forceinline__ void ka_pass(const float *__restrict__ col, bool cok, int n, long long M, int nk, int shift,
+                                        unsigned int *hist, unsigned int (&cp)[KA_CPW], unsigned int (&cr)[KA_CPW],
+                                        long long c0, int lane, int wave, int tid)
 {
-    constexpr int NB = 1 << BITS, PER = (NB + 63) / 64, CPW = KA_W / KA_WAVES;
-    __shared__ unsigned int hist[SLOTS * NB * 32];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nk = kl.nk;
-    const long long c0 = (long long)blockIdx.x * KA_W, c = c0 + lane;
-    const bool cok = c < M;
-    const bool first = (shift + BITS == 32);
-    const unsigned int mask = first ? 0u : ~0u << (shift + BITS);
-
-    // state of the CPW cells this wave will narrow after the sweep (lane j <-> rank j); fetched
-    // now so its latency hides under the sweep
-    unsigned int cp[CPW], cr[CPW];
-#pragma unroll
-    for (int q = 0; q < CPW; ++q) {
-        const long long cg = c0 + wave + q * KA_WAVES;
-        const bool ok = lane < nk && cg < M;
-        cp[q] = (ok && !first) ? ws_prefix[(long long)lane * M + cg] : 0u;
-        cr[q] = ok ? (first ? (unsigned)kl.k[lane] : ws_rank[(long long)lane * M + cg]) : 0u;
-    }
+    constexpr int NB = 1 << BITS, PER = (NB + 63) / 64;
+    const unsigned int mask = (shift + BITS == 32) ? 0u : ~0u << (shift + BITS);
 
     // my cell's DISTINCT prefixes, compacted to the front (slot i = i-th distinct prefix); the
     // sentinel 1 (low bit set) never equals a masked key.  lmax = most slots any cell of this wave
-    // has: the match loop below runs to that wave-uniform bound instead of KA_MAXK.
+    // has: the match loop runs to that wave-uniform bound instead of KA_MAXK.
     unsigned int pf[KA_MAXK];
     int lmax = 1;
     if (SLOTS > 1) {
-        unsigned int *scr = hist + wave * (KA_MAXK * 64);        // per-wave scratch, before hist is zeroed
+        // hist[j*64 + cell] holds the prefixes published by the previous narrowing
+        unsigned int *scr = hist + 1024 + wave * (KA_MAXK * 64);
         unsigned int prev = 0;
         int L = 0;
 #pragma unroll
         for (int j = 0; j < KA_MAXK; ++j) {
-            const unsigned int p = (j < nk && cok) ? ws_prefix[(long long)j * M + c] : 0u;
+            const unsigned int p = j < nk ? hist[j * 64 + lane] : 0u;
             if (j < nk && (j == 0 || p != prev)) { scr[L * 64 + lane] = p; ++L; }
             prev = p;
         }
@@ -325,7 +313,6 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restric
         if (m) atomicAdd(&hist[ka_word((m - 1) * NB + dig, half)], inc);
     };
     if (cok) {
-        const float *col = s + c;
         int i = wave;
         for (; i + 7 * KA_WAVES < n; i += 8 * KA_WAVES) {
             float v[8];
@@ -339,12 +326,11 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restric
     __syncthreads();
 
     // narrow: one wave per cell; lanes over bins (bin = u*64 + lane), ranks resolved slot by slot
+    const bool mine = lane < nk;
 #pragma unroll
-    for (int q = 0; q < CPW; ++q) {
+    for (int q = 0; q < KA_CPW; ++q) {
         const int cc = wave + q * KA_WAVES;
-        const long long cg = c0 + cc;
-        if (cg >= M) break;
-        const bool mine = lane < nk;
+        if (c0 + cc >= M) break;
         const unsigned int myp = cp[q], myr = cr[q];
         const unsigned int upp = __shfl_up(myp, 1);
         unsigned long long lead = __ballot(mine && (lane == 0 || myp != upp));
@@ -356,7 +342,6 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restric
             const int sl = __ffsll((long long)lead) - 1;
             lead &= lead - 1;
             const int nxt = lead ? __ffsll((long long)lead) - 1 : nk;
-            // inclusive prefix sums of this slot's bins, PER blocks of 64 bins
             unsigned int b[PER], incl[PER], carry = 0;
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
@@ -383,13 +368,42 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_pass(const float *__restric
             }
             ++slot;
         }
-        if (mine) {
-            if (shift == 0) {
-                out[(long long)lane * M + cg] = key2f(newp);
-            } else {
-                ws_prefix[(long long)lane * M + cg] = newp;
-                ws_rank[(long long)lane * M + cg] = newr;
-            }
+        cp[q] = newp;
+        cr[q] = newr;
+    }
+    __syncthreads();                       // every wave is done reading the histograms
+    if (shift > 0 && mine) {               // publish the new prefixes for the next sweep's matching
+#pragma unroll
+        for (int q = 0; q < KA_CPW; ++q) hist[lane * 64 + wave + q * KA_WAVES] = cp[q];
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024, 8) kth_axis0_kernel(const float *__restrict__ s, int n, long long M, const KAList kl,
+                                                            float *__restrict__ out)
+{
+    __shared__ unsigned int hist[KA_HIST_WORDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nk = kl.nk;
+    const long long c0 = (long long)blockIdx.x * KA_W, c = c0 + lane;
+    const bool cok = c < M;
+    const float *col = s + c;
+
+    unsigned int cp[KA_CPW], cr[KA_CPW];
+#pragma unroll
+    for (int q = 0; q < KA_CPW; ++q) { cp[q] = 0u; cr[q] = lane < nk ? (unsigned)kl.k[lane] : 0u; }
+
+    ka_pass<9, 1>(col, cok, n, M, nk, 23, hist, cp, cr, c0, lane, wave, tid);
+    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 17, hist, cp, cr, c0, lane, wave, tid);
+    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 11, hist, cp, cr, c0, lane, wave, tid);
+    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 5, hist, cp, cr, c0, lane, wave, tid);
+    ka_pass<5, KA_MAXK>(col, cok, n, M, nk, 0, hist, cp, cr, c0, lane, wave, tid);
+
+    if (lane < nk) {
+#pragma unroll
+        for (int q = 0; q < KA_CPW; ++q) {
+            const long long cg = c0 + wave + q * KA_WAVES;
+            if (cg < M) out[(long long)lane * M + cg] = key2f(cp[q]);
         }
     }
 }
@@ -539,39 +553,22 @@ int pre_kth_f32(const float *scores, int64_t N, const int64_t *ks, int nk, float
     return PRE_OK;
 }
 
-int64_t pre_kth_axis0_workspace_bytes(int64_t M, int nk)
+int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks, int nk, float *out, void *stream)
 {
-    if (M <= 0 || nk <= 0) return 0;
-    const int64_t g = nk < KA_MAXK ? nk : KA_MAXK;
-    return 2 * g * M * (int64_t)sizeof(unsigned int);
-}
-
-int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks, int nk, float *out,
-                      void *workspace, int64_t workspace_bytes, void *stream)
-{
-    if (!scores || !ks || !out || !workspace || n <= 0 || M <= 0 || nk <= 0) return PRE_E_NULL;
+    if (!scores || !ks || !out || n <= 0 || M <= 0 || nk <= 0) return PRE_E_NULL;
     if (n >= 65536 || nk > 64) return PRE_E_SHAPE;
-    if (workspace_bytes < pre_kth_axis0_workspace_bytes(M, nk)) return PRE_E_RANGE;
     for (int j = 0; j < nk; ++j) {
         if (ks[j] < 0 || ks[j] >= n) return PRE_E_RANGE;
         if (j > 0 && ks[j] < ks[j - 1]) return PRE_E_RANGE;      // ascending (slots rely on it)
     }
     const long long tiles = (M + KA_W - 1) / KA_W;
     if (tiles > 0x7fffffffLL) return PRE_E_SHAPE;
-    hipStream_t st = as_stream(stream);
-    unsigned int *wp = static_cast<unsigned int *>(workspace);
     for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < kl.nk; ++j) kl.k[j] = ks[j0 + j];
-        unsigned int *wr = wp + (long long)kl.nk * M;
-        float *o = out + (long long)j0 * M;
-        const dim3 grid((unsigned)tiles), block(1024);
-        hipLaunchKernelGGL((kth_axis0_pass<9, 1>), grid, block, 0, st, scores, (int)n, (long long)M, kl, 23, wp, wr, o);
-        hipLaunchKernelGGL((kth_axis0_pass<6, KA_MAXK>), grid, block, 0, st, scores, (int)n, (long long)M, kl, 17, wp, wr, o);
-        hipLaunchKernelGGL((kth_axis0_pass<6, KA_MAXK>), grid, block, 0, st, scores, (int)n, (long long)M, kl, 11, wp, wr, o);
-        hipLaunchKernelGGL((kth_axis0_pass<6, KA_MAXK>), grid, block, 0, st, scores, (int)n, (long long)M, kl, 5, wp, wr, o);
-        hipLaunchKernelGGL((kth_axis0_pass<5, KA_MAXK>), grid, block, 0, st, scores, (int)n, (long long)M, kl, 0, wp, wr, o);
+        hipLaunchKernelGGL(kth_axis0_kernel, dim3((unsigned)tiles), dim3(1024), 0, as_stream(stream), scores, (int)n,
+                           (long long)M, kl, out + (long long)j0 * M);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;

@@ -111,10 +111,8 @@ def kth_axis0(scores, ks):
         else:
             M = scores.numel() // n
             out = torch.empty((len(sk),) + tuple(scores.shape[1:]), dtype=torch.float32, device=scores.device)
-            nbytes = lib.pre_kth_axis0_workspace_bytes(M, len(sk))
-            work = torch.empty(nbytes, dtype=torch.uint8, device=scores.device)
             _lib.check(lib.pre_kth_axis0_f32(_lib.ptr(scores), n, M, _lib.iarr32(sk), len(sk), _lib.ptr(out),
-                                             _lib.ptr(work), nbytes, _lib.stream()), "pre_kth_axis0_f32")
+                                             _lib.stream()), "pre_kth_axis0_f32")
     inv = [0] * len(ks)
     for pos, i in enumerate(order):
         inv[i] = pos

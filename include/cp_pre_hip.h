@@ -136,13 +136,10 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod,
  * ks: host array of 0-based sorted ranks (the caller derives them from alpha).
  * pre_kth_f32:       scores[N]            -> out[nk]
  * pre_kth_axis0_f32: scores[n, M] contiguous -> out[nk, M]   (per-cell over the batch axis),
- *                    n < 65536, ks ascending, nk <= 64.  `workspace` is device scratch of at least
- *                    pre_kth_axis0_workspace_bytes(M, nk) bytes (per-cell prefixes and ranks
- *                    carried between the digit passes); the library never allocates. */
+ *                    n < 65536, ks ascending, nk <= 64. */
 int pre_kth_f32(const float *scores, int64_t N, const int64_t *ks /*host*/, int nk, float *out, void *stream);
-int64_t pre_kth_axis0_workspace_bytes(int64_t M, int nk);
 int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks /*host*/, int nk,
-                      float *out, void *workspace, int64_t workspace_bytes, void *stream);
+                      float *out, void *stream);
 
 /* ---- a14: emp_cov / emp_cov_joint / filter_sims_joint -----------------------------------
  * (Joint/Burgers_Residuals_CP.py:298-300; Tests/test_advection_inv_sampling_marginal.py:465)
