@@ -647,3 +647,39 @@ def test_interior_t_fast_path_equals_full_path(gpu):
     qb = b.finish(alphas)
     assert torch.equal(qa, qb)
     assert torch.equal(a.modulation[0][1:-1], b.modulation[0][1:-1]) and torch.isnan(a.modulation[0][0]).all()
+
+
+def test_index_arithmetic_beyond_2_31_elements(gpu):
+    """Tensors with more than 2^31 elements (BASELINE C3 slabs have 1e10): the last samples of a big
+    batch must equal the same samples evaluated on their own, for the fused residual, the moments /
+    joint score and the per-cell select (64-bit offsets everywhere)."""
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    from cp_pre_amd.residuals import NavierStokes
+    B, T, X, Y = 300, 10, 512, 512                       # 300*3*10*512*512 = 2.36e9 elements (9.4 GB)
+    assert B * 3 * T * X * Y > 2 ** 31
+    v = torch.empty(B, 3, T, X, Y, device=gpu).uniform_(0.5, 1.5)
+    ns = NavierStokes(0.01, 1 / X, 1 / Y)
+    res = ns.residual_momentum(v, boundary=True)
+    tail = ns.residual_momentum(v[-2:].clone(), boundary=True)
+    assert torch.equal(res[-2:], tail)
+    head = ns.residual_momentum(v[:2].clone(), boundary=True)
+    assert torch.equal(res[:2], head)
+    # calibration over > 2^31 residual elements: [2200, 1M cells]
+    del v, res
+    n, M = 2200, 1 << 20
+    assert n * M > 2 ** 31
+    s = torch.empty(n, M, device=gpu).normal_()
+    ks = [0, n // 2, n - 1]
+    q = icp.kth_axis0(s, ks)
+    for cols in (slice(0, 256), slice(M - 256, M)):
+        ref = torch.sort(s[:, cols], dim=0).values[ks]
+        assert torch.equal(q[:, cols], ref)
+    mom = pipeline.HipOps.zeros_moments(M, gpu)
+    pipeline.HipOps.add_moments(s, mom)
+    ref_sum = s[:, -128:].double().sum(0)
+    assert torch.allclose(mom[0, -128:], ref_sum, rtol=1e-12, atol=1e-9)
+    mod = torch.ones(1, 1, M, device=gpu)
+    sc = pipeline.HipOps.zeros_scores(n, gpu)
+    pipeline.HipOps.max_scores(s.view(n, 1, 1, M), mod, (0, 0, 0), sc)
+    assert torch.equal(sc[-3:], s[-3:].abs().amax(1))
