@@ -28,6 +28,11 @@ class PreField(ctypes.Structure):
     _fields_ = [("ptr", c_void_p), ("sB", c_int64), ("sT", c_int64), ("sX", c_int64), ("sY", c_int64)]
 
 
+class PreBC(ctypes.Structure):
+    """``pre_bc_t``: boundary mode / value for left, right (columns) and top, bottom (rows)."""
+    _fields_ = [("mode", c_int * 4), ("value", c_float * 4)]
+
+
 _fp, _fld = c_void_p, POINTER(PreField)
 # name -> argtypes; every symbol include/cp_pre_hip.h declares
 SIGNATURES = {
@@ -38,6 +43,9 @@ SIGNATURES = {
     "pre_residual_linear2_f32": [_fld, _fld, _fld, POINTER(c_float), POINTER(c_float), c_float] + [c_int64] * 4 + [c_int, c_void_p],
     "pre_residual_burgers_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_int64)] + [POINTER(c_float)] * 3 + [c_float] * 4 + [c_int64] * 3 + [c_int, c_void_p],
     "pre_residual_mhd_f32": [c_int, POINTER(PreField), _fld] + [POINTER(c_float)] * 3 + [c_double] + [c_int64] * 4 + [c_int, c_void_p],
+    "pre_spatial2d_bc_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_int64), POINTER(c_float), POINTER(PreBC), c_int64, c_int64, c_int64, c_int, c_void_p],
+    "pre_spatial2d_linear2_bc_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_int64), _fp, POINTER(c_int64), POINTER(c_float), POINTER(c_float),
+                                     c_float, POINTER(PreBC), c_int64, c_int64, c_int64, c_int, c_void_p],
     "pre_absdiff_f32": [_fp, _fp, _fp, c_int64, c_void_p],
     "pre_std_axis0_f32": [_fp, _fp, c_int64, c_int64, c_float, _fp, c_void_p],
     "pre_moments_axis0_f64": [_fp, _fp, c_int64, c_int64, c_int64, _fp, _fp, c_void_p],

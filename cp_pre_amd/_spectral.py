@@ -23,7 +23,7 @@ def _kernel_spectrum(kernel, like, dims):
     return k, rfftn(F.pad(k, grow).float(), dim=dims)
 
 
-def fft_xcorr(field, kernel, inverse=False):
+def fft_xcorr(field, kernel, inverse=False, keep_channel=False):
     """``fft_conv(field, K, padding=k//2[, inverse])``: zero-pad by k//2, make the last axis
     even, multiply by the CONJUGATE kernel spectrum (cross-correlation) - or by
     1/(conj(K)+1e-6) when ``inverse`` - and keep the leading ``n - k + 1`` samples."""
@@ -41,7 +41,8 @@ def fft_xcorr(field, kernel, inverse=False):
         kf = 1 / (kf + 1e-6)
     out = irfftn(rfftn(x.float(), dim=dims) * kf, dim=dims)
     keep = (slice(None), slice(None)) + tuple(slice(0, size[i] - k.size(i) + 1) for i in range(2, x.ndim))
-    return out[keep].contiguous().squeeze(1)
+    out = out[keep].contiguous()
+    return out if keep_channel else out.squeeze(1)
 
 
 def _pad_all(field, kernel):
@@ -51,27 +52,27 @@ def _pad_all(field, kernel):
     return F.pad(x, (p, p) * nd, mode='constant'), tuple(range(2, x.ndim))
 
 
-def _crop(out, xp, k, slice_pad):
+def _crop(out, xp, k, slice_pad, keep_channel=False):
     if slice_pad:
         keep = (slice(None), slice(None)) + tuple(slice(0, xp.size(i) - k.size(i) + 1) for i in range(2, xp.ndim))
         out = out[keep].contiguous()
-    return out.squeeze(1)
+    return out if keep_channel else out.squeeze(1)
 
 
-def differentiate(field, kernel, correlation=False, slice_pad=True):
+def differentiate(field, kernel, correlation=False, slice_pad=True, keep_channel=False):
     xp, dims = _pad_all(field, kernel)
     k, kf = _kernel_spectrum(kernel, xp, dims)
     if correlation:
         kf = torch.conj(kf)
     out = irfftn(rfftn(xp.float(), dim=dims) * kf, dim=dims)
-    return _crop(out, xp, k, slice_pad)
+    return _crop(out, xp, k, slice_pad, keep_channel)
 
 
-def integrate(field, kernel, correlation=False, slice_pad=False, eps=1e-6):
+def integrate(field, kernel, correlation=False, slice_pad=False, eps=1e-6, keep_channel=False):
     xp, dims = _pad_all(field, kernel)
     k, kf = _kernel_spectrum(kernel, xp, dims)
     inv = 1 / (kf + eps)
     if correlation:
         inv = torch.conj(inv)
     out = irfftn(rfftn(xp, dim=dims) * inv, dim=dims)
-    return _crop(out, xp, k, slice_pad)
+    return _crop(out, xp, k, slice_pad, keep_channel)

@@ -17,6 +17,7 @@
 // taken from the caller's dense 3x3x3 kernels, so the reference's kernel-construction
 // quirks are inherited (see include/cp_pre_hip.h).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -224,8 +225,17 @@ __device__ __forceinline__ void lds_barrier()
 
 template <int F> struct Halo { float4 row[F]; float yl[F], yr[F]; };
 
-template <class Fn, int NR, int TYQ>
-__global__ void __launch_bounds__(NR *TYQ) march_kernel(const Geom g, const typename Fn::Params prm)
+// Boundary conditions on the (x, y) rim for the BC=true instantiations (Utils/boundary_conditions.py:
+// BoundaryManager.pad_signal followed by a 'valid' conv == a 'same' conv whose out-of-domain neighbour
+// is a mapped in-domain cell or a constant).  For each side: idx >= 0 = row / column to read instead
+// of the cell just outside (periodic: the opposite edge; neumann/outflow: the edge itself; symmetric:
+// one inside the edge), idx < 0 = the constant val (dirichlet).  Radius-1 stars never see corners.
+struct BCInfo { int xlo, xhi, ylo, yhi; float vxlo, vxhi, vylo, vyhi; };
+struct NoBC {};
+
+template <class Fn, int NR, int TYQ, bool BC = false>
+__global__ void __launch_bounds__(NR *TYQ)
+march_kernel(const Geom g, const typename Fn::Params prm, const typename std::conditional<BC, BCInfo, NoBC>::type bc)
 {
     constexpr int F = Fn::F;
     static_assert(NR >= 2, "tile needs at least two rows (top and bottom halo owners differ)");
@@ -240,6 +250,14 @@ __global__ void __launch_bounds__(NR *TYQ) march_kernel(const Geom g, const type
 
     const int x = xt * NR + ty, y = (yt * TYQ + q) * 4;
     const bool inb = (x < g.X) && (y < g.Y);
+    // BC: the row just below the domain (x == X, only in a partial last tile) is a ghost row that
+    // feeds the x+ neighbour of row X-1; it loads its mapped row and never stores
+    int xl = x;                 // row this thread loads as its "own"
+    float ghost = 0.f;
+    bool ldown = inb;
+    if constexpr (BC) {
+        if (x == g.X && y < g.Y) { xl = bc.xhi; ghost = bc.vxhi; ldown = bc.xhi >= 0; }
+    }
     int t0 = ts * g.tSeg;
     int t1 = min(t0 + g.tSeg, g.T);
     if (g.flags & PRE_FLAG_INTERIOR_T) {       // the caller crops the t rim: neither compute nor store it
@@ -249,36 +267,50 @@ __global__ void __launch_bounds__(NR *TYQ) march_kernel(const Geom g, const type
 
     // halo-row duty: thread-row 0 fetches the row above the tile, thread-row NR-1 the row below
     const bool top = (ty == 0), bot = (ty == NR - 1);
-    const int hx = top ? x - 1 : x + 1;
-    const bool hrow = (top || bot) && (hx >= 0) && (hx < g.X) && (y < g.Y);
+    int hx = top ? x - 1 : x + 1;
+    bool hrow = (top || bot) && (hx >= 0) && (hx < g.X) && (y < g.Y);
+    float hfill = 0.f;          // value of an out-of-domain halo row
     const int hslot = top ? 0 : NR + 1;
     // y-halo duty: the edge lanes of each wave (and of the tile) fetch one scalar
-    const bool ledge = ((q & 63) == 0), redge = ((q & 63) == 63) || (q == TYQ - 1);
-    const bool lload = ledge && inb && (y > 0);
-    const bool rload = redge && inb && (y + 4 < g.Y);
+    const bool ledge = ((q & 63) == 0);
+    bool redge = ((q & 63) == 63) || (q == TYQ - 1);
+    bool lload = ledge && inb && (y > 0);
+    bool rload = redge && inb && (y + 4 < g.Y);
+    int yloff = -1, yroff = 4;  // element offsets of the y- / y+ scalar relative to the own float4
+    float ylfill = 0.f, yrfill = 0.f;
+    if constexpr (BC) {
+        if ((top || bot) && y < g.Y && (hx == -1 || hx == g.X)) {
+            const int m = hx < 0 ? bc.xlo : bc.xhi;
+            hfill = hx < 0 ? bc.vxlo : bc.vxhi;
+            hrow = m >= 0;
+            hx = m >= 0 ? m : 0;
+        }
+        if (inb && y == 0) { lload = bc.ylo >= 0; yloff = bc.ylo; ylfill = bc.vylo; }
+        if (inb && y + 4 >= g.Y) { redge = true; rload = bc.yhi >= 0; yroff = bc.yhi - y; yrfill = bc.vyhi; }
+    }
 
     const float *own[F], *hal[F];
 #pragma unroll
     for (int i = 0; i < F; ++i) {
         const float *base = g.f[i] + (long long)b * g.sB[i];
-        own[i] = base + (long long)x * g.sX[i] + y;
+        own[i] = base + (long long)xl * g.sX[i] + y;
         hal[i] = base + (long long)hx * g.sX[i] + y;
     }
     float *outp = g.out + (long long)b * g.oB + (long long)x * g.oX + y;
     const long long oT = g.oT;
 
     auto load_own = [&](int t, float4(&dst)[F]) __attribute__((always_inline)) {
-        const bool ok = inb && (t >= 0) && (t < g.T);
+        const bool ok = ldown && (t >= 0) && (t < g.T);
 #pragma unroll
-        for (int i = 0; i < F; ++i) dst[i] = ok ? ldg4(own[i] + (long long)t * g.sT[i]) : f4(0.f);
+        for (int i = 0; i < F; ++i) dst[i] = ok ? ldg4(own[i] + (long long)t * g.sT[i]) : f4(BC ? ghost : 0.f);
     };
     auto load_halo = [&](int t, Halo<F> &h) __attribute__((always_inline)) {
         const bool okt = (t >= 0) && (t < g.T);
 #pragma unroll
         for (int i = 0; i < F; ++i) {
-            h.row[i] = (hrow && okt) ? ldg4(hal[i] + (long long)t * g.sT[i]) : f4(0.f);
-            h.yl[i] = (lload && okt) ? own[i][(long long)t * g.sT[i] - 1] : 0.f;
-            h.yr[i] = (rload && okt) ? own[i][(long long)t * g.sT[i] + 4] : 0.f;
+            h.row[i] = (hrow && okt) ? ldg4(hal[i] + (long long)t * g.sT[i]) : f4(BC ? hfill : 0.f);
+            h.yl[i] = (lload && okt) ? own[i][(long long)t * g.sT[i] + (BC ? yloff : -1)] : (BC ? ylfill : 0.f);
+            h.yr[i] = (rload && okt) ? own[i][(long long)t * g.sT[i] + (BC ? yroff : 4)] : (BC ? yrfill : 0.f);
         }
     };
 
@@ -373,8 +405,8 @@ int pick_mode(const Star &Dt, const Star &Dx, const Star &Dy, const Star *L)
     return 2;
 }
 
-template <class Fn, int NR, int TYQ>
-int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st)
+template <class Fn, int NR, int TYQ, bool BC = false>
+int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const BCInfo *bc = nullptr)
 {
     static_assert(2 * Fn::F * (NR + 2) * TYQ * 16 <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     {
@@ -389,21 +421,25 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st)
     g.nTSeg = (g.T + tSeg - 1) / tSeg;
     tiles *= g.nTSeg;
     if (tiles <= 0 || tiles > 0x7fffffffLL) return PRE_E_SHAPE;
-    hipLaunchKernelGGL((march_kernel<Fn, NR, TYQ>), dim3((unsigned)tiles), dim3(TYQ, NR), 0, st, g, prm);
+    if constexpr (BC) {
+        hipLaunchKernelGGL((march_kernel<Fn, NR, TYQ, true>), dim3((unsigned)tiles), dim3(TYQ, NR), 0, st, g, prm, *bc);
+    } else {
+        hipLaunchKernelGGL((march_kernel<Fn, NR, TYQ, false>), dim3((unsigned)tiles), dim3(TYQ, NR), 0, st, g, prm, NoBC{});
+    }
     PRE_LAUNCH_CHECK();
     return PRE_OK;
     }
 }
 
-template <class Fn>
-int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st)
+template <class Fn, bool BC = false>
+int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st, const BCInfo *bc = nullptr)
 {
     // 512 threads per workgroup; rows of the tile trade halo re-reads (2/NR) against columns covered
     // 8 rows x 256 columns: measured best of {4,8,16} rows (16 rows = 1024 threads, one workgroup per CU: -5 %)
     // (also measured: 16x128 and 32x64 tiles at 512 threads, -2..-7 % on every functor)
-    if (g.Y >= 192) return launch_tiled<Fn, 8, 64>(g, prm, st);
-    if (g.Y >= 96) return launch_tiled<Fn, 16, 32>(g, prm, st);
-    return launch_tiled<Fn, 32, 16>(g, prm, st);
+    if (g.Y >= 192) return launch_tiled<Fn, 8, 64, BC>(g, prm, st, bc);
+    if (g.Y >= 96) return launch_tiled<Fn, 16, 32, BC>(g, prm, st, bc);
+    return launch_tiled<Fn, 32, 16, BC>(g, prm, st, bc);
 }
 
 // Fill the kernel geometry from the caller's views and RELABEL the axes so that the kernel's
@@ -595,6 +631,82 @@ int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], const pre_out_t *o
     if (rc) return rc;
     if (eq == 1) return launch_mode<MHDMomentum>(relabeled_mode(mode, rel), g, prm, st);
     return launch_mode<MHDEnergy>(relabeled_mode(mode, rel), g, prm, st);
+}
+
+// ---- 2-D spatial operators with boundary conditions ----------------------------
+namespace {
+// pre_bc_t side -> (index to read, constant); n = extent of the axis
+bool bc_side(int mode, float value, int64_t n, bool hi, int *idx, float *val)
+{
+    *val = 0.f;
+    switch (mode) {
+    case PRE_BC_CONSTANT: *idx = -1; *val = value; return true;
+    case PRE_BC_REPLICATE: *idx = hi ? (int)n - 1 : 0; return true;
+    case PRE_BC_PERIODIC: *idx = hi ? 0 : (int)n - 1; return true;
+    case PRE_BC_REFLECT: if (n < 2) return false; *idx = hi ? (int)n - 2 : 1; return true;
+    default: return false;
+    }
+}
+
+int fill_bc(const pre_bc_t *bc, int64_t X, int64_t Y, BCInfo *o)
+{
+    if (!bc) return PRE_E_NULL;
+    // top/bottom act on the first spatial axis (X, rows), left/right on the second (Y, columns)
+    if (!bc_side(bc->mode[2], bc->value[2], X, false, &o->xlo, &o->vxlo) || !bc_side(bc->mode[3], bc->value[3], X, true, &o->xhi, &o->vxhi) ||
+        !bc_side(bc->mode[0], bc->value[0], Y, false, &o->ylo, &o->vylo) || !bc_side(bc->mode[1], bc->value[1], Y, true, &o->yhi, &o->vyhi))
+        return PRE_E_RANGE;
+    return PRE_OK;
+}
+
+bool star_from_dense9(const float *K, Star *s)     // 3x3 kernel, axes (X, Y)
+{
+    if (K[0] != 0.f || K[2] != 0.f || K[6] != 0.f || K[8] != 0.f) return false;
+    *s = Star{K[4], 0.f, 0.f, K[1], K[7], K[3], K[5]};
+    return true;
+}
+}  // namespace
+
+int pre_spatial2d_bc_f32(const float *in, const int64_t in_strides[3], float *out, const int64_t out_strides[3],
+                         const float *K, const pre_bc_t *bc, int64_t B, int64_t X, int64_t Y, int flags, void *stream)
+{
+    if (!in || !out || !in_strides || !out_strides || !K) return PRE_E_NULL;
+    // planes [B,X,Y] -> [1,B,X,Y]: the plane axis is the tap-free marching axis
+    pre_field_t f{in, 0, in_strides[0], in_strides[1], in_strides[2]};
+    pre_out_t o{out, 0, out_strides[0], out_strides[1], out_strides[2]};
+    if (f.sY != 1 || o.sY != 1) return PRE_E_UNSUPPORTED;            // no relabelling here: the BCs are tied to the axes
+    const pre_field_t *fs[1] = {&f};
+    Linear1::Params prm;
+    if (!star_from_dense9(K, &prm.s)) return PRE_E_UNSUPPORTED;
+    BCInfo info;
+    int rc = fill_bc(bc, X, Y, &info);
+    if (rc) return rc;
+    Geom g;
+    int rel;
+    rc = prepare(g, rel, fs, 1, &o, 1, B, X, Y, flags & ~PRE_FLAG_INTERIOR_T, nullptr, 0);
+    if (rc) return rc;
+    return launch<Linear1, true>(g, prm, as_stream(stream), &info);
+}
+
+int pre_spatial2d_linear2_bc_f32(const float *in0, const int64_t s0[3], const float *in1, const int64_t s1[3], float *out,
+                                 const int64_t out_strides[3], const float *K0, const float *K1, float ratio,
+                                 const pre_bc_t *bc, int64_t B, int64_t X, int64_t Y, int flags, void *stream)
+{
+    if (!in0 || !in1 || !out || !s0 || !s1 || !out_strides || !K0 || !K1) return PRE_E_NULL;
+    pre_field_t f0{in0, 0, s0[0], s0[1], s0[2]}, f1{in1, 0, s1[0], s1[1], s1[2]};
+    pre_out_t o{out, 0, out_strides[0], out_strides[1], out_strides[2]};
+    if (f0.sY != 1 || f1.sY != 1 || o.sY != 1) return PRE_E_UNSUPPORTED;
+    const pre_field_t *fs[2] = {&f0, &f1};
+    Linear2::Params prm;
+    if (!star_from_dense9(K0, &prm.a) || !star_from_dense9(K1, &prm.b)) return PRE_E_UNSUPPORTED;
+    prm.ratio = ratio;
+    BCInfo info;
+    int rc = fill_bc(bc, X, Y, &info);
+    if (rc) return rc;
+    Geom g;
+    int rel;
+    rc = prepare(g, rel, fs, 2, &o, 1, B, X, Y, flags & ~PRE_FLAG_INTERIOR_T, nullptr, 0);
+    if (rc) return rc;
+    return launch<Linear2, true>(g, prm, as_stream(stream), &info);
 }
 
 }  // extern "C"

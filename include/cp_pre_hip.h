@@ -99,6 +99,31 @@ int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], const pre_out_t *o
                          const float *K_t, const float *K_x, const float *K_y, double gamma,
                          int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream);
 
+/* ---- 8f rank 4: 2-D spatial operators with boundary conditions -------------------------------
+ * Utils/ConvOps_Spatial.py:83-136 (F.conv2d, 'valid') applied to a field padded by
+ * Utils/boundary_conditions.py:81-185 (BoundaryManager.pad_signal), as the Gradient / Laplace /
+ * Divergence / Curl of Utils/VectorConvOps_Spatial.py:33-165 do - fused: a 'same'-sized output whose
+ * out-of-domain neighbours are mapped cells (periodic / neumann-outflow / symmetric) or a constant
+ * (dirichlet).  Planes [B,X,Y] (the [BS,1,Nx,Ny] field with the channel squeezed), strides {sB,sX,sY}
+ * with sY == 1; K is the 3x3 kernel (9 host floats, axes (Nx,Ny)), cross-shaped; otherwise
+ * PRE_E_UNSUPPORTED and the caller pads with device ops and runs pre_stencil3d_f32. */
+#define PRE_BC_CONSTANT  0     /* 'dirichlet' (value)            */
+#define PRE_BC_REPLICATE 1     /* 'neumann', 'outflow'           */
+#define PRE_BC_PERIODIC  2     /* 'periodic'                     */
+#define PRE_BC_REFLECT   3     /* 'symmetric' (F.pad 'reflect')  */
+typedef struct {
+    int mode[4];               /* left, right (columns / Ny), top, bottom (rows / Nx) */
+    float value[4];
+} pre_bc_t;
+int pre_spatial2d_bc_f32(const float *in, const int64_t in_strides[3], float *out, const int64_t out_strides[3],
+                         const float *K /*host, 9*/, const pre_bc_t *bc /*host*/,
+                         int64_t B, int64_t X, int64_t Y, int flags, void *stream);
+/* out = K0(pad(in0)) + ratio*K1(pad(in1))   (Divergence: ratio 1; Curl: K0=grad_x on input_y, ratio -1) */
+int pre_spatial2d_linear2_bc_f32(const float *in0, const int64_t s0[3], const float *in1, const int64_t s1[3],
+                                 float *out, const int64_t out_strides[3], const float *K0, const float *K1,
+                                 float ratio, const pre_bc_t *bc /*host*/,
+                                 int64_t B, int64_t X, int64_t Y, int flags, void *stream);
+
 /* ---- a10: marginal nonconformity score ------------------------------------------------
  * out = |a - b| (b may be NULL: |a|).  Marginal/Wave_Residuals_CP.py:219,280 */
 int pre_absdiff_f32(const float *a, const float *b, float *out, int64_t n, void *stream);

@@ -18,6 +18,8 @@ What is executed from the reference (nothing of it is copied into this repo):
   * ``filter_sims_joint`` (Joint/Burgers_Residuals_CP.py:298-300) and ``filter_sims_within_bounds``
     (Active_Learning/Advection_AL_Marginal.py:169-198) - defined inside the reference tree -
     compiled from it the same way -> filters.npz
+  * ``Utils/ConvOps_Spatial.py``, ``Utils/boundary_conditions.py``, ``Utils/VectorConvOps_Spatial.py``
+    - imported on CPU -> spatial.npz
   * conformal.npz is BUILD-DEFINED (numpy, oracle/conformal.py): the reference's
     ``Neural_PDE.UQ.inductive_cp`` is absent, so these vectors pin the oracle to numpy,
     not to the reference ("parity unpinned").
@@ -222,15 +224,69 @@ def gen_filters():
     np.savez_compressed(os.path.join(HERE, "filters.npz"), **out)
 
 
+def gen_spatial():
+    """Utils/ConvOps_Spatial.py, Utils/boundary_conditions.py, Utils/VectorConvOps_Spatial.py imported on
+    CPU.  Gradient / Vector_Gradient hard-code device='cuda' for their sub-operators and cannot be
+    built here; their pieces (padding + the two first-derivative operators) are all dumped."""
+    import importlib
+    sp = importlib.import_module("ConvOps_Spatial")
+    vs = importlib.import_module("VectorConvOps_Spatial")
+    bcm = importlib.import_module("boundary_conditions")
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 1, 12, 16, generator=g)
+    y = torch.randn(3, 1, 12, 16, generator=g)
+    out["x"], out["y"] = x.numpy(), y.numpy()
+    for d in ["x", "y", ("x", "y"), "t", None]:
+        for o in (0, 1, 2):
+            for ty in (2, 4, 6):
+                for sc in (1.0, 0.37):
+                    op = sp.ConvOperator(d, o, scale=sc, taylor_order=ty, device="cpu")
+                    key = f"k|{dom_tag(d)}|{o}|{ty}|{sc}"
+                    if hasattr(op, "kernel"):
+                        out[key] = op.kernel.detach().numpy()
+                        if sc == 1.0:
+                            out["conv|" + key[2:]] = op(x).detach().numpy() if hasattr(op, "__call__") and callable(getattr(op, "forward", None)) else op.convolution(x).detach().numpy()
+                    else:
+                        out[key] = np.zeros((0,), np.float32)
+    for bc in ("periodic", "dirichlet", "neumann", "outflow", "symmetric", "free_slip"):
+        for ks in (3, 5):
+            m = bcm.BoundaryManager(kernel_size=(ks, ks))
+            m.set_all_boundaries(bc_type=bc, value=0.75)
+            out[f"pad|{bc}|{ks}"] = m.pad_signal(x).numpy()
+    m = bcm.BoundaryManager(kernel_size=3)
+    m.set_boundary_type("left", "dirichlet", 1.5); m.set_boundary_type("right", "neumann")
+    m.set_boundary_type("top", "symmetric"); m.set_boundary_type("bottom", "periodic")
+    out["pad|mixed|3"] = m.pad_signal(x).numpy()
+    for bc in ("periodic", "dirichlet", "neumann", "symmetric"):
+        for ty in (2, 4):
+            L = vs.Laplace(scale=1.7, taylor_order=ty, boundary_cond=bc, device="cpu")
+            out[f"laplace|{bc}|{ty}"] = L(x).detach().numpy()
+        Lv = vs.Laplace(scale=0.5, boundary_cond=bc, scalar=False, device="cpu")
+        out[f"laplace_vec|{bc}"] = Lv(x, y).detach().numpy()
+        Dv = vs.Divergence(scale=2.0, boundary_cond=bc, device="cpu")
+        out[f"divergence|{bc}"] = Dv(x, y).detach().numpy()
+        Cv = vs.Curl(scale=2.0, boundary_cond=bc, device="cpu")
+        out[f"curl|{bc}"] = Cv(x, y).detach().numpy()
+    v2 = torch.cat((x, y), dim=1)
+    out["dot"] = vs.dot(v2, v2.flip(1)).numpy()
+    out["cross"] = vs.cross(v2, v2 * 2).numpy()
+    np.savez_compressed(os.path.join(HERE, "spatial.npz"), **out)
+
+
 if __name__ == "__main__":
     if "filters" in sys.argv[1:]:
         gen_filters()
+        sys.exit(0)
+    if "spatial" in sys.argv[1:]:
+        gen_spatial()
         sys.exit(0)
     ks = gen_kernels()
     gen_apply(ks)
     gen_residuals()
     gen_conformal()
     gen_filters()
+    gen_spatial()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

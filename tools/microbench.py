@@ -119,6 +119,24 @@ def bench_permuted():
         del sur, v
 
 
+def bench_spatial():
+    """2-D spatial operators with fused boundary conditions (Utils/VectorConvOps_Spatial.py)."""
+    from cp_pre_amd import vector_convops_spatial as V
+    for (B, X, Y) in [(4096, 512, 512), (16384, 256, 256)]:
+        a = torch.empty(B, 1, X, Y, device=dev).uniform_()
+        b = torch.empty(B, 1, X, Y, device=dev).uniform_()
+        cells = B * X * Y
+        L = V.Laplace(scale=1.0, boundary_cond='periodic', device=dev)
+        D = V.Divergence(scale=1.0, boundary_cond='periodic', device=dev)
+        with torch.no_grad():
+            report(f"spatial Laplace periodic fused [{B},1,{X},{Y}] 8B/cell", timeit(lambda: L(a)), 8 * cells)
+            report(f"spatial Divergence periodic fused 12B/cell", timeit(lambda: D(a, b)), 12 * cells)
+            report(f"spatial Laplace: pad_signal + valid conv (reference recipe) 8B/cell", timeit(lambda: L.laplace(L.bc.pad_signal(a))), 8 * cells)
+        del a, b
+
+
+if __name__ == "__main__" and "spatial" in sys.argv[1:]:
+    bench_spatial()
 if __name__ == "__main__" and "copy" in sys.argv[1:]:
     bench_copy()
 if __name__ == "__main__" and "permuted" in sys.argv[1:]:
