@@ -274,7 +274,33 @@ def gen_spatial():
     np.savez_compressed(os.path.join(HERE, "spatial.npz"), **out)
 
 
+def gen_spectral():
+    """conv='spectral', differentiate, integrate of the three ConvOperator files (torch.fft on CPU)."""
+    import importlib
+    sp = importlib.import_module("ConvOps_Spatial")
+    out = {}
+    g = torch.Generator().manual_seed(9)
+    x4, x3, xs = torch.randn(2, 6, 8, 10, generator=g), torch.randn(3, 9, 12, generator=g), torch.randn(2, 1, 9, 12, generator=g)
+    out["x4"], out["x3"], out["xs"] = x4.numpy(), x3.numpy(), xs.numpy()
+    cases = [("2d_lap", Ref2D(("x", "y"), 2), x4), ("2d_t1", Ref2D("t", 1), x4), ("1d_x2", Ref1D("x", 2), x3),
+             ("1d_xt", Ref1D(("x", "t"), 2), x3), ("sp_lap", sp.ConvOperator(("x", "y"), 2, device="cpu"), xs),
+             ("sp_x1", sp.ConvOperator("x", 1, scale=0.5, device="cpu"), xs)]
+    for name, op, x in cases:
+        out[f"{name}|kernel"] = op.kernel.detach().numpy()
+        out[f"{name}|spectral"] = op.spectral_convolution(x).detach().numpy()
+        if name.startswith(("2d", "sp")):
+            out[f"{name}|spectral_inv"] = op.spectral_convolution(x, inverse=True).detach().numpy()
+        for corr in (False, True):
+            for sl in (False, True):
+                out[f"{name}|diff|{int(corr)}|{int(sl)}"] = op.differentiate(x, correlation=corr, slice_pad=sl).detach().numpy()
+                out[f"{name}|int|{int(corr)}|{int(sl)}"] = op.integrate(x, correlation=corr, slice_pad=sl).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "spectral.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "spectral" in sys.argv[1:]:
+        gen_spectral()
+        sys.exit(0)
     if "filters" in sys.argv[1:]:
         gen_filters()
         sys.exit(0)
@@ -287,6 +313,7 @@ if __name__ == "__main__":
     gen_conformal()
     gen_filters()
     gen_spatial()
+    gen_spectral()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
