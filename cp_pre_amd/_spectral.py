@@ -3,14 +3,29 @@
 ``conv='spectral'``, ``differentiate`` and ``integrate`` of ``Utils/ConvOps_2d.py:153-284`` /
 ``Utils/ConvOps_1d.py:153-283`` (and the ``fft_conv`` they call,
 ``Utils/fft_conv_pytorch/fft_conv.py:35-131``) are kept on the class surface as thin
-``torch.fft`` compositions, which run through hipFFT when the field lives on the GPU.
-No hand-written kernel here; out of the measured path.
+``torch.fft`` compositions executed by hipFFT: like every other compute entry of the package they
+run on the MI355X only - CPU tensors are staged through the GPU and come back on the CPU, and without
+a HIP device the call raises (no CPU fallback).  No hand-written kernel here; out of the measured path.
 """
 from __future__ import annotations
+
+import functools
 
 import torch
 import torch.nn.functional as F
 from torch.fft import irfftn, rfftn
+
+from . import _dispatch
+
+
+def _on_gpu(fn):
+    @functools.wraps(fn)
+    def wrapped(field, kernel, *args, **kwargs):
+        _dispatch._check_field(field)
+        dev, origin = _dispatch.to_device(field)
+        return _dispatch.from_device(fn(dev, kernel.detach().to(dev.device) if not kernel.requires_grad else kernel.to(dev.device),
+                                        *args, **kwargs), origin)
+    return wrapped
 
 
 def _with_channel(field, nd):
@@ -23,6 +38,7 @@ def _kernel_spectrum(kernel, like, dims):
     return k, rfftn(F.pad(k, grow).float(), dim=dims)
 
 
+@_on_gpu
 def fft_xcorr(field, kernel, inverse=False, keep_channel=False):
     """``fft_conv(field, K, padding=k//2[, inverse])``: zero-pad by k//2, make the last axis
     even, multiply by the CONJUGATE kernel spectrum (cross-correlation) - or by
@@ -59,6 +75,7 @@ def _crop(out, xp, k, slice_pad, keep_channel=False):
     return out if keep_channel else out.squeeze(1)
 
 
+@_on_gpu
 def differentiate(field, kernel, correlation=False, slice_pad=True, keep_channel=False):
     xp, dims = _pad_all(field, kernel)
     k, kf = _kernel_spectrum(kernel, xp, dims)
@@ -68,6 +85,7 @@ def differentiate(field, kernel, correlation=False, slice_pad=True, keep_channel
     return _crop(out, xp, k, slice_pad, keep_channel)
 
 
+@_on_gpu
 def integrate(field, kernel, correlation=False, slice_pad=False, eps=1e-6, keep_channel=False):
     xp, dims = _pad_all(field, kernel)
     k, kf = _kernel_spectrum(kernel, xp, dims)

@@ -142,9 +142,11 @@ class NavierStokes(_Residual2D):
 
     def periodic_bc_residual(self, u, wall='right'):
         """``Marginal/NS_Residuals_CP.py:468-478`` (edge differences; plain slicing)."""
-        res = {'top': lambda: u[..., 0, :] - u[..., -1, :], 'bottom': lambda: u[..., -1, :] - u[..., 0, :],
-               'left': lambda: u[..., :, 0] - u[..., :, -1], 'right': lambda: u[..., :, -1] - u[..., :, 0]}[wall]()
-        return res * self.dx
+        def edges(u):
+            res = {'top': lambda: u[..., 0, :] - u[..., -1, :], 'bottom': lambda: u[..., -1, :] - u[..., 0, :],
+                   'left': lambda: u[..., :, 0] - u[..., :, -1], 'right': lambda: u[..., :, -1] - u[..., :, 0]}[wall]()
+            return res * self.dx
+        return _on_device((u,), edges)
 
 
 class PRE_NS(NavierStokes):

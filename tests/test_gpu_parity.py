@@ -754,3 +754,39 @@ def test_spatial_family_matches_reference_golden(gpu):
     xg = big.to(gpu).requires_grad_(True)
     V.Divergence(scale=2.0, device=gpu)(xg, xg).pow(2).sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+def test_spectral_family_matches_reference_golden(gpu):
+    """conv='spectral' / differentiate / integrate (torch.fft pass-through, not a HIP
+    kernel) of all three ConvOperator files against outputs of the reference's own methods."""
+    from conftest import load_golden
+    from cp_pre_amd.convops_1d import ConvOperator as Conv1D
+    from cp_pre_amd.convops_2d import ConvOperator as Conv2D
+    from cp_pre_amd.convops_spatial import ConvOperator as ConvS
+    g = load_golden("spectral.npz")
+    x4, x3, xs = (torch.from_numpy(g[k]) for k in ("x4", "x3", "xs"))
+    cases = {"2d_lap": (Conv2D(("x", "y"), 2), x4), "2d_t1": (Conv2D("t", 1), x4), "1d_x2": (Conv1D("x", 2), x3),
+             "1d_xt": (Conv1D(("x", "t"), 2), x3), "sp_lap": (ConvS(("x", "y"), 2, device="cpu"), xs),
+             "sp_x1": (ConvS("x", 1, scale=0.5, device="cpu"), xs)}
+    n = 0
+    for name, (op, x) in cases.items():
+        assert np.array_equal(op.kernel.detach().numpy(), g[f"{name}|kernel"])
+        with torch.no_grad():
+            for key in [k for k in g.files if k.startswith(name + "|") and not k.endswith("kernel")]:
+                parts = key.split("|")
+                if parts[1] == "spectral":
+                    got = op.spectral_convolution(x)
+                elif parts[1] == "spectral_inv":
+                    got = op.spectral_convolution(x, inverse=True)
+                elif parts[1] == "diff":
+                    got = op.differentiate(x, correlation=bool(int(parts[2])), slice_pad=bool(int(parts[3])))
+                else:
+                    got = op.integrate(x, correlation=bool(int(parts[2])), slice_pad=bool(int(parts[3])))
+                assert not got.is_cuda and tuple(got.shape) == g[key].shape, key      # CPU in -> hipFFT -> CPU out
+                assert rel_err(got.numpy(), g[key]) <= 1e-4, (key, rel_err(got.numpy(), g[key]))
+                n += 1
+    assert n >= 50
+    from oracle.convops import xcorr_torch
+    D = Conv2D(("x", "y"), 2)
+    got = D.spectral_convolution(x4.to(gpu))
+    assert got.is_cuda and torch.allclose(got.cpu(), xcorr_torch(x4, D.kernel), atol=1e-4)
