@@ -231,50 +231,38 @@ __global__ void __launch_bounds__(1024) kth_kernel(const float *__restrict__ s, 
 // MSD radix select over [n, M] for ALL requested ranks at once: 9 + 6 + 6 + 6 + 5 bits = 5 sweeps
 // of the tile's data, ONE launch.  A 1024-thread workgroup owns 64 adjacent cells (256 B of every
 // sample row - narrower column tiles lose DRAM efficiency fast: 128 B -> 0.7x, 64 B -> 0.3x,
-// tools/exp/colread.hip): lane = cell, one wave = one row, so the 64 LDS atomics of a
-// wave-instruction never hit the same counter.  Counters are 16 bit (n < 65536), two cells per
-// word; histogram row r (= slot*bins + bin) is 32 words, rotated by r so that both the
-// cell-parallel updates and the bin-parallel scan spread over the banks.  Per cell there is one
-// histogram per *distinct* prefix among its ranks ("slot"; ranks ascend, so equal prefixes are
-// adjacent); the first sweep has one slot and spends the LDS on 512 bins.  80 KiB of LDS: two
-// workgroups per CU, one sweeps while the other zeroes / narrows.
-// State: wave w narrows cells w, w+16, w+32, w+48 in every pass, so their (prefix, residual rank)
-// stay in its registers (lane j <-> rank j); the new prefixes reach the other waves through the
-// (then idle) histogram memory.  For small n the tile (n * 256 B) stays L2-resident between
-// sweeps, so HBM sees it about once.
-constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16, KA_CPW = KA_W / KA_WAVES;
-constexpr int KA_HIST_WORDS = KA_MAXK * 64 * 32;          // 80 KiB; also >= 512 * 32 for the first sweep
+// tools/exp/colread.hip): lane = cell everywhere.
+//   sweep:  one wave = one row, so the 64 LDS atomics of a wave-instruction never hit the same
+//           counter.  Counters are 16 bit (n < 65536), two cells per word; histogram row r
+//           (= slot*bins + bin) is 32 words, rotated by r across the banks.  Per cell there is one
+//           histogram per *distinct* prefix among its ranks ("slot"; ranks ascend, so equal prefixes
+//           are adjacent); the first sweep has one slot and spends the LDS on 512 bins.
+//   narrow: thread (cell c = tid & 63, rank j = tid >> 6) owns the state (prefix, residual rank) of
+//           its pair in registers and walks the bins of its slot serially - 640 independent walks,
+//           no cross-lane traffic (the first sweep's 512 bins are pre-summed in 16 groups by all
+//           1024 threads).  New prefixes reach the sweeping waves through the idle histogram memory.
+// 80 KiB of LDS: two workgroups per CU (tools/exp/ldsocc.hip), one sweeps while the other narrows.
+// For small n the tile (n * 256 B) stays L2-resident between sweeps, so HBM sees it about once.
+constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16;
+constexpr int KA_HIST_WORDS = KA_MAXK * 64 * 32;          // 80 KiB; the first sweep uses 512*32 of them
+constexpr int KA_GROUPS_AT = 512 * 32;                    // 16 x 64 group sums of the first sweep live here
 struct KAList { int nk; int k[KA_MAXK]; };
 
 __device__ __forceinline__ int ka_word(int row, int half) { return row * 32 + ((half + row) & 31); }
 
-// Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (VALU only; the
-// __shfl_up form goes through ds_bpermute and made the narrowing step latency-bound).
-__device__ __forceinline__ unsigned int wave_incl_scan(unsigned int x)
-{
-    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
-    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
-    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
-    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
-    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
-    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
-    return x;
-}
-
-// One sweep + narrowing.  cp/cr: state of this wave's KA_CPW cells (lane j <-> rank j).
 template <int BITS, int SLOTS>
 __device__ __forceinline__ void ka_pass(const float *__restrict__ col, bool cok, int n, long long M, int nk, int shift,
-                                        unsigned int *hist, unsigned int (&cp)[KA_CPW], unsigned int (&cr)[KA_CPW],
-                                        long long c0, int lane, int wave, int tid)
+                                        unsigned int *hist, unsigned int &myp, unsigned int &myr, int lane, int wave, int tid)
 {
-    constexpr int NB = 1 << BITS, PER = (NB + 63) / 64;
+    constexpr int NB = 1 << BITS;
     const unsigned int mask = (shift + BITS == 32) ? 0u : ~0u << (shift + BITS);
+    const bool state = wave < nk;                 // this thread owns (cell = lane, rank = wave)
 
     // my cell's DISTINCT prefixes, compacted to the front (slot i = i-th distinct prefix); the
-    // sentinel 1 (low bit set) never equals a masked key.  lmax = most slots any cell of this wave
-    // has: the match loop runs to that wave-uniform bound instead of KA_MAXK.
+    // sentinel 1 (low bit set) never equals a masked key.  lmax = most slots any cell has: the
+    // match loop runs to that wave-uniform bound instead of KA_MAXK.  myslot = slot of my own rank.
     unsigned int pf[KA_MAXK];
-    int lmax = 1;
+    int lmax = 1, myslot = 0;
     if (SLOTS > 1) {
         // hist[j*64 + cell] holds the prefixes published by the previous narrowing
         unsigned int *scr = hist + 1024 + wave * (KA_MAXK * 64);
@@ -284,6 +272,7 @@ __device__ __forceinline__ void ka_pass(const float *__restrict__ col, bool cok,
         for (int j = 0; j < KA_MAXK; ++j) {
             const unsigned int p = j < nk ? hist[j * 64 + lane] : 0u;
             if (j < nk && (j == 0 || p != prev)) { scr[L * 64 + lane] = p; ++L; }
+            if (j == wave) myslot = L - 1;
             prev = p;
         }
 #pragma unroll
@@ -298,7 +287,7 @@ __device__ __forceinline__ void ka_pass(const float *__restrict__ col, bool cok,
     __syncthreads();
 
     const unsigned int inc = 1u << (16 * (lane & 1));
-    const int half = lane >> 1;
+    const int half = lane >> 1, sh16 = 16 * (lane & 1);
     auto count = [&](float v) __attribute__((always_inline)) {
         const unsigned int key = f2key(v);
         const int dig = (int)((key >> shift) & (NB - 1));
@@ -325,57 +314,43 @@ __device__ __forceinline__ void ka_pass(const float *__restrict__ col, bool cok,
     }
     __syncthreads();
 
-    // narrow: one wave per cell; lanes over bins (bin = u*64 + lane), ranks resolved slot by slot
-    const bool mine = lane < nk;
-#pragma unroll
-    for (int q = 0; q < KA_CPW; ++q) {
-        const int cc = wave + q * KA_WAVES;
-        if (c0 + cc >= M) break;
-        const unsigned int myp = cp[q], myr = cr[q];
-        const unsigned int upp = __shfl_up(myp, 1);
-        unsigned long long lead = __ballot(mine && (lane == 0 || myp != upp));
-        if (SLOTS == 1) lead = 1ull;
-        unsigned int newp = myp, newr = myr;
-        const int sh16 = 16 * (cc & 1), hcc = cc >> 1;
-        int slot = 0;
-        while (lead) {
-            const int sl = __ffsll((long long)lead) - 1;
-            lead &= lead - 1;
-            const int nxt = lead ? __ffsll((long long)lead) - 1 : nk;
-            unsigned int b[PER], incl[PER], carry = 0;
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int bin = u * 64 + lane;
-                b[u] = bin < NB ? (hist[ka_word(slot * NB + bin, hcc)] >> sh16) & 0xffffu : 0u;
-                incl[u] = wave_incl_scan(b[u]) + carry;
-                carry = (unsigned)__builtin_amdgcn_readlane((int)incl[u], 63);
+    // narrow: walk the bins of my slot for my cell until the running count passes my rank
+    auto cnt = [&](int row) __attribute__((always_inline)) { return (hist[ka_word(row, half)] >> sh16) & 0xffffu; };
+    int bin0 = 0, bin1 = NB;
+    unsigned int cum = 0;
+    if (SLOTS == 1) {
+        // 512 bins: 16 groups of 32 are summed by all 1024 threads first
+        unsigned int gs = 0;
+#pragma unroll 8
+        for (int u = 0; u < 32; ++u) gs += cnt(wave * 32 + u);
+        hist[KA_GROUPS_AT + wave * 64 + lane] = gs;
+        __syncthreads();
+        if (state) {
+            int g = 0;
+            for (; g < 15; ++g) {
+                const unsigned int x = hist[KA_GROUPS_AT + g * 64 + lane];
+                if (cum + x > myr) break;
+                cum += x;
             }
-            for (int j = sl; j < nxt; ++j) {
-                const unsigned int r = (unsigned)__builtin_amdgcn_readlane((int)myr, j);
-                unsigned int digit = NB - 1, before = 0;
-                bool found = false;
-#pragma unroll
-                for (int u = 0; u < PER; ++u) {
-                    const unsigned long long crossed = __ballot(incl[u] > r);
-                    if (!found && crossed) {
-                        const int win = __ffsll((long long)crossed) - 1;
-                        digit = (unsigned)(u * 64 + win);
-                        before = (unsigned)__builtin_amdgcn_readlane((int)(incl[u] - b[u]), win);
-                        found = true;
-                    }
-                }
-                if (lane == j) { newp = myp | (digit << shift); newr = r - before; }
-            }
-            ++slot;
+            bin0 = g * 32;
+            bin1 = bin0 + 32;
         }
-        cp[q] = newp;
-        cr[q] = newr;
     }
-    __syncthreads();                       // every wave is done reading the histograms
-    if (shift > 0 && mine) {               // publish the new prefixes for the next sweep's matching
-#pragma unroll
-        for (int q = 0; q < KA_CPW; ++q) hist[lane * 64 + wave + q * KA_WAVES] = cp[q];
+    if (state) {
+        unsigned int digit = (unsigned)(bin1 - 1), before = cum;
+        bool found = false;
+        const int base = (SLOTS == 1 ? 0 : myslot) * NB;
+#pragma unroll 8
+        for (int bin = bin0; bin < bin1; ++bin) {
+            const unsigned int h = cnt(base + bin);
+            if (!found && cum + h > myr) { digit = (unsigned)bin; before = cum; found = true; }
+            cum += h;
+        }
+        myp |= digit << shift;
+        myr -= before;
     }
+    __syncthreads();                       // everyone is done reading the histograms
+    if (shift > 0 && state) hist[wave * 64 + lane] = myp;     // publish for the next sweep's matching
     __syncthreads();
 }
 
@@ -389,23 +364,13 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_kernel(const float *__restr
     const bool cok = c < M;
     const float *col = s + c;
 
-    unsigned int cp[KA_CPW], cr[KA_CPW];
-#pragma unroll
-    for (int q = 0; q < KA_CPW; ++q) { cp[q] = 0u; cr[q] = lane < nk ? (unsigned)kl.k[lane] : 0u; }
-
-    ka_pass<9, 1>(col, cok, n, M, nk, 23, hist, cp, cr, c0, lane, wave, tid);
-    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 17, hist, cp, cr, c0, lane, wave, tid);
-    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 11, hist, cp, cr, c0, lane, wave, tid);
-    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 5, hist, cp, cr, c0, lane, wave, tid);
-    ka_pass<5, KA_MAXK>(col, cok, n, M, nk, 0, hist, cp, cr, c0, lane, wave, tid);
-
-    if (lane < nk) {
-#pragma unroll
-        for (int q = 0; q < KA_CPW; ++q) {
-            const long long cg = c0 + wave + q * KA_WAVES;
-            if (cg < M) out[(long long)lane * M + cg] = key2f(cp[q]);
-        }
-    }
+    unsigned int myp = 0u, myr = wave < nk ? (unsigned)kl.k[wave] : 0u;
+    ka_pass<9, 1>(col, cok, n, M, nk, 23, hist, myp, myr, lane, wave, tid);
+    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 17, hist, myp, myr, lane, wave, tid);
+    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 11, hist, myp, myr, lane, wave, tid);
+    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 5, hist, myp, myr, lane, wave, tid);
+    ka_pass<5, KA_MAXK>(col, cok, n, M, nk, 0, hist, myp, myr, lane, wave, tid);
+    if (wave < nk && cok) out[(long long)wave * M + c] = key2f(myp);
 }
 
 // ------------------------------------------------------------------ coverage
