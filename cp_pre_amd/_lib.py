@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_ulonglong, c_void_p
+from ctypes import POINTER, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 import torch  # imported first on purpose: the .so must bind to the HIP runtime torch already loaded
 

@@ -21,7 +21,6 @@ from __future__ import annotations
 
 import ctypes
 
-import numpy as np
 import torch
 
 from . import _dispatch, _lib

@@ -2,7 +2,7 @@
 """Per-kernel timings on the MI355X (HIP events on torch's current stream).
     python tools/microbench.py [eval] [calib] [select]
 Prints algorithmic GB/s per kernel; used to steer optimisation, not a contract output."""
-import sys, os, json
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cp_pre_amd import _lib, inductive_cp as icp, pipeline
