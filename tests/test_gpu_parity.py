@@ -790,3 +790,42 @@ def test_spectral_family_matches_reference_golden(gpu):
     D = Conv2D(("x", "y"), 2)
     got = D.spectral_convolution(x4.to(gpu))
     assert got.is_cuda and torch.allclose(got.cpu(), xcorr_torch(x4, D.kernel), atol=1e-4)
+
+
+def test_full_size_properties_c2(gpu):
+    """BASELINE config 2 at its full size [512,32,256,256] (too big for the CPU oracle in a test):
+    size-independent properties - linearity of the additive wave kernel, |.| idempotence, per-cell
+    q-hat non-increasing in alpha and an input value, conformal guarantee on the calibration set
+    (at least ceil((n+1)(1-alpha)) of n calibration scores lie within q-hat) for marginal and joint CP."""
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd.residuals import PRE_Wave
+    B, T, X, Y = 512, 32, 256, 256
+    g = torch.Generator(device=gpu).manual_seed(3)
+    u1 = torch.randn(B, T, X, Y, device=gpu, generator=g)
+    u2 = torch.randn(B, T, X, Y, device=gpu, generator=g)
+    w = PRE_Wave(dt=0.005, dx=0.01, c=1.0)
+    r1, r2 = w.residual(u1, boundary=True), w.residual(u2, boundary=True)
+    lin = w.residual(0.75 * u1 - 1.25 * u2, boundary=True)
+    assert (lin - (0.75 * r1 - 1.25 * r2)).abs().max().item() <= 1e-5 * lin.abs().max().item()
+    a1 = w.residual(u1, boundary=True, absolute=True)
+    assert torch.equal(a1, r1.abs()) and torch.equal(a1.abs(), a1)
+    del u2, r2, lin
+    n = B
+    alphas = [float(a) for a in icp.ALPHA_LEVELS]
+    q = icp.calibrate_multi(a1, n, alphas)                                  # [10, T, X, Y]
+    assert (q[:-1] >= q[1:]).all()                                          # alpha ascending -> q-hat non-increasing
+    for j, a in enumerate(alphas):
+        k = icp.kth_index(n, n, a)
+        inside = (a1 <= q[j]).sum(0)
+        assert int(inside.min()) >= k + 1                                   # q-hat is the (k+1)-th smallest score
+    cell = a1[:, 7, 100, 33].contiguous()
+    assert torch.equal(q[:, 7, 100, 33], torch.sort(cell).values[[icp.kth_index(n, n, a) for a in alphas]])
+    # joint recipe on the same residuals
+    mod = icp.modulation_func(r1, None)
+    sc = icp.ncf_metric_joint(r1, None, mod, crop=1)
+    qj = icp.calibrate_multi(sc, n, alphas)
+    assert (qj[:-1] >= qj[1:]).all()
+    inner = r1[:, 1:-1, 1:-1, 1:-1]
+    for j in (0, 4, 9):
+        cov = icp.emp_cov_joint([-(qj[j] * mod)[1:-1, 1:-1, 1:-1], (qj[j] * mod)[1:-1, 1:-1, 1:-1]], inner)
+        assert cov >= (icp.kth_index(n, n, alphas[j]) + 1) / n - 2.0 / n    # knife-edge samples sit exactly on the bound
