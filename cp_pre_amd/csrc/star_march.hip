@@ -29,6 +29,8 @@ struct Geom {
     float *out;
     long long oB, oT, oX;        // output strides (elements); the marched-to axis is contiguous
     int B, T, X, Y;
+    int Yc;                      // columns computed by the streaming kernel: Y rounded down to a multiple of 4
+                                 // (the <= 3 remaining columns of an odd-width grid go to the generic kernel)
     int tSeg, nTSeg, nXT, nYT;
     int flags;
 };
@@ -212,7 +214,16 @@ struct MHDInduction {  // Marginal/MHD_Residuals_CP.py:259-268   fields u,v,Bx,B
 };
 
 // ------------------------------------------------------------------ the marching kernel
-__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// Global float4 accesses are declared 4-byte aligned: gfx950 runs with unaligned access enabled and
+// the compiler still emits one global_load/store_dwordx4, so views whose base or row pitch is not a
+// multiple of 16 bytes (odd grid widths, offset slices) stream through the same kernel.
+struct __attribute__((aligned(4))) F4u { float x, y, z, w; };
+__device__ __forceinline__ float4 ldg4(const float *p)
+{
+    const F4u v = *reinterpret_cast<const F4u *>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stg4(float *p, const float4 &r) { *reinterpret_cast<F4u *>(p) = F4u{r.x, r.y, r.z, r.w}; }
 
 // Barrier that orders LDS traffic only: __syncthreads() would also drain vmcnt and with it
 // the global prefetches that are meant to stay in flight across the barrier.
@@ -249,14 +260,14 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
     const int b = L / g.nTSeg;
 
     const int x = xt * NR + ty, y = (yt * TYQ + q) * 4;
-    const bool inb = (x < g.X) && (y < g.Y);
+    const bool inb = (x < g.X) && (y < g.Yc);
     // BC: the row just below the domain (x == X, only in a partial last tile) is a ghost row that
     // feeds the x+ neighbour of row X-1; it loads its mapped row and never stores
     int xl = x;                 // row this thread loads as its "own"
     float ghost = 0.f;
     bool ldown = inb;
     if constexpr (BC) {
-        if (x == g.X && y < g.Y) { xl = bc.xhi; ghost = bc.vxhi; ldown = bc.xhi >= 0; }
+        if (x == g.X && y < g.Yc) { xl = bc.xhi; ghost = bc.vxhi; ldown = bc.xhi >= 0; }
     }
     int t0 = ts * g.tSeg;
     int t1 = min(t0 + g.tSeg, g.T);
@@ -268,18 +279,20 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
     // halo-row duty: thread-row 0 fetches the row above the tile, thread-row NR-1 the row below
     const bool top = (ty == 0), bot = (ty == NR - 1);
     int hx = top ? x - 1 : x + 1;
-    bool hrow = (top || bot) && (hx >= 0) && (hx < g.X) && (y < g.Y);
+    bool hrow = (top || bot) && (hx >= 0) && (hx < g.X) && (y < g.Yc);
     float hfill = 0.f;          // value of an out-of-domain halo row
     const int hslot = top ? 0 : NR + 1;
     // y-halo duty: the edge lanes of each wave (and of the tile) fetch one scalar
     const bool ledge = ((q & 63) == 0);
-    bool redge = ((q & 63) == 63) || (q == TYQ - 1);
+    // (the last computed float4 of a row is an edge too: beyond it lie either the domain end or the
+    // <= 3 columns of an odd-width grid that this kernel leaves to the generic one)
+    bool redge = ((q & 63) == 63) || (q == TYQ - 1) || (y + 4 >= g.Yc);
     bool lload = ledge && inb && (y > 0);
     bool rload = redge && inb && (y + 4 < g.Y);
     int yloff = -1, yroff = 4;  // element offsets of the y- / y+ scalar relative to the own float4
     float ylfill = 0.f, yrfill = 0.f;
     if constexpr (BC) {
-        if ((top || bot) && y < g.Y && (hx == -1 || hx == g.X)) {
+        if ((top || bot) && y < g.Yc && (hx == -1 || hx == g.X)) {
             const int m = hx < 0 ? bc.xlo : bc.xhi;
             hfill = hx < 0 ? bc.vxlo : bc.vxhi;
             hrow = m >= 0;
@@ -350,8 +363,7 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
         float4 r = Fn::eval(n, prm);
         if (g.flags & PRE_FLAG_ABS) r = fabs4(r);
         if (inb) {
-            float4 *dst = reinterpret_cast<float4 *>(outp + (long long)t * oT);
-            *dst = r;
+            stg4(outp + (long long)t * oT, r);
         }
     };
 
@@ -411,7 +423,7 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const 
     static_assert(2 * Fn::F * (NR + 2) * TYQ * 16 <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     {
     g.nXT = (g.X + NR - 1) / NR;
-    g.nYT = (g.Y + 4 * TYQ - 1) / (4 * TYQ);
+    g.nYT = (g.Yc + 4 * TYQ - 1) / (4 * TYQ);
     // split long T axes so the grid fills the chip (>= ~4 workgroups per CU) without
     // paying the 2-plane window prologue too often
     long long tiles = (long long)g.B * g.nXT * g.nYT;
@@ -452,7 +464,7 @@ int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st, const BCInfo
 // arithmetic is unchanged - zero-copy for the layouts real callers hand in.  Returns
 // PRE_E_UNSUPPORTED when no common unit-stride axis / alignment exists.
 int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const pre_out_t *out,
-            int64_t B, int64_t T, int64_t X, int64_t Y, int flags, Star *const *stars, int nstars)
+            int64_t B, int64_t T, int64_t X, int64_t Y, int flags, Star *const *stars, int nstars, bool relaxed = false)
 {
     if (!out || !out->ptr || B <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
     if (B > 0x7fffffff || T > 0x7fffffff || X > 0x7fffffff || Y > 0x7fffffff) return PRE_E_SHAPE;
@@ -473,9 +485,11 @@ int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const
     else if (all_unit(1)) { p[0] = 0; p[1] = 2; p[2] = 1; }
     else return PRE_E_UNSUPPORTED;
     relabeled = p[2] == 2 ? 0 : (p[2] == 0 ? 1 : 2);      // 0 identity, 1 kernel axes (X,Y,T), 2 kernel axes (T,Y,X)
-    if (D[p[2]] % 4 != 0) return PRE_E_UNSUPPORTED;
-    auto aligned = [](const void *ptr, int64_t a, int64_t b2, int64_t c) {
-        return !(((uintptr_t)ptr) & 15) && a % 4 == 0 && b2 % 4 == 0 && c % 4 == 0;
+    // relaxed (single-field linear operators): any contiguous extent >= 4 (the last extent % 4 columns are
+    // left to the caller) and any 4-byte alignment; fused multi-field kernels keep the strict layout
+    if (relaxed ? D[p[2]] < 4 : D[p[2]] % 4 != 0) return PRE_E_UNSUPPORTED;
+    auto aligned = [relaxed](const void *ptr, int64_t a, int64_t b2, int64_t c) {
+        return relaxed || (!(((uintptr_t)ptr) & 15) && a % 4 == 0 && b2 % 4 == 0 && c % 4 == 0);
     };
     if (!aligned(out->ptr, out->sB, ostride(p[0]), ostride(p[1]))) return PRE_E_UNSUPPORTED;
     for (int i = 0; i < nf; ++i) {
@@ -485,6 +499,7 @@ int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const
     for (int i = nf; i < MAXF; ++i) { g.f[i] = nullptr; g.sB[i] = g.sT[i] = g.sX[i] = 0; }
     g.out = out->ptr; g.oB = out->sB; g.oT = ostride(p[0]); g.oX = ostride(p[1]);
     g.B = (int)B; g.T = (int)D[p[0]]; g.X = (int)D[p[1]]; g.Y = (int)D[p[2]];
+    g.Yc = g.Y & ~3;
     g.flags = relabeled ? (flags & ~PRE_FLAG_INTERIOR_T) : flags;     // the skipped rim is on the LOGICAL t axis
     if (relabeled)
         for (int k = 0; k < nstars; ++k) {
@@ -514,8 +529,12 @@ int launch_mode(int mode, Geom &g, const P &prm, hipStream_t st)
 }  // namespace
 
 // Internal: called by stencil_generic.hip when a tap list is star-shaped and the layout allows it.
+// On success *tail_axis / *tail_from describe the columns the streaming kernel did NOT compute (the last
+// extent % 4 cells of the contiguous axis, given as the caller's axis 0=T,1=X,2=Y and first index), or
+// *tail_axis = -1 if everything was computed.
 int pre_star_try_linear1(const pre_field_t *in, const pre_out_t *out, const float star7[7],
-                         int64_t B, int64_t T, int64_t X, int64_t Y, int flags, hipStream_t st)
+                         int64_t B, int64_t T, int64_t X, int64_t Y, int flags, hipStream_t st,
+                         int *tail_axis, int64_t *tail_from)
 {
     const pre_field_t *fs[1] = {in};
     Linear1::Params p;
@@ -523,8 +542,14 @@ int pre_star_try_linear1(const pre_field_t *in, const pre_out_t *out, const floa
     Star *stars[1] = {&p.s};
     Geom g;
     int rel;
-    int rc = prepare(g, rel, fs, 1, out, B, T, X, Y, flags, stars, 1);
+    int rc = prepare(g, rel, fs, 1, out, B, T, X, Y, flags, stars, 1, true);
     if (rc) return rc;
+    *tail_axis = -1;
+    if (g.Yc < g.Y) {
+        *tail_axis = rel == 0 ? 2 : (rel == 1 ? 0 : 1);
+        *tail_from = g.Yc;
+        g.flags &= ~PRE_FLAG_INTERIOR_T;           // keep it simple: the tail pass computes every plane
+    }
     return launch<Linear1>(g, p, st);
 }
 

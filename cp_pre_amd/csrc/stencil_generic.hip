@@ -2,15 +2,16 @@
 // (any stride, any odd kernel extent up to 7) tap-list kernel.
 //
 // pre_stencil3d_f32 first offers the tap list to the streaming star kernel
-// (star_march.hip); tap sets that are not on the 7-point star, views that are not
-// y-contiguous / 16-byte aligned, and rows whose length is not a multiple of 4 run here:
+// (star_march.hip); tap sets that are not on the 7-point star, views without a unit-stride
+// axis, and the last (extent % 4) columns of an odd-width grid run here:
 // one thread per output cell, coalesced along y, neighbours served by L1/L2.  It is the
 // correctness floor of the library (5^3 / 7^3 Taylor kernels, permuted views, odd sizes);
 // it is not on the benchmarked path.
 #include "common.h"
 
 int pre_star_try_linear1(const pre_field_t *in, const pre_out_t *out, const float star7[7],
-                         int64_t B, int64_t T, int64_t X, int64_t Y, int flags, hipStream_t st);
+                         int64_t B, int64_t T, int64_t X, int64_t Y, int flags, hipStream_t st,
+                         int *tail_axis, int64_t *tail_from);
 
 namespace {
 
@@ -25,16 +26,19 @@ struct TapList {
 __global__ void __launch_bounds__(256) generic_kernel(const float *__restrict__ in, long long sB, long long sT,
                                                       long long sX, long long sY, float *__restrict__ out,
                                                       long long oB, long long oT, long long oX, long long oY,
-                                                      int B, int T, int X, int Y, int flags, const TapList taps)
+                                                      int B, int T, int X, int Y, int t0, int x0, int y0,
+                                                      int flags, const TapList taps)
 {
-    const long long plane = (long long)X * Y;
-    const long long total = (long long)B * T * plane;
+    // outputs: the sub-box [t0,T) x [x0,X) x [y0,Y) (all of it for t0=x0=y0=0); taps see the whole domain
+    const int nT = T - t0, nX = X - x0, nY = Y - y0;
+    const long long plane = (long long)nX * nY;
+    const long long total = (long long)B * nT * plane;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(idx % Y);
-        const int x = (int)((idx / Y) % X);
-        const int t = (int)((idx / plane) % T);
-        const int b = (int)(idx / (plane * T));
+        const int y = y0 + (int)(idx % nY);
+        const int x = x0 + (int)((idx / nY) % nX);
+        const int t = t0 + (int)((idx / plane) % nT);
+        const int b = (int)(idx / (plane * nT));
         const float *base = in + b * sB;
         float acc = 0.f;
         for (int i = 0; i < taps.n; ++i) {
@@ -73,9 +77,15 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *
         const int slot = dt ? (dt < 0 ? 1 : 2) : dx ? (dx < 0 ? 3 : 4) : dy ? (dy < 0 ? 5 : 6) : 0;
         s7[slot] += tap_w[i];
     }
+    int box[3] = {0, 0, 0};                       // first (t, x, y) the generic kernel has to compute
     if (star) {
-        int rc = pre_star_try_linear1(in, out, s7, B, T, X, Y, flags, st);
-        if (rc != PRE_E_UNSUPPORTED) return rc;
+        int tail_axis = -1;
+        int64_t tail_from = 0;
+        int rc = pre_star_try_linear1(in, out, s7, B, T, X, Y, flags, st, &tail_axis, &tail_from);
+        if (rc != PRE_E_UNSUPPORTED) {
+            if (rc != PRE_OK || tail_axis < 0) return rc;
+            box[tail_axis] = (int)tail_from;       // streaming kernel done; <= 3 leftover columns follow
+        }
     }
 
     TapList taps;
@@ -84,12 +94,13 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *
         taps.w[i] = tap_w[i];
         taps.off[i] = (tap_off[3 * i] + 8) | ((tap_off[3 * i + 1] + 8) << 4) | ((tap_off[3 * i + 2] + 8) << 8);
     }
-    const long long total = (long long)B * T * X * Y;
+    const long long total = (long long)B * (T - box[0]) * (X - box[1]) * (Y - box[2]);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in->ptr, (long long)in->sB,
                        (long long)in->sT, (long long)in->sX, (long long)in->sY, out->ptr, (long long)out->sB,
-                       (long long)out->sT, (long long)out->sX, (long long)out->sY, (int)B, (int)T, (int)X, (int)Y, flags, taps);
+                       (long long)out->sT, (long long)out->sX, (long long)out->sY, (int)B, (int)T, (int)X, (int)Y, box[0], box[1],
+                       box[2], flags, taps);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }

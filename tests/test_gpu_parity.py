@@ -368,7 +368,8 @@ def test_edge_shapes_and_layouts(gpu):
     L = C2(("x", "y"), 2)
     Dt = C2("t", 2)
     assert L(torch.empty(0, 3, 4, 8, device=gpu)).shape == (0, 3, 4, 8)
-    for shape in [(1, 1, 1, 4), (2, 1, 1, 1), (1, 3, 1, 8), (1, 2, 5, 1), (2, 3, 4, 7), (1, 1, 1, 1024), (1, 2, 1030, 4)]:
+    for shape in [(1, 1, 1, 4), (2, 1, 1, 1), (1, 3, 1, 8), (1, 2, 5, 1), (2, 3, 4, 7), (1, 1, 1, 1024), (1, 2, 1030, 4),
+                  (2, 4, 9, 101), (1, 3, 20, 1030), (2, 2, 33, 510), (3, 5, 6, 5)]:       # odd widths: streaming + <=3 tail columns
         x = torch.randn(*shape, generator=g)
         for D in (L, Dt):
             got = D(x.to(gpu)).cpu().numpy()

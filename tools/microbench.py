@@ -51,6 +51,13 @@ def bench_eval():
     report(f"burgers [{B},{T},{X}] 8B/cell", timeit(lambda: bur.residual(u, True)), 8 * B * T * X)
     adv = R.Advection(1.0, 0.005, 0.01)
     report(f"advection additive kernel [{B},{T},{X}] 8B/cell", timeit(lambda: adv.residual(u, True)), 8 * B * T * X)
+    L = ConvOperator(("x", "y"), 2)
+    for (B, T, X, Y) in [(256, 10, 510, 510), (256, 10, 201, 201)]:
+        xo = torch.randn(B, T, X, Y, device=dev)
+        report(f"laplacian, odd width [{B},{T},{X},{Y}] 8B/cell (unaligned rows + tail cols)", timeit(lambda: L(xo)), 8 * xo.numel())
+        crop = torch.randn(B, T, X + 2, Y + 2, device=dev)[..., 1:-1, 1:-1]
+        report(f"laplacian on a cropped view [{B},{T},{X},{Y}] 8B/cell", timeit(lambda: L(crop)), 8 * crop.numel())
+        del xo, crop
     D = ConvOperator(("x", "y"), 2, taylor_order=4)
     x = torch.randn(64, 10, 512, 512, device=dev)
     report("generic kernel 5^3 taylor-4 [64,10,512,512] 8B/cell", timeit(lambda: D(x)), 8 * x.numel())
