@@ -486,14 +486,10 @@ int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const
     else return PRE_E_UNSUPPORTED;
     relabeled = p[2] == 2 ? 0 : (p[2] == 0 ? 1 : 2);      // 0 identity, 1 kernel axes (X,Y,T), 2 kernel axes (T,Y,X)
     // relaxed (single-field linear operators): any contiguous extent >= 4 (the last extent % 4 columns are
-    // left to the caller) and any 4-byte alignment; fused multi-field kernels keep the strict layout
+    // left to the caller); fused multi-field kernels need extent % 4 == 0.  No alignment requirement
+    // beyond the 4 bytes of a float: the float4 accesses are unaligned-capable (F4u).
     if (relaxed ? D[p[2]] < 4 : D[p[2]] % 4 != 0) return PRE_E_UNSUPPORTED;
-    auto aligned = [relaxed](const void *ptr, int64_t a, int64_t b2, int64_t c) {
-        return relaxed || (!(((uintptr_t)ptr) & 15) && a % 4 == 0 && b2 % 4 == 0 && c % 4 == 0);
-    };
-    if (!aligned(out->ptr, out->sB, ostride(p[0]), ostride(p[1]))) return PRE_E_UNSUPPORTED;
     for (int i = 0; i < nf; ++i) {
-        if (!aligned(fs[i]->ptr, fs[i]->sB, stride(fs[i], p[0]), stride(fs[i], p[1]))) return PRE_E_UNSUPPORTED;
         g.f[i] = fs[i]->ptr; g.sB[i] = fs[i]->sB; g.sT[i] = stride(fs[i], p[0]); g.sX[i] = stride(fs[i], p[1]);
     }
     for (int i = nf; i < MAXF; ++i) { g.f[i] = nullptr; g.sB[i] = g.sT[i] = g.sX[i] = 0; }

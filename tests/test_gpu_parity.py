@@ -105,6 +105,13 @@ def test_strided_views_and_dense_kernels_vs_oracle(gpu):
     Dd.kernel = dense
     x = torch.randn(2, 5, 9, 16, generator=g)
     assert rel_err(Dd(x.to(gpu)).cpu().numpy(), xcorr_c(x.numpy(), dense.numpy())) <= RES_TOL
+    # fused residual on views whose base is 4 bytes off a 16-byte boundary (a sliced vars tensor)
+    from cp_pre_amd.residuals import NavierStokes
+    from oracle import residuals as orr
+    wide = torch.rand(3, 3, 6, 10, 70, generator=g) + 0.5
+    sl = wide[..., 1:65]
+    got = NavierStokes(0.01, 0.1, 0.1).residual_momentum(wide.to(gpu)[..., 1:65], boundary=True)
+    assert rel_err(got.cpu().numpy(), orr.ns_momentum(sl, 0.01, 0.1, 0.1, boundary=True).numpy()) <= RES_TOL
     # convolution(field, kernel) replaces the operator's kernel (Utils/ConvOps_2d.py:146-147)
     Dd.convolution(x.to(gpu), D.kernel)
     assert Dd.kernel is D.kernel
