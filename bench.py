@@ -223,7 +223,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("PRE_BENCH_FORCE_GROUP") == "1":     # the latter: RCCL at world size 1 (plumbing check)
         import torch.distributed as dist
         if rehearse:
             dist.init_process_group("gloo")

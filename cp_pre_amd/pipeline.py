@@ -139,11 +139,14 @@ class JointCalibration:
         return self.ops.kth(scores, _ranks(self.n_total, alphas))
 
 
-def marginal_qhat(scores, alphas, group=None, ops=None):
+def marginal_qhat(scores, alphas, group=None, ops=None, stage_bytes=8 << 30):
     """Per-cell q-hat [len(alphas), *cells] of |residual| scores [n_local, *cells].
 
     Single rank: one multi-rank radix select.  Sharded: all-to-all (batch-sharded ->
-    cell-sharded), local select over all ``n_local * world`` samples, all-gather of the result."""
+    cell-sharded), local select over all ``n_local * world`` samples, all-gather of the result.
+    The exchange runs over runs of cells sized so that the send and the receive staging buffers
+    hold at most ``stage_bytes`` each (a C3 slab of scores is 43 GB; staging it whole twice next to
+    the fields would not fit in HBM)."""
     ops = ops or HipOps
     n_local, cells = scores.shape[0], tuple(scores.shape[1:])
     if group is None:
@@ -151,16 +154,24 @@ def marginal_qhat(scores, alphas, group=None, ops=None):
     world = torch.distributed.get_world_size(group)
     flat = scores.reshape(n_local, -1)
     M = flat.shape[1]
-    per = (M + world - 1) // world
-    send = flat.new_zeros(world, n_local, per)
-    for r in range(world):                                   # rank r will own cells [r*per, (r+1)*per)
-        w = max(0, min(per, M - r * per))
-        send[r, :, :w] = flat[:, r * per:r * per + w]
+    ks = _ranks(n_local * world, alphas)
+    per = max(1, min((M + world - 1) // world, int(stage_bytes) // (4 * n_local * world)))   # cells per rank per run
+    run = per * world
+    q = flat.new_empty(len(alphas), M)
+    send = flat.new_empty(world, n_local, per)
     recv = torch.empty_like(send)
-    torch.distributed.all_to_all_single(recv, send, group=group)          # RCCL: 7/8 of the local scores leave
-    mine = recv.reshape(world * n_local, per)                # every sample of my cells
-    q_local = ops.kth(mine, _ranks(n_local * world, alphas))              # [nk, per]
-    parts = [torch.empty_like(q_local) for _ in range(world)]
-    torch.distributed.all_gather(parts, q_local.contiguous(), group=group)
-    q = torch.cat(parts, dim=1)[:, :M]
+    parts = [flat.new_empty(len(alphas), per) for _ in range(world)]
+    for c0 in range(0, M, run):
+        w = min(run, M - c0)
+        if w == run:                                           # rank r will own cells [c0 + r*per, c0 + (r+1)*per)
+            send.copy_(flat[:, c0:c0 + run].reshape(n_local, world, per).permute(1, 0, 2))
+        else:                                                  # ragged last run: pad with zeros, dropped below
+            send.zero_()
+            for r in range(world):
+                wr = max(0, min(per, w - r * per))
+                send[r, :, :wr] = flat[:, c0 + r * per:c0 + r * per + wr]
+        torch.distributed.all_to_all_single(recv, send, group=group)      # RCCL: (world-1)/world of the run leaves
+        q_local = ops.kth(recv.reshape(world * n_local, per), ks)         # every sample of my cells: [nk, per]
+        torch.distributed.all_gather(parts, q_local.contiguous(), group=group)
+        q[:, c0:c0 + w] = torch.cat(parts, dim=1)[:, :w]
     return q.reshape((len(alphas),) + cells)

@@ -72,6 +72,10 @@ def _worker(rank, world, port, n_local, shape, slabs, out_dir):
             jc.add_slab(mine[:, s * step:s * step + step + 2].contiguous(), crop=(1, 1, 1))
         q = jc.finish(ALPHAS)
         qm = pipeline.marginal_qhat(mine.abs().contiguous(), ALPHAS, group=dist.group.WORLD, ops=CpuOps)
+        # bounded staging: 100 cells per rank per exchange -> 3 full runs and a ragged one (170 of 200 cells)
+        qm_runs = pipeline.marginal_qhat(mine.abs().contiguous(), ALPHAS, group=dist.group.WORLD, ops=CpuOps,
+                                         stage_bytes=4 * n_local * world * 100)
+        assert torch.equal(qm_runs, qm)
         np.save(os.path.join(out_dir, f"q_{rank}.npy"), q.numpy())
         np.save(os.path.join(out_dir, f"scores_{rank}.npy"), jc.all_scores.numpy())
         np.save(os.path.join(out_dir, f"mod_{rank}.npy"), torch.cat([m[1:-1] for m in jc.modulation]).numpy())
