@@ -4,9 +4,12 @@
 // pre_stencil3d_f32 first offers the tap list to the streaming star kernel
 // (star_march.hip); tap sets that are not on the 7-point star, views without a unit-stride
 // axis, and the last (extent % 4) columns of an odd-width grid run here:
-// one thread per output cell, coalesced along y, neighbours served by L1/L2.  It is the
-// correctness floor of the library (5^3 / 7^3 Taylor kernels, permuted views, odd sizes);
-// it is not on the benchmarked path.
+// Two forms:
+//   generic_tile_kernel  views with a unit-stride axis (relabelled to be the last one): 16 x 256 output
+//                        tiles, each needed input plane staged once in LDS, taps grouped by row;
+//   generic_kernel       anything else (and sub-box tails): one thread per cell, neighbours via L2.
+// It is the correctness floor of the library (5^3 / 7^3 Taylor kernels, padded additive kernels,
+// fully strided views, odd sizes); it is not on the benchmarked path.
 #include "common.h"
 
 int pre_star_try_linear1(const pre_field_t *in, const pre_out_t *out, const float star7[7],
@@ -23,22 +26,21 @@ struct TapList {
     int off[MAX_TAPS];          // (dt+8) | (dx+8)<<4 | (dy+8)<<8
 };
 
+// Thread map of both kernels (no 64-bit divisions): a block is 2^wsh columns wide and 256 >> wsh rows tall;
+// blockIdx.x walks the (column-strip, row-group) tiles of a plane, blockIdx.y the planes, blockIdx.z the batch.
 __global__ void __launch_bounds__(256) generic_kernel(const float *__restrict__ in, long long sB, long long sT,
                                                       long long sX, long long sY, float *__restrict__ out,
                                                       long long oB, long long oT, long long oX, long long oY,
                                                       int B, int T, int X, int Y, int t0, int x0, int y0,
-                                                      int flags, const TapList taps)
+                                                      int wsh, int nstrips, int flags, const TapList taps)
 {
     // outputs: the sub-box [t0,T) x [x0,X) x [y0,Y) (all of it for t0=x0=y0=0); taps see the whole domain
-    const int nT = T - t0, nX = X - x0, nY = Y - y0;
-    const long long plane = (long long)nX * nY;
-    const long long total = (long long)B * nT * plane;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int y = y0 + (int)(idx % nY);
-        const int x = x0 + (int)((idx / nY) % nX);
-        const int t = t0 + (int)((idx / plane) % nT);
-        const int b = (int)(idx / (plane * nT));
+    const int strip = blockIdx.x % nstrips, rowgrp = blockIdx.x / nstrips;
+    const int y = y0 + (strip << wsh) + (threadIdx.x & ((1 << wsh) - 1));
+    const int x = x0 + rowgrp * (256 >> wsh) + (threadIdx.x >> wsh);
+    if (y >= Y || x >= X) return;
+    for (int b = blockIdx.z; b < B; b += gridDim.z)
+    for (int t = t0 + blockIdx.y; t < T; t += gridDim.y) {
         const float *base = in + b * sB;
         float acc = 0.f;
         for (int i = 0; i < taps.n; ++i) {
@@ -48,6 +50,101 @@ __global__ void __launch_bounds__(256) generic_kernel(const float *__restrict__ 
                 acc += taps.w[i] * base[tt * sT + xx * sX + yy * sY];
         }
         out[b * oB + t * oT + x * oX + y * oY] = (flags & PRE_FLAG_ABS) ? fabsf(acc) : acc;
+    }
+}
+
+// ---- LDS-tiled form: views with a unit-stride axis (relabelled to be the last one) ------------------------
+// The vector L1 does not merge requests to lines that are still in flight and is far smaller than the
+// footprint of the resident waves, so every per-tap global load is an L2 request: a one-load-per-tap kernel
+// runs at (L2 rate) / ntaps however the loads are shaped (measured: 0.45 ms per tap on 671 Mcells, aligned or
+// not).  Here a block stages each input plane it needs ONCE in LDS (16 x 256 outputs + the reach of the tap
+// set, zero-filled outside the domain = the zero padding of F.conv3d) and the taps read LDS: grouped by
+// (dt, dx) row, one aligned ds_read_b128 under the thread's 4 cells plus the quads left / right of it when
+// the row has dy < 0 / dy > 0 taps, shifted in registers.
+constexpr int MAX_ROWS = 49;             // 7 * 7
+constexpr int TILE_R = 16, TILE_C = 256;
+constexpr int LDS_R = TILE_R + 6, LDS_Q = TILE_C / 4 + 2;     // +-3 rows, one quad left and right
+
+struct RowList {
+    int n;
+    int lo, hi;                 // reach of the tap set along the row (dx) axis
+    int off[MAX_ROWS];          // sorted by (dt, dx): (dt+8) | (dx+8)<<4 | mask<<8, mask bit k: dy = k-3 present
+    float w[MAX_ROWS][7];       // dy = -3..3
+};
+
+struct __attribute__((aligned(4))) G4u { float x, y, z, w; };
+
+__global__ void __launch_bounds__(256) generic_tile_kernel(const float *__restrict__ in, long long sB, long long sT,
+                                                           long long sX, float *__restrict__ out, long long oB,
+                                                           long long oT, long long oX, int B, int T, int X, int Y,
+                                                           int nstrips, int flags, const RowList rows)
+{
+    __shared__ float4 tile[LDS_R][LDS_Q];
+    const int strip = blockIdx.x % nstrips, rowgrp = blockIdx.x / nstrips;
+    const int x0 = rowgrp * TILE_R, y0 = strip * TILE_C;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nload = (TILE_R + rows.hi - rows.lo) * LDS_Q;      // quads of the tile the tap set can touch
+    for (int b = blockIdx.z; b < B; b += gridDim.z)
+    for (int t = blockIdx.y; t < T; t += gridDim.y) {
+        const float *base = in + b * sB;
+        float a[4][4] = {};
+        int staged = 99;                                          // dt of the plane now in LDS
+        for (int i = 0; i < rows.n; ++i) {
+            const int of = rows.off[i];
+            const int dt = (of & 15) - 8, dx = ((of >> 4) & 15) - 8, mask = of >> 8;
+            if (t + dt < 0 || t + dt >= T) continue;              // whole plane is padding
+            if (dt != staged) {
+                staged = dt;
+                __syncthreads();                                  // readers of the previous plane are done
+                const float *pl = base + (t + dt) * sT;
+                for (int q = threadIdx.x; q < nload; q += 256) {
+                    const int rr = q / LDS_Q + 3 + rows.lo, qc = q % LDS_Q;
+                    const int gx = x0 + rr - 3, gy = y0 + 4 * qc - 4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gx >= 0 && gx < X) {
+                        const float *src = pl + gx * sX + gy;
+                        if (gy >= 0 && gy + 3 < Y) {
+                            const G4u u = *reinterpret_cast<const G4u *>(src);
+                            v = make_float4(u.x, u.y, u.z, u.w);
+                        } else {
+                            if (gy >= 0 && gy < Y) v.x = src[0];
+                            if (gy + 1 >= 0 && gy + 1 < Y) v.y = src[1];
+                            if (gy + 2 >= 0 && gy + 2 < Y) v.z = src[2];
+                            if (gy + 3 >= 0 && gy + 3 < Y) v.w = src[3];
+                        }
+                    }
+                    tile[rr][qc] = v;
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                         // my rows: wv, wv+4, wv+8, wv+12
+                const float4 *row = tile[wv + 4 * k + dx + 3];
+                const float4 C = row[lane + 1];
+                float4 L = make_float4(0.f, 0.f, 0.f, 0.f), R = L;
+                if (mask & 0x07) L = row[lane];
+                if (mask & 0x70) R = row[lane + 2];
+                const float e[12] = {L.x, L.y, L.z, L.w, C.x, C.y, C.z, C.w, R.x, R.y, R.z, R.w};
+#pragma unroll
+                for (int d = 0; d < 7; ++d)                       // dy = d - 3, ascending: the dense kernel's tap order
+                    if (mask & (1 << d)) {                        // wave-uniform
+                        const float wd = rows.w[i][d];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[k][j] += wd * e[1 + d + j];
+                    }
+            }
+        }
+        const int y = y0 + 4 * lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + wv + 4 * k;
+            if (x >= X || y >= Y) continue;
+            if (flags & PRE_FLAG_ABS)
+                for (int j = 0; j < 4; ++j) a[k][j] = fabsf(a[k][j]);
+            float *o = out + b * oB + t * oT + x * oX + y;
+            if (y + 3 < Y) *reinterpret_cast<G4u *>(o) = G4u{a[k][0], a[k][1], a[k][2], a[k][3]};
+            else for (int j = 0; j < Y - y; ++j) o[j] = a[k][j];
+        }
     }
 }
 
@@ -88,19 +185,60 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *
         }
     }
 
+    // whole domain, input and output share a unit-stride axis long enough to fill a tile row: relabel it to be
+    // the last one (the tap list is symmetric in the axes) and group the taps by (dt, dx) row
+    const int64_t D[3] = {T, X, Y}, si[3] = {in->sT, in->sX, in->sY}, so[3] = {out->sT, out->sX, out->sY};
+    int unit = -1;
+    for (int a = 2; a >= 0 && unit < 0; --a)
+        if (si[a] == 1 && so[a] == 1 && D[a] >= 64) unit = a;
+    if (unit >= 0 && !box[0] && !box[1] && !box[2] && ntaps > 0) {
+        const int p[3] = {unit == 0 ? 2 : 0, unit == 1 ? 2 : 1, unit};     // swap `unit` with the last axis
+        const long long nstrips = (D[p[2]] + TILE_C - 1) / TILE_C;
+        const long long tiles = nstrips * ((D[p[1]] + TILE_R - 1) / TILE_R);
+        if (tiles < (1 << 23)) {
+            float w[7][7][7] = {};
+            int mask[7][7] = {};
+            for (int i = 0; i < ntaps; ++i) {
+                const int o0 = tap_off[3 * i + p[0]] + 3, o1 = tap_off[3 * i + p[1]] + 3, o2 = tap_off[3 * i + p[2]] + 3;
+                w[o0][o1][o2] += tap_w[i];
+                mask[o0][o1] |= 1 << o2;
+            }
+            RowList rows;
+            rows.n = rows.lo = rows.hi = 0;
+            for (int o0 = 0; o0 < 7; ++o0)
+                for (int o1 = 0; o1 < 7; ++o1) {
+                    if (!mask[o0][o1]) continue;
+                    rows.off[rows.n] = (o0 - 3 + 8) | ((o1 - 3 + 8) << 4) | (mask[o0][o1] << 8);
+                    for (int d = 0; d < 7; ++d) rows.w[rows.n][d] = w[o0][o1][d];
+                    rows.lo = o1 - 3 < rows.lo ? o1 - 3 : rows.lo;
+                    rows.hi = o1 - 3 > rows.hi ? o1 - 3 : rows.hi;
+                    ++rows.n;
+                }
+            const dim3 grid((unsigned)tiles, (unsigned)(D[p[0]] < 65535 ? D[p[0]] : 65535), (unsigned)(B < 65535 ? B : 65535));
+            hipLaunchKernelGGL(generic_tile_kernel, grid, dim3(256), 0, st, in->ptr, (long long)in->sB, (long long)si[p[0]],
+                               (long long)si[p[1]], out->ptr, (long long)out->sB, (long long)so[p[0]], (long long)so[p[1]],
+                               (int)B, (int)D[p[0]], (int)D[p[1]], (int)D[p[2]], (int)nstrips, flags, rows);
+            PRE_LAUNCH_CHECK();
+            return PRE_OK;
+        }
+    }
     TapList taps;
     taps.n = ntaps;
     for (int i = 0; i < ntaps; ++i) {
         taps.w[i] = tap_w[i];
         taps.off[i] = (tap_off[3 * i] + 8) | ((tap_off[3 * i + 1] + 8) << 4) | ((tap_off[3 * i + 2] + 8) << 8);
     }
-    const long long total = (long long)B * (T - box[0]) * (X - box[1]) * (Y - box[2]);
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in->ptr, (long long)in->sB,
+    const long long nT = T - box[0], nX = X - box[1], nY = Y - box[2];
+    int wsh = 0;
+    while (wsh < 6 && (1 << wsh) < nY) ++wsh;
+    const long long nstrips = (nY + (1 << wsh) - 1) >> wsh, rows = 256 >> wsh;
+    const long long tiles = nstrips * ((nX + rows - 1) / rows);
+    if (tiles >= (1 << 23)) return PRE_E_SHAPE;              // a plane of > 2^31 cells
+    const dim3 grid((unsigned)tiles, (unsigned)(nT < 65535 ? nT : 65535), (unsigned)(B < 65535 ? B : 65535));
+    hipLaunchKernelGGL(generic_kernel, grid, dim3(256), 0, st, in->ptr, (long long)in->sB,
                        (long long)in->sT, (long long)in->sX, (long long)in->sY, out->ptr, (long long)out->sB,
                        (long long)out->sT, (long long)out->sX, (long long)out->sY, (int)B, (int)T, (int)X, (int)Y, box[0], box[1],
-                       box[2], flags, taps);
+                       box[2], wsh, (int)nstrips, flags, taps);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }

@@ -117,6 +117,49 @@ def test_strided_views_and_dense_kernels_vs_oracle(gpu):
     assert Dd.kernel is D.kernel
 
 
+def test_tiled_tap_list_kernel_vs_oracle(gpu):
+    """Tap sets off the 7-point star on views with a long unit-stride axis (LDS-tiled tap-list kernel):
+    Taylor-4/6 Laplacians (taps on kernel slab 1, Utils/ConvOps_2d.py:70-71), dense 3^3/5^3/7^3 kernels,
+    widths that are not multiples of 4 or of the tile, more rows than one tile, offset views,
+    the Nt-fastest surrogate layout, |.| epilogue, and the adjoint (flipped taps) used by autograd."""
+    from cp_pre_amd.convops_2d import ConvOperator
+    from oracle.cstencil import xcorr_c
+    g = torch.Generator().manual_seed(11)
+    cases = [("t4", ConvOperator(("x", "y"), 2, taylor_order=4).kernel), ("t6", ConvOperator(("x", "y"), 2, taylor_order=6).kernel),
+             ("d3", torch.randn(3, 3, 3, generator=g)), ("d5", torch.randn(5, 5, 5, generator=g)),
+             ("d7", torch.randn(7, 7, 7, generator=g) * (torch.rand(7, 7, 7, generator=g) < 0.2))]
+    shapes = [(2, 3, 20, 64), (1, 5, 37, 130), (2, 2, 16, 259), (1, 9, 5, 515)]
+    for name, k in cases:
+        D = ConvOperator()
+        D.kernel = k
+        for shape in shapes:
+            x = torch.randn(*shape, generator=g)
+            want = xcorr_c(x.numpy(), k.numpy())
+            assert rel_err(D(x.to(gpu)).cpu().numpy(), want) <= RES_TOL, (name, shape)
+        wide = torch.randn(2, 4, 19, 140, generator=g)
+        view = wide[:, 1:, 2:, 3:133]                                    # offset base, row stride != width
+        got = D(wide.to(gpu)[:, 1:, 2:, 3:133])
+        assert rel_err(got.cpu().numpy(), xcorr_c(view.contiguous().numpy(), k.numpy())) <= RES_TOL, name
+        surrogate = torch.randn(2, 9, 12, 70, generator=g)               # [BS,Nx,Ny,Nt]: Nt is the unit-stride axis
+        v = surrogate.permute(0, 3, 1, 2)
+        got = D(v.to(gpu))
+        assert got.stride() == v.stride()
+        assert rel_err(got.cpu().numpy(), xcorr_c(v.contiguous().numpy(), k.numpy())) <= RES_TOL, name
+    # |.| epilogue through the C ABI, and the adjoint pass (autograd)
+    from cp_pre_amd import _dispatch
+    k = cases[3][1]
+    x = torch.randn(2, 4, 18, 100, generator=g)
+    got = _dispatch.xcorr(x.to(gpu), k, 3, flags=1)                      # PRE_FLAG_ABS
+    assert rel_err(got.cpu().numpy(), np.abs(xcorr_c(x.numpy(), k.numpy()))) <= RES_TOL
+    xg = x.to(gpu).requires_grad_(True)
+    D = ConvOperator()
+    D.kernel = k
+    D(xg).square().sum().backward()
+    xc = x.clone().requires_grad_(True)
+    torch.nn.functional.conv3d(xc[:, None], k[None, None], padding=2).square().sum().backward()
+    assert rel_err(xg.grad.cpu().numpy(), xc.grad.numpy()) <= 1e-4
+
+
 def test_vector_ops_vs_oracle(gpu):
     from cp_pre_amd import vector_convops as V
     from oracle import convops as ocv

@@ -58,9 +58,27 @@ def bench_eval():
         crop = torch.randn(B, T, X + 2, Y + 2, device=dev)[..., 1:-1, 1:-1]
         report(f"laplacian on a cropped view [{B},{T},{X},{Y}] 8B/cell", timeit(lambda: L(crop)), 8 * crop.numel())
         del xo, crop
-    D = ConvOperator(("x", "y"), 2, taylor_order=4)
-    x = torch.randn(64, 10, 512, 512, device=dev)
-    report("generic kernel 5^3 taylor-4 [64,10,512,512] 8B/cell", timeit(lambda: D(x)), 8 * x.numel())
+
+
+def bench_generic():
+    """Tap sets off the 7-point star: the L1/L2-served tap-list kernel."""
+    x = torch.randn(256, 10, 512, 512, device=dev)
+    D4, D6 = ConvOperator(("x", "y"), 2, taylor_order=4), ConvOperator(("x", "y"), 2, taylor_order=6)
+    report("taylor-4 laplacian (9 taps, 5^3) [256,10,512,512] 8B/cell", timeit(lambda: D4(x)), 8 * x.numel())
+    report("taylor-6 laplacian (13 taps, 7^3) 8B/cell", timeit(lambda: D6(x)), 8 * x.numel())
+    W = ConvOperator()
+    D_tt = ConvOperator("t", 2)
+    k5 = torch.zeros(5, 5, 5)
+    k5[1:4, 1:4, 1:4] = D_tt.kernel
+    W.kernel = k5 - 0.25 * D4.kernel
+    report("wave, taylor-4 laplacian, additive 5^3 kernel (12 taps) 8B/cell", timeit(lambda: W(x)), 8 * x.numel())
+    dense = ConvOperator()
+    dense.kernel = torch.randn(3, 3, 3)
+    report("dense 3^3 kernel (27 taps) 8B/cell", timeit(lambda: dense(x)), 8 * x.numel())
+    xt = torch.randn(256, 512, 512, 10, device=dev).permute(0, 3, 1, 2)
+    report("taylor-4 laplacian on an Nt-fastest view 8B/cell", timeit(lambda: D4(xt)), 8 * xt.numel())
+    xo = torch.randn(256, 10, 201, 201, device=dev)
+    report("taylor-4 laplacian, odd width [256,10,201,201] 8B/cell", timeit(lambda: D4(xo)), 8 * xo.numel())
 
 
 def bench_calib():
@@ -142,6 +160,8 @@ def bench_spatial():
         del a, b
 
 
+if __name__ == "__main__" and "generic" in sys.argv[1:]:
+    bench_generic()
 if __name__ == "__main__" and "spatial" in sys.argv[1:]:
     bench_spatial()
 if __name__ == "__main__" and "copy" in sys.argv[1:]:
