@@ -298,7 +298,7 @@ def test_conformal_golden_vectors(gpu, golden):
             j += 1
 
 
-@pytest.mark.parametrize("n,cells", [(33, (5, 7)), (512, (3, 40, 50)), (1000, (4099,)), (4096, (2, 16, 48))])
+@pytest.mark.parametrize("n,cells", [(33, (5, 7)), (129, (70,)), (256, (9, 33)), (512, (3, 40, 50)), (1000, (4099,)), (4096, (2, 16, 48))])
 def test_marginal_qhat_bit_exact_vs_numpy(gpu, n, cells):
     """Per-cell radix select over the batch axis: ragged cell counts, ties, negatives, +-0, inf."""
     from cp_pre_amd import inductive_cp as icp
