@@ -607,6 +607,72 @@ def test_reference_script_shaped_usage_through_compat_shims(gpu):
             del sys.modules[m]
 
 
+def test_intents_of_the_reference_test_scripts(gpu):
+    """The reference's Tests/*.py are eyeball scripts; what each means to show, as assertions:
+    Tests/test_wave.py:146-169 and Tests/test_advection.py:271-282 (individual kernels == additive kernel ==
+    spectral convolution), Tests/test_convops.py:31-79 (Laplace / Divergence / Gradient classes == the scalar
+    operators, 128^2 Gaussian), Tests/findiff_test.py:34-39 (scaled first derivative vs the analytic one),
+    Tests/NS_vector_convops.py:131-176 (vector classes reproduce the scalar NS continuity residual),
+    Tests/MM_FinDiff.py (the stencil as a matrix: W @ u == conv)."""
+    from cp_pre_amd import vector_convops as V
+    from cp_pre_amd.convops_1d import ConvOperator as Conv1D
+    from cp_pre_amd.convops_2d import ConvOperator, get_stencil
+    g = torch.Generator().manual_seed(17)
+    # test_wave
+    c, dt, dx = 1.0, 0.01, 0.02
+    u = torch.randn(2, 12, 33, 33, generator=g).to(gpu)
+    D_tt, D_xx_yy = ConvOperator('t', 2), ConvOperator(('x', 'y'), 2)
+    individual = D_tt(u) - (c * dt / dx) ** 2 * D_xx_yy(u)
+    D = ConvOperator()
+    D.kernel = D_tt.kernel - (c * dt / dx) ** 2 * D_xx_yy.kernel
+    additive, spectral = D(u), D.spectral_convolution(u)
+    assert rel_err(additive.cpu().numpy(), individual.cpu().numpy()) <= RES_TOL
+    assert rel_err(spectral.cpu().numpy(), individual.cpu().numpy()) <= 1e-4
+    # test_advection
+    v = 1.0
+    uu = torch.randn(3, 30, 200, generator=g).to(gpu)
+    D_t, D_x = Conv1D(domain='t', order=1), Conv1D(domain='x', order=1)
+    D1 = Conv1D()
+    D1.kernel = D_t.kernel + (v * dt / dx) * D_x.kernel
+    individual = D_t(uu) + (v * dt / dx) * D_x(uu)
+    assert rel_err(D1(uu).cpu().numpy(), individual.cpu().numpy()) <= RES_TOL
+    assert rel_err(D1.spectral_convolution(uu).cpu().numpy(), individual.cpu().numpy()) <= 1e-4
+    # test_convops: 2D Gaussian, field [1,1,128,128]
+    x = np.linspace(-1, 1, 128)
+    xx, yy = np.meshgrid(x, x)
+    field = torch.tensor(np.exp(-50 * (xx ** 2 + yy ** 2)), dtype=torch.float32).view(1, 1, 128, 128).to(gpu)
+    lap = V.Laplace()(field, field)
+    assert torch.equal(lap[0], ConvOperator(('x', 'y'), 2)(field)) and torch.equal(lap[0], lap[1])
+    Dx, Dy = ConvOperator('x', 1), ConvOperator('y', 1)
+    assert rel_err(V.Divergence()(field, field).cpu().numpy(), (Dx(field) + Dy(field)).cpu().numpy()) <= RES_TOL
+    gx, gy = V.Gradient()(field, field)
+    assert torch.equal(gx, Dx(field)) and torch.equal(gy, Dy(field))
+    # findiff_test: f = sin(x) cos(y) on [0, 2pi]^2, D_x scaled by 1/(2 dx) against the analytic d/dx
+    n = 256
+    xs = np.linspace(0, 2 * np.pi, n)
+    h = xs[1] - xs[0]
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    f = torch.tensor(np.sin(X) * np.cos(Y), dtype=torch.float32)
+    fx = ConvOperator(('x'), 1, scale=1 / (2 * h))(f[None, None].to(gpu))[0, 0].cpu().numpy()      # [1,1,Nx,Ny]: d/dx on axis 2
+    assert np.max(np.abs(fx[1:-1, 1:-1] - (np.cos(X) * np.cos(Y))[1:-1, 1:-1])) < 2e-3              # O(h^2) + fp32
+    # NS_vector_convops: continuity residual through Divergence == scalar operators
+    uvel, vvel = torch.randn(2, 6, 20, 24, generator=g).to(gpu), torch.randn(2, 6, 20, 24, generator=g).to(gpu)
+    assert rel_err(V.Divergence()(uvel, vvel).cpu().numpy(), (Dx(uvel) + Dy(vvel)).cpu().numpy()) <= RES_TOL
+    # MM_FinDiff: the 5-point Laplacian as a matrix acting on the flattened plane
+    m = 12
+    st = get_stencil(2, 2).numpy()
+    W = np.zeros((m * m, m * m), np.float32)
+    for i in range(m):
+        for j in range(m):
+            for di in (-1, 0, 1):
+                for dj in (-1, 0, 1):
+                    if 0 <= i + di < m and 0 <= j + dj < m:
+                        W[i * m + j, (i + di) * m + (j + dj)] = st[1 + di, 1 + dj]
+    plane = torch.randn(m, m, generator=g)
+    got = ConvOperator(('x', 'y'), 2)(plane[None, None].to(gpu))[0, 0].cpu().numpy()
+    assert rel_err(got, (W @ plane.numpy().reshape(-1)).reshape(m, m)) <= RES_TOL
+
+
 def test_graft_smoke(gpu):
     import __graft_entry__ as ge
     ge.smoke()
