@@ -58,7 +58,37 @@ SIGNATURES = {
     "pre_cov_joint_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int, _fp, c_void_p],
 }
 
+# libcp_pre_fft.so (include/cp_pre_fft.h): the spectral family; separate because it links hipFFT
+FFT_SO_PATH = os.path.join(_HERE, "libcp_pre_fft.so")
+PRE_FFT_CONJ, PRE_FFT_INVERT = 1, 2
+_i64p = POINTER(c_int64)
+FFT_SIGNATURES = {
+    "pre_fft_abi_version": [],
+    "pre_fft_create": [POINTER(c_void_p), c_int, _i64p, c_int64, c_int64],
+    "pre_fft_destroy": [c_void_p],
+    "pre_fft_work_bytes": [c_void_p, POINTER(ctypes.c_size_t)],
+    "pre_spectral_apply_f32": [c_void_p, _fp, _i64p, _i64p, _i64p, POINTER(c_float), _i64p, c_int, c_float, _fp, _i64p, _i64p,
+                               c_void_p, c_void_p],
+}
+
 _lib = None
+_fft = None
+
+
+def load_fft():
+    """ctypes handle of libcp_pre_fft.so (loaded once, after torch so that it binds to the hipFFT / HIP runtime
+    torch already loaded); raises loudly if absent."""
+    global _fft
+    if _fft is None:
+        if not os.path.exists(FFT_SO_PATH):
+            raise ImportError(f"{FFT_SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = ctypes.CDLL(FFT_SO_PATH)
+        for name, argtypes in FFT_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        _fft = lib
+    return _fft
 
 
 def load():
@@ -89,6 +119,8 @@ def check(rc, what):
         return
     if rc < 0:
         raise RuntimeError(f"{what}: {_ERR.get(rc, 'error')} (rc={rc})")
+    if rc >= 1000:
+        raise RuntimeError(f"{what}: hipfftResult {rc - 1000}")
     raise RuntimeError(f"{what}: hipError_t {rc}")
 
 

@@ -874,8 +874,9 @@ def test_spatial_family_matches_reference_golden(gpu):
 
 
 def test_spectral_family_matches_reference_golden(gpu):
-    """conv='spectral' / differentiate / integrate (torch.fft pass-through, not a HIP
-    kernel) of all three ConvOperator files against outputs of the reference's own methods."""
+    """conv='spectral' / differentiate / integrate (libcp_pre_fft.so - hipFFT plus fused
+    embed / spectrum-multiply / crop kernels) of all three ConvOperator files against outputs of the
+    reference's own methods."""
     from conftest import load_golden
     from cp_pre_amd.convops_1d import ConvOperator as Conv1D
     from cp_pre_amd.convops_2d import ConvOperator as Conv2D
@@ -907,6 +908,61 @@ def test_spectral_family_matches_reference_golden(gpu):
     D = Conv2D(("x", "y"), 2)
     got = D.spectral_convolution(x4.to(gpu))
     assert got.is_cuda and torch.allclose(got.cpu(), xcorr_torch(x4, D.kernel), atol=1e-4)
+
+
+def test_spectral_native_route_equals_torch_fft_composition(gpu):
+    """libcp_pre_fft.so against the same recipe composed from torch.fft ops (the differentiable route), on
+    odd and even sizes, strided views, 5^3 kernels, and a batch that is staged in several hipFFT chunks."""
+    from cp_pre_amd import _spectral as S
+    from cp_pre_amd.convops_2d import ConvOperator
+    g = torch.Generator().manual_seed(23)
+    kernels = [ConvOperator(("x", "y"), 2).kernel, ConvOperator("t", 1).kernel, torch.randn(3, 3, 3, generator=g),
+               ConvOperator(("x", "y"), 2, taylor_order=4).kernel]
+    fields = [torch.randn(3, 6, 9, 12, generator=g), torch.randn(2, 7, 8, 11, generator=g),
+              torch.randn(2, 12, 9, 5, generator=g).permute(0, 3, 2, 1)]
+    tol = 2e-5
+    for k in kernels:
+        for x in fields:
+            xd = x.to(gpu)
+            a, b = S.fft_xcorr(xd, k), S._torch_fft_xcorr(xd, k)
+            assert a.shape == b.shape and rel_err(a.cpu().numpy(), b.cpu().numpy()) <= tol, "xcorr"
+            # PRE_FFT_INVERT on a well-conditioned eps (the singular eps=1e-6 case amplifies round-off 1e6 times)
+            a = S._native_fft_xcorr_inverse(xd, k, eps=0.3)
+            x_pad = torch.nn.functional.pad(xd[:, None], [p for d in reversed(range(3)) for p in (k.shape[d] // 2,) * 2])
+            if x_pad.size(-1) % 2:
+                x_pad = torch.nn.functional.pad(x_pad, [0, 1])
+            kf = torch.fft.rfftn(torch.nn.functional.pad(k.to(gpu)[None, None], [v for i in reversed(range(2, 5))
+                                                                                 for v in (0, x_pad.size(i) - k.size(i - 2))]),
+                                 dim=(2, 3, 4))
+            b = torch.fft.irfftn(torch.fft.rfftn(x_pad, dim=(2, 3, 4)) / (torch.conj(kf) + 0.3), dim=(2, 3, 4))
+            b = b[:, 0, :xd.shape[1], :xd.shape[2], :xd.shape[3]]
+            assert a.shape == b.shape and rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4, "xcorr inverse"
+            for corr in (False, True):
+                for sp in (False, True):
+                    a, b = S.differentiate(xd, k, corr, sp), S._torch_differentiate(xd, k, corr, sp)
+                    assert a.shape == b.shape and rel_err(a.cpu().numpy(), b.cpu().numpy()) <= tol, ("diff", corr, sp)
+                    a, b = S._native_integrate(xd, k, corr, sp, 0.3), S._torch_integrate(xd, k, corr, sp, 0.3)
+                    assert a.shape == b.shape and rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4, ("integ", corr, sp)
+    # 1-D file (nd=2) and the spatial family ([B,C,X,Y], channels kept)
+    k2 = torch.randn(3, 3, generator=g)
+    x3 = torch.randn(4, 9, 16, generator=g).to(gpu)
+    assert rel_err(S.fft_xcorr(x3, k2).cpu().numpy(), S._torch_fft_xcorr(x3, k2).cpu().numpy()) <= tol
+    x4 = torch.randn(2, 3, 10, 13, generator=g).to(gpu)
+    a, b = S.differentiate(x4, k2, True, True, keep_channel=True), S._torch_differentiate(x4, k2, True, True, keep_channel=True)
+    assert a.shape == b.shape == (2, 3, 10, 13) and rel_err(a.cpu().numpy(), b.cpu().numpy()) <= tol
+    # several hipFFT chunks (ragged last one)
+    old = S._STAGE_BYTES
+    try:
+        S._STAGE_BYTES = 3 * (4 * 8 * 11 * 14 + 8 * 8 * 11 * 8 + 256) + 100          # 3 samples per chunk, batch 7
+        x = torch.randn(7, 6, 9, 12, generator=g).to(gpu)
+        a = S.fft_xcorr(x, kernels[0])
+    finally:
+        S._STAGE_BYTES = old
+    assert rel_err(a.cpu().numpy(), S._torch_fft_xcorr(x, kernels[0]).cpu().numpy()) <= tol
+    # a gradient request takes the torch route and still works
+    xg = torch.randn(2, 5, 8, 8, generator=g).to(gpu).requires_grad_(True)
+    S.fft_xcorr(xg, kernels[0]).square().sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
 
 
 def test_full_size_properties_c2(gpu):

@@ -30,6 +30,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.pre_abi_version() == 2
+    # the spectral family's library (links hipFFT)
+    header = open(os.path.join(ROOT, "include", "cp_pre_fft.h")).read()
+    declared = set(re.findall(r"\bint\s+(pre_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.FFT_SIGNATURES), declared ^ set(_lib.FFT_SIGNATURES)
+    fft = _lib.load_fft()
+    for name in declared:
+        assert hasattr(fft, name), name
+    assert fft.pre_fft_abi_version() == 1
 
 
 def test_kernel_construction_matches_reference_bit_for_bit(golden):

@@ -160,6 +160,23 @@ def bench_spatial():
         del a, b
 
 
+def bench_spectral():
+    """Spectral family: libcp_pre_fft.so (fused embed / multiply / crop around hipFFT) vs the torch.fft composition."""
+    from cp_pre_amd import _spectral as S
+    D = ConvOperator()
+    D.kernel = ConvOperator("t", 2).kernel - 0.25 * ConvOperator(("x", "y"), 2).kernel
+    for shape in [(64, 32, 256, 256), (16, 64, 512, 512)]:
+        x = torch.randn(*shape, device=dev)
+        with torch.no_grad():
+            report(f"spectral_convolution native {list(shape)} 8B/cell", timeit(lambda: S.fft_xcorr(x, D.kernel)), 8 * x.numel())
+            report("spectral_convolution torch.fft composition", timeit(lambda: S._torch_fft_xcorr(x, D.kernel)), 8 * x.numel())
+            report("differentiate native", timeit(lambda: S.differentiate(x, D.kernel, True, True)), 8 * x.numel())
+            report("differentiate torch.fft composition", timeit(lambda: S._torch_differentiate(x, D.kernel, True, True)), 8 * x.numel())
+        del x
+
+
+if __name__ == "__main__" and "spectral" in sys.argv[1:]:
+    bench_spectral()
 if __name__ == "__main__" and "generic" in sys.argv[1:]:
     bench_generic()
 if __name__ == "__main__" and "spatial" in sys.argv[1:]:
