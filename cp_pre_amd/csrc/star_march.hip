@@ -96,6 +96,10 @@ struct MHDParams { Star Dt, Dx, Dy; float gamma, gm2; };
 template <int MODE>
 struct NSMomentum {    // Marginal/NS_Residuals_CP.py:231-240
     static constexpr int F = 3;
+    // Nt-fastest relabelling (MODE 3/4) needs 130-138 VGPRs unconstrained = 3 waves/SIMD; capped at 128 it
+    // spills 0-6 dwords and runs 4 waves/SIMD: +11 % (4.7-5.0 TB/s).  The same cap on the MHD induction kernel
+    // (146 VGPRs, 17 dwords spilled) was -30 %: scratch traffic inside the plane loop.
+    static constexpr int MIN_WAVES = MODE >= 3 ? 4 : 1;
     using Params = NSParams;
     static __device__ __forceinline__ float4 eval(const Nbr (&n)[3], const Params &p)
     {
@@ -244,8 +248,12 @@ template <int F> struct Halo { float4 row[F]; float yl[F], yr[F]; };
 struct BCInfo { int xlo, xhi, ylo, yhi; float vxlo, vxhi, vylo, vyhi; };
 struct NoBC {};
 
+// Fn::MIN_WAVES (optional): waves per SIMD the register allocator must leave room for
+template <class Fn, class = void> struct MinWaves { static constexpr int value = 1; };
+template <class Fn> struct MinWaves<Fn, std::void_t<decltype(Fn::MIN_WAVES)>> { static constexpr int value = Fn::MIN_WAVES; };
+
 template <class Fn, int NR, int TYQ, bool BC = false>
-__global__ void __launch_bounds__(NR *TYQ)
+__global__ void __launch_bounds__(NR *TYQ, MinWaves<Fn>::value)
 march_kernel(const Geom g, const typename Fn::Params prm, const typename std::conditional<BC, BCInfo, NoBC>::type bc)
 {
     constexpr int F = Fn::F;
