@@ -116,7 +116,8 @@ def kth_axis0(scores, ks):
     inv = [0] * len(ks)
     for pos, i in enumerate(order):
         inv[i] = pos
-    out = out[inv] if inv != list(range(len(ks))) else out
+    if inv != list(range(len(ks))):              # device-only reorder (no index upload: stays HIP-graph capturable)
+        out = out.flip(0) if inv == list(range(len(ks) - 1, -1, -1)) else torch.stack([out[i] for i in inv])
     return uncanon(out, cell_order, 1)
 
 

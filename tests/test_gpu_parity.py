@@ -673,6 +673,35 @@ def test_intents_of_the_reference_test_scripts(gpu):
     assert rel_err(got, (W @ plane.numpy().reshape(-1)).reshape(m, m)) <= RES_TOL
 
 
+def test_marginal_step_is_hip_graph_capturable(gpu):
+    """The library never allocates, synchronises or reads device data back on the host path (operator kernels
+    on the CPU, ranks computed on the host), so a whole eval + |.| + per-cell q-hat step records into a HIP
+    graph on torch's capture stream and replays on new data (C1 shape: Marginal/Advection_Residuals_CP.py)."""
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    from cp_pre_amd import residuals as R
+    alphas = [float(a) for a in icp.ALPHA_LEVELS]
+    g = torch.Generator().manual_seed(29)
+    u = (torch.rand(256, 100, 200, generator=g) + 0.5).to(gpu)
+    op = R.Advection(1.0, 0.005, 0.01, disc=2)
+
+    def step():
+        return pipeline.marginal_qhat(op.residual(u, boundary=True, absolute=True), alphas)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        q = step()
+    u.copy_((torch.rand(256, 100, 200, generator=g) + 0.5).to(gpu))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(q, step())
+
+
 def test_graft_smoke(gpu):
     import __graft_entry__ as ge
     ge.smoke()
