@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
+#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh'
+# then   python tools/distill_profiles.py r01   turns gpurun_out/prof/* into profiles/r01/*.
+# Trace and counter passes are separate runs (PMC is never combined with other trace domains).
+set -e
+R=${GRAFT_REPO_ROOT:-$PWD}
+P=$R/gpurun_out/prof
+rm -rf "$P"; mkdir -p "$P"
+cd /tmp && export TMPDIR=/tmp
+run() {  # tag, rocprof args..., -- bench args
+    tag=$1; shift
+    echo "== $tag" >&2
+    timeout -k 10 500 rocprofv3 "$@" > "$P/bench_$tag.log" 2>&1
+}
+B="python3 $R/bench.py --no-cpu-baseline"
+run trace    --kernel-trace --stats --output-format csv -d "$P/trace"   -- $B --steps 3 --warmup 1
+run trace_m  --kernel-trace --stats --output-format csv -d "$P/trace_m" -- $B --steps 2 --warmup 1 --mode marginal
+run fetch    --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch" -- $B --steps 1 --warmup 0
+run write    --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write" -- $B --steps 1 --warmup 0
+# SQ counters on a quarter batch (same per-wave behaviour, shorter run); one small group per pass
+run sq1      --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d "$P/sq1" -- $B --steps 1 --warmup 0 --batch 1024
+run sq2      --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d "$P/sq2" -- $B --steps 1 --warmup 0 --batch 1024
+for c in c2 c4 c5; do
+    run trace_$c --kernel-trace --stats --output-format csv -d "$P/trace_$c" -- $B --config $c --steps 3 --warmup 1
+done
+echo done >&2
