@@ -176,6 +176,19 @@ def pmc_traffic(args):
     return best
 
 
+def host_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (a 1-GPU box of the pool shows 256 logical CPUs but is limited to 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, alphas):
     """The oracle (reference arithmetic: F.conv3d per operator + torch elementwise + numpy
     calibration) on a bounded sample of the same workload, on this box's host cores."""
@@ -184,7 +197,8 @@ def cpu_baseline(args, alphas):
     from oracle import residuals as orr
     T = args.slab + 2
     dt, dx, dy = 1e-2, 1.0 / args.nx, 1.0 / args.ny
-    threads = torch.get_num_threads()
+    threads = host_cores()
+    torch.set_num_threads(threads)
 
     def run(nb):
         g = torch.Generator().manual_seed(0)
