@@ -110,6 +110,18 @@ def test_no_cpu_fallback_without_gpu():
         icp.calibrate(np.zeros(5, np.float32), 5, 0.5)
 
 
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback when libcp_pre_hip.so / libcp_pre_fft.so are absent: loading raises ImportError."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", str(tmp_path / "libcp_pre_hip.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+    monkeypatch.setattr(_lib, "_fft", None)
+    monkeypatch.setattr(_lib, "FFT_SO_PATH", str(tmp_path / "libcp_pre_fft.so"))
+    with pytest.raises(ImportError, match="is missing"):
+        _lib.load_fft()
+
+
 def test_rank_arithmetic_matches_numpy_higher():
     for n in (7, 100, 256, 4096, 8192, 65536):
         for a in oc.ALPHA_LEVELS:
