@@ -272,7 +272,7 @@ def filter_sims_within_bounds(lower_bound, upper_bound, samples, threshold, with
 
 def emp_cov_joint(pred_sets, y):
     f = filter_sims_joint(pred_sets, y)
-    return float(f.float().mean().item()) if isinstance(f, torch.Tensor) else float(f.mean())
+    return float(f.sum().item()) / f.numel() if isinstance(f, torch.Tensor) else float(f.mean())     # count / n in float64, as numpy
 
 
 ALPHA_LEVELS = np.arange(0.05, 0.95 + 0.1, 0.1)     # Marginal/Wave_Residuals_CP.py:284

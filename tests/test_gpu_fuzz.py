@@ -1,0 +1,194 @@
+"""Seeded randomised differential tests (MI355X): the HIP path against the oracle on shapes, memory
+layouts, kernels and calibration parameters drawn at random - tile edges, ragged widths, offset /
+permuted / sliced views, tap sets on and off the star, ties and rank extremes.  The seed is fixed:
+the cases are the same on every run (raise PRE_FUZZ_CASES to widen the sweep by hand)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import conformal as oc
+from oracle import residuals as orr
+from oracle.cstencil import xcorr_c
+
+pytestmark = pytest.mark.gpu
+CASES = int(os.environ.get("PRE_FUZZ_CASES", "60"))
+RES_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _random_view(rng, shape, gen):
+    """A CPU tensor of logical ``shape`` with a random memory layout: contiguous, offset slice of a
+    larger buffer, a permuted buffer (some other axis fastest), or a strided (::2) slice."""
+    kind = rng.choice(["contig", "slice", "perm", "step"], p=[0.3, 0.3, 0.3, 0.1])
+    if kind == "contig":
+        return torch.randn(*shape, generator=gen)
+    if kind == "slice":
+        pad = [int(rng.integers(0, 4)) for _ in shape]
+        big = torch.randn(*[s + 2 * p for s, p in zip(shape, pad)], generator=gen)
+        return big[tuple(slice(p, p + s) for s, p in zip(shape, pad))]
+    if kind == "perm":
+        perm = list(rng.permutation(len(shape) - 1) + 1)              # batch stays first
+        phys = [shape[0]] + [shape[p] for p in perm]
+        inv = [0] + [perm.index(a) + 1 for a in range(1, len(shape))]
+        return torch.randn(*phys, generator=gen).permute(*inv)
+    big = torch.randn(*(list(shape[:-1]) + [2 * shape[-1]]), generator=gen)
+    return big[..., ::2]
+
+
+def _random_kernel(rng, gen, nd):
+    kind = rng.choice(["star", "planar", "dense", "sparse"])
+    k = int(rng.choice([3, 3, 5, 7]))
+    if kind == "star":
+        ker = torch.zeros(*([3] * nd))
+        for ax in range(nd):
+            for off in (0, 2):
+                idx = [1] * nd
+                idx[ax] = off
+                ker[tuple(idx)] = float(rng.standard_normal())
+        ker[tuple([1] * nd)] = float(rng.standard_normal())
+        return ker
+    if kind == "planar":                                               # Taylor-4/6 like: one slab of a k^nd kernel
+        ker = torch.zeros(*([k] * nd))
+        slab = int(rng.integers(0, k))
+        sub = torch.randn(*([k] * (nd - 1)), generator=gen) * (torch.rand(*([k] * (nd - 1)), generator=gen) < 0.5)
+        ker[slab] = sub
+        return ker
+    ker = torch.randn(*([k] * nd), generator=gen)
+    if kind == "sparse":
+        ker = ker * (torch.rand(*([k] * nd), generator=gen) < 0.15)
+    return ker
+
+
+def test_fuzz_convolution_against_c_oracle(gpu):
+    from cp_pre_amd.convops_1d import ConvOperator as Conv1D
+    from cp_pre_amd.convops_2d import ConvOperator as Conv2D
+    rng = np.random.default_rng(2024)
+    gen = torch.Generator().manual_seed(2024)
+    widths = [1, 2, 3, 4, 5, 7, 8, 17, 31, 64, 65, 100, 130, 255, 256, 257, 260, 515]
+    for case in range(CASES):
+        nd = int(rng.choice([2, 3]))
+        if nd == 3:
+            shape = (int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(1, 40)), int(rng.choice(widths)))
+        else:
+            shape = (int(rng.integers(1, 6)), int(rng.integers(1, 40)), int(rng.choice(widths)))
+        x = _random_view(rng, shape, gen)
+        ker = _random_kernel(rng, gen, nd)
+        D = (Conv2D if nd == 3 else Conv1D)()
+        D.kernel = ker
+        got = D(x.to(gpu)) if rng.random() < 0.7 else D(x)              # device tensor, or a CPU tensor staged through
+        want = xcorr_c(x.contiguous().numpy(), ker.numpy())
+        assert tuple(got.shape) == shape
+        assert rel_err(got.cpu().numpy(), want) <= RES_TOL, (case, shape, tuple(x.stride()), tuple(ker.shape))
+
+
+def test_fuzz_fused_residuals_against_oracle(gpu):
+    from cp_pre_amd import residuals as R
+    rng = np.random.default_rng(7)
+    gen = torch.Generator().manual_seed(7)
+    for case in range(max(8, CASES // 4)):
+        B, T, X = int(rng.integers(1, 4)), int(rng.integers(1, 9)), int(rng.integers(1, 30))
+        Y = int(rng.choice([4, 8, 12, 60, 64, 68, 128, 200, 256, 260, 510, 512]))
+        boundary = bool(rng.random() < 0.5)
+        if not boundary and min(T, X, Y) < 3:
+            boundary = True
+        dt, dx, dy = (float(v) for v in rng.uniform(0.005, 0.1, 3))
+        layout = rng.choice(["vars", "nt_fastest", "offset"])
+        if layout == "vars":
+            v = torch.rand(B, 6, T, X, Y, generator=gen) + 0.5
+        elif layout == "nt_fastest":
+            v = (torch.rand(B, 6, X, Y, T, generator=gen) + 0.5).permute(0, 1, 4, 2, 3)     # Marginal/NS_Residuals_CP.py:282
+        else:
+            v = (torch.rand(B, 6, T, X + 2, Y + 5, generator=gen) + 0.5)[..., 1:X + 1, 3:Y + 3]
+        vd = v.to(gpu)
+        checks = [
+            (R.NavierStokes(dt, dx, dy).residual_momentum(vd[:, :3], boundary), orr.ns_momentum(v[:, :3], dt, dx, dy, boundary=boundary)),
+            (R.NavierStokes(dt, dx, dy).residual_continuity(vd[:, :2], boundary), orr.ns_continuity(v[:, :2], dx, dy, boundary=boundary)),
+            (R.MHD().residual_induction(vd, boundary), orr.mhd_induction(v, boundary=boundary)),
+            (R.MHD().residual_energy(vd, boundary), orr.mhd_energy(v, boundary=boundary)),
+            (R.MHD().residual_momentum(vd, boundary), orr.mhd_momentum(v, boundary=boundary)),
+            (R.MHD().residual_continuity(vd, boundary), orr.mhd_continuity(v, boundary=boundary)),
+        ]
+        for i, (got, want) in enumerate(checks):
+            assert tuple(got.shape) == tuple(want.shape), (case, i)
+            if want.numel():
+                assert rel_err(got.cpu().numpy(), want.numpy()) <= RES_TOL, (case, i, layout, (B, T, X, Y), boundary)
+
+
+def test_fuzz_calibration_against_numpy(gpu):
+    from cp_pre_amd import inductive_cp as icp
+    rng = np.random.default_rng(99)
+    for case in range(max(10, CASES // 3)):
+        n = int(rng.choice([2, 3, 17, 64, 100, 255, 256, 257, 1000, 1025, 2048, 5000]))
+        cells = tuple(int(v) for v in rng.choice([1, 2, 3, 5, 16, 33, 63, 64, 65, 130], size=int(rng.integers(1, 4))))
+        if n * int(np.prod(cells)) > 4_000_000:
+            cells = cells[:1]
+        kind = rng.choice(["normal", "ties", "const", "signed"])
+        s = rng.standard_normal((n,) + cells).astype(np.float32)
+        if kind == "ties":
+            s = np.round(s * 2) / 2                                      # heavy duplicates
+        elif kind == "const":
+            s[:] = 0.25
+        if kind != "signed":
+            s = np.abs(s)
+        sd = torch.from_numpy(s).to(gpu)
+        for alpha in rng.choice(oc.ALPHA_LEVELS, size=3, replace=False):
+            if oc.quantile_level(n, alpha) > 1:
+                with pytest.raises(ValueError):
+                    icp.calibrate(sd, n, alpha)
+                continue
+            got = icp.calibrate(sd, n, alpha)
+            assert np.array_equal(np.asarray(got.cpu()), oc.calibrate(s, n, alpha)), (case, n, cells, kind, alpha)
+        # joint recipe pieces on the same data
+        if n >= 3 and kind in ("normal", "signed"):
+            b = rng.standard_normal(s.shape).astype(np.float32)
+            mod = icp.modulation_func(sd, torch.from_numpy(b).to(gpu))
+            mref = oc.modulation_func(s, b)
+            sc = icp.ncf_metric_joint(sd, torch.from_numpy(b).to(gpu), torch.from_numpy(mref).to(gpu))
+            if int(np.prod(cells)) > 1:       # numpy reduces axis 0 of [n, M>1] row by row: the kernel's order, bit for bit
+                assert np.array_equal(np.asarray(mod.cpu()), mref), (case, "modulation")
+            else:                             # a single cell is a contiguous 1-D reduction: numpy sums pairwise (<= 1 ulp apart)
+                assert rel_err(np.asarray(mod.cpu()), mref) <= 1e-6, (case, "modulation, M=1")
+            assert np.array_equal(np.asarray(sc.cpu()), oc.ncf_metric_joint(s, b, mref)), (case, "score")
+            q = float(oc.calibrate(np.asarray(sc.cpu()), n, 0.25)) if oc.quantile_level(n, 0.25) <= 1 else 1.0
+            sets = [b - q * mref, b + q * mref]
+            dsets = [torch.from_numpy(v).to(gpu) for v in sets]
+            assert float(icp.emp_cov(dsets, sd)) == pytest.approx(float(oc.emp_cov(sets, s)), abs=1e-12)
+            assert float(icp.emp_cov_joint(dsets, sd)) == pytest.approx(float(oc.emp_cov_joint(sets, s)), abs=1e-12)
+
+
+def test_fuzz_spatial_family_mixed_boundaries(gpu):
+    """Utils/VectorConvOps_Spatial.py classes with a different boundary type on every side (set through the
+    BoundaryManager, boundary_conditions.py:29-40) against the oracle's pad-then-valid-conv recipe."""
+    from cp_pre_amd import vector_convops_spatial as VS
+    from oracle import spatial as osp
+    rng = np.random.default_rng(314)
+    gen = torch.Generator().manual_seed(314)
+    types = ["dirichlet", "neumann", "outflow", "periodic", "symmetric"]
+    kinds = {"gradient": VS.Gradient, "laplace": VS.Laplace, "divergence": VS.Divergence, "curl": VS.Curl,
+             "vector_gradient": VS.Vector_Gradient}
+    for case in range(max(12, CASES // 2)):
+        B, X = int(rng.integers(1, 5)), int(rng.integers(2, 40))
+        Y = int(rng.choice([2, 3, 4, 5, 8, 31, 64, 65, 100, 128, 256, 260]))
+        a, b = torch.randn(B, 1, X, Y, generator=gen), torch.randn(B, 1, X, Y, generator=gen)
+        kind = str(rng.choice(list(kinds)))
+        sides = {s: str(rng.choice(types)) for s in ("left", "right", "top", "bottom")}
+        vals = {s: float(rng.standard_normal()) for s in sides}
+        scale = float(rng.uniform(0.2, 3.0))
+        ref = osp.VectorOp(kind, scale=scale, boundary_cond="periodic")
+        ref.types, ref.values = dict(sides), dict(vals)
+        op = kinds[kind](scale=scale, boundary_cond="periodic", device=gpu)
+        for s in sides:
+            op.bc.set_boundary_type(s, sides[s], vals[s])
+        with torch.no_grad():
+            got = op(a.to(gpu), b.to(gpu)) if kind != "laplace" else op(a.to(gpu))
+        want = ref(a, b) if kind != "laplace" else ref(a)
+        assert tuple(got.shape) == tuple(want.shape), (case, kind)
+        assert rel_err(got.cpu().numpy(), want.numpy()) <= RES_TOL, (case, kind, sides, (B, X, Y))
