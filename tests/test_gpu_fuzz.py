@@ -122,6 +122,41 @@ def test_fuzz_fused_residuals_against_oracle(gpu):
                 assert rel_err(got.cpu().numpy(), want.numpy()) <= RES_TOL, (case, i, layout, (B, T, X, Y), boundary)
 
 
+def test_fuzz_1d_and_wave_residuals_against_oracle(gpu):
+    from cp_pre_amd import residuals as R
+    rng = np.random.default_rng(11)
+    gen = torch.Generator().manual_seed(11)
+    for case in range(max(10, CASES // 3)):
+        B, T = int(rng.integers(1, 7)), int(rng.integers(1, 40))
+        X = int(rng.choice([3, 4, 5, 8, 63, 64, 66, 100, 128, 200, 256, 258, 512, 515]))
+        boundary = bool(rng.random() < 0.5) or min(T, X) < 3
+        layout = rng.choice(["contig", "nt_fastest", "offset"])
+        if layout == "contig":
+            u = torch.rand(B, T, X, generator=gen) + 0.5
+        elif layout == "nt_fastest":
+            u = (torch.rand(B, X, T, generator=gen) + 0.5).permute(0, 2, 1)          # Marginal/Advection_Residuals_CP.py:231
+        else:
+            u = (torch.rand(B, T + 3, X + 6, generator=gen) + 0.5)[:, 2:T + 2, 5:X + 5]
+        dx, dt, nu = (float(v) for v in rng.uniform(0.002, 0.05, 3))
+        ud = u.to(gpu)
+        got = R.Burgers(dx, dt, nu).residual(ud, boundary)
+        want = orr.burgers_residual(u, dx, dt, nu, boundary=boundary)
+        assert tuple(got.shape) == tuple(want.shape)
+        if want.numel():
+            assert rel_err(got.cpu().numpy(), want.numpy()) <= RES_TOL, (case, "burgers", layout, (B, T, X), boundary)
+        got = R.Advection(1.3, dt, dx, disc=2).residual(ud, boundary, absolute=True)
+        want = orr.advection_residual(u, 1.3, 2, dt, dx, boundary=boundary).abs()
+        if want.numel():
+            assert rel_err(got.cpu().numpy(), want.numpy()) <= RES_TOL, (case, "advection", layout, (B, T, X), boundary)
+        Y = int(rng.choice([3, 4, 16, 33, 64]))
+        w = torch.randn(B, max(T, 1), Y, X, generator=gen)
+        b3 = boundary or min(T, Y, X) < 3
+        got = R.PRE_Wave(dt=dt, dx=dx, c=1.1).residual(w.to(gpu), boundary=b3)
+        want = orr.wave_residual(w, 1.1, dt, dx, boundary=b3)
+        if want.numel():
+            assert rel_err(got.cpu().numpy(), want.numpy()) <= RES_TOL, (case, "wave", (B, T, Y, X), b3)
+
+
 def test_fuzz_calibration_against_numpy(gpu):
     from cp_pre_amd import inductive_cp as icp
     rng = np.random.default_rng(99)
