@@ -246,12 +246,41 @@ __global__ void __launch_bounds__(1024) kth_kernel(const float *__restrict__ s, 
 constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16;
 constexpr int KA_HIST_WORDS = KA_MAXK * 64 * 32;          // 80 KiB; the first sweep uses 512*32 of them
 constexpr int KA_GROUPS_AT = 512 * 32;                    // 16 x 64 group sums of the first sweep live here
+constexpr int KA_FLAGS_AT = 1008, KA_CAP = 31;            // per-wave "many survivors" flags (640..1023 is never used otherwise)
 struct KAList { int nk; int k[KA_MAXK]; };
 
 __device__ __forceinline__ int ka_word(int row, int half) { return row * 32 + ((half + row) & 31); }
 
+// My cell's DISTINCT prefixes (published in hist[j*64 + cell] by the previous narrowing), compacted to the
+// front: slot i = i-th distinct prefix (ranks ascend, so equal prefixes are adjacent); unused entries hold the
+// sentinel 1 (low bit set: never equals a masked key).  lmax = most slots any cell of the tile has (wave-uniform
+// loop bound for the match); myslot = slot of this thread's own rank.  Ends with a barrier: hist is free again.
+__device__ __forceinline__ void ka_prefixes(unsigned int *hist, int nk, int lane, int wave, unsigned int (&pf)[KA_MAXK],
+                                            int &lmax, int &myslot)
+{
+    unsigned int *scr = hist + 1024 + wave * (KA_MAXK * 64);
+    unsigned int prev = 0;
+    int L = 0;
+#pragma unroll
+    for (int j = 0; j < KA_MAXK; ++j) {
+        const unsigned int p = j < nk ? hist[j * 64 + lane] : 0u;
+        if (j < nk && (j == 0 || p != prev)) { scr[L * 64 + lane] = p; ++L; }
+        if (j == wave) myslot = L - 1;
+        prev = p;
+    }
+#pragma unroll
+    for (int j = 0; j < KA_MAXK; ++j) pf[j] = j < L ? scr[j * 64 + lane] : 1u;
+    int m = L;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    lmax = __builtin_amdgcn_readfirstlane(m);
+    __syncthreads();
+}
+
+// Returns (block-uniform) whether some (cell, rank) of the tile still has more than KA_CAP elements under its
+// prefix after this sweep.
 template <int BITS, int SLOTS>
-__device__ __forceinline__ void ka_pass(const float *__restrict__ col, bool cok, int n, long long M, int nk, int shift,
+__device__ __forceinline__ bool ka_pass(const float *__restrict__ col, bool cok, int n, long long M, int nk, int shift,
                                         unsigned int *hist, unsigned int &myp, unsigned int &myr, int lane, int wave, int tid)
 {
     constexpr int NB = 1 << BITS;
@@ -263,26 +292,7 @@ __device__ __forceinline__ void ka_pass(const float *__restrict__ col, bool cok,
     // match loop runs to that wave-uniform bound instead of KA_MAXK.  myslot = slot of my own rank.
     unsigned int pf[KA_MAXK];
     int lmax = 1, myslot = 0;
-    if (SLOTS > 1) {
-        // hist[j*64 + cell] holds the prefixes published by the previous narrowing
-        unsigned int *scr = hist + 1024 + wave * (KA_MAXK * 64);
-        unsigned int prev = 0;
-        int L = 0;
-#pragma unroll
-        for (int j = 0; j < KA_MAXK; ++j) {
-            const unsigned int p = j < nk ? hist[j * 64 + lane] : 0u;
-            if (j < nk && (j == 0 || p != prev)) { scr[L * 64 + lane] = p; ++L; }
-            if (j == wave) myslot = L - 1;
-            prev = p;
-        }
-#pragma unroll
-        for (int j = 0; j < KA_MAXK; ++j) pf[j] = j < L ? scr[j * 64 + lane] : 1u;
-        int m = L;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-        lmax = __builtin_amdgcn_readfirstlane(m);
-        __syncthreads();
-    }
+    if (SLOTS > 1) ka_prefixes(hist, nk, lane, wave, pf, lmax, myslot);
     for (int i = tid; i < SLOTS * NB * 32; i += 1024) hist[i] = 0u;
     __syncthreads();
 
@@ -318,6 +328,7 @@ __device__ __forceinline__ void ka_pass(const float *__restrict__ col, bool cok,
     auto cnt = [&](int row) __attribute__((always_inline)) { return (hist[ka_word(row, half)] >> sh16) & 0xffffu; };
     int bin0 = 0, bin1 = NB;
     unsigned int cum = 0;
+    bool many = false;                     // more than KA_CAP elements share my (now longer) prefix
     if (SLOTS == 1) {
         // 512 bins: 16 groups of 32 are summed by all 1024 threads first
         unsigned int gs = 0;
@@ -343,15 +354,77 @@ __device__ __forceinline__ void ka_pass(const float *__restrict__ col, bool cok,
 #pragma unroll 8
         for (int bin = bin0; bin < bin1; ++bin) {
             const unsigned int h = cnt(base + bin);
-            if (!found && cum + h > myr) { digit = (unsigned)bin; before = cum; found = true; }
+            if (!found && cum + h > myr) { digit = (unsigned)bin; before = cum; many = h > (unsigned)KA_CAP; found = true; }
             cum += h;
         }
         myp |= digit << shift;
         myr -= before;
     }
+    const bool wmany = __ballot(many) != 0;
     __syncthreads();                       // everyone is done reading the histograms
     if (shift > 0 && state) hist[wave * 64 + lane] = myp;     // publish for the next sweep's matching
+    if (lane == 0) hist[KA_FLAGS_AT + wave] = wmany;
     __syncthreads();
+    return __ballot(hist[KA_FLAGS_AT + (lane & (KA_WAVES - 1))] != 0u) != 0;
+}
+
+// Finish without further histogram sweeps once every (cell, rank) of the tile has at most KA_CAP elements left
+// under its prefix: ONE more sweep appends each surviving key to the list of its slot - the idle histogram
+// memory, list[slot][i][cell] with the fill counter in row KA_CAP - and the owner thread picks its rank from
+// the <= KA_CAP candidates by counting (k-th smallest = the smallest key with more than k keys <= it).
+// Typical data needs 9 + 6 known bits for that (two histogram sweeps + this one instead of five); heavy
+// ties never get there and take all five histogram sweeps.
+__device__ __forceinline__ int ka_list(int slot, int i, int cell) { return (slot * 32 + i) * 64 + cell; }
+
+__device__ __forceinline__ void ka_collect(const float *__restrict__ col, bool cok, int n, long long M, int nk, int known,
+                                           unsigned int *hist, unsigned int &myp, unsigned int myr, int lane, int wave, int tid)
+{
+    const unsigned int mask = ~0u << known;
+    unsigned int pf[KA_MAXK];
+    int lmax = 1, myslot = 0;
+    ka_prefixes(hist, nk, lane, wave, pf, lmax, myslot);
+    for (int i = tid; i < KA_HIST_WORDS; i += 1024) hist[i] = ((i >> 6) & 31) == KA_CAP ? 0u : 0xffffffffu;   // counters / sentinels
+    __syncthreads();
+
+    auto take = [&](float v) __attribute__((always_inline)) {
+        const unsigned int key = f2key(v), hi = key & mask;
+        int m = 0;
+#pragma unroll
+        for (int j = 0; j < KA_MAXK; ++j)
+            if (j < lmax) m = (hi == pf[j]) ? j + 1 : m;
+        if (m) {
+            const unsigned int pos = atomicAdd(&hist[ka_list(m - 1, KA_CAP, lane)], 1u);
+            hist[ka_list(m - 1, (int)pos, lane)] = key;      // pos < KA_CAP: the histogram counted these elements
+        }
+    };
+    if (cok) {
+        int i = wave;
+        for (; i + 7 * KA_WAVES < n; i += 8 * KA_WAVES) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(long long)(i + u * KA_WAVES) * M];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) take(v[u]);
+        }
+        for (; i < n; i += KA_WAVES) take(col[(long long)i * M]);
+    }
+    __syncthreads();
+
+    if (wave < nk) {
+        const int c = (int)hist[ka_list(myslot, KA_CAP, lane)];
+        int cmax = c;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+        cmax = __builtin_amdgcn_readfirstlane(cmax);
+        unsigned int ans = 0xffffffffu;
+        for (int i = 0; i < cmax; ++i) {
+            const unsigned int ki = hist[ka_list(myslot, i, lane)];          // sentinel beyond my own count
+            unsigned int le = 0;
+            for (int j = 0; j < cmax; ++j) le += hist[ka_list(myslot, j, lane)] <= ki;
+            if (i < c && le > myr) ans = min(ans, ki);
+        }
+        myp = ans;
+    }
 }
 
 __global__ void __launch_bounds__(1024, 8) kth_axis0_kernel(const float *__restrict__ s, int n, long long M, const KAList kl,
@@ -363,14 +436,16 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_kernel(const float *__restr
     const long long c0 = (long long)blockIdx.x * KA_W, c = c0 + lane;
     const bool cok = c < M;
     const float *col = s + c;
-
-    unsigned int myp = 0u, myr = wave < nk ? (unsigned)kl.k[wave] : 0u;
-    ka_pass<9, 1>(col, cok, n, M, nk, 23, hist, myp, myr, lane, wave, tid);
-    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 17, hist, myp, myr, lane, wave, tid);
-    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 11, hist, myp, myr, lane, wave, tid);
-    ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 5, hist, myp, myr, lane, wave, tid);
-    ka_pass<5, KA_MAXK>(col, cok, n, M, nk, 0, hist, myp, myr, lane, wave, tid);
-    if (wave < nk && cok) out[(long long)wave * M + c] = key2f(myp);
+    const bool state = wave < nk;
+    unsigned int myp = 0u, myr = state ? (unsigned)kl.k[wave] : 0u;
+    int known = 23;                        // lowest known bit when the tile switches from counting to collecting
+    bool many = ka_pass<9, 1>(col, cok, n, M, nk, 23, hist, myp, myr, lane, wave, tid);
+    if (many) { many = ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 17, hist, myp, myr, lane, wave, tid); known = 17; }
+    if (many) { many = ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 11, hist, myp, myr, lane, wave, tid); known = 11; }
+    if (many) { many = ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 5, hist, myp, myr, lane, wave, tid); known = 5; }
+    if (many) ka_pass<5, KA_MAXK>(col, cok, n, M, nk, 0, hist, myp, myr, lane, wave, tid);
+    else ka_collect(col, cok, n, M, nk, known, hist, myp, myr, lane, wave, tid);
+    if (state && cok) out[(long long)wave * M + c] = key2f(myp);
 }
 
 // ------------------------------------------------------------------ coverage
