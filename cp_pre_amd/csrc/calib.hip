@@ -228,28 +228,33 @@ __global__ void __launch_bounds__(1024) kth_kernel(const float *__restrict__ s, 
 }
 
 // ------------------------------------------------------------------ per-cell k-th over axis 0
-// MSD radix select over [n, M] for ALL requested ranks at once: 9 + 6 + 6 + 6 + 5 bits = 5 sweeps
-// of the tile's data, ONE launch.  A 1024-thread workgroup owns 64 adjacent cells (256 B of every
-// sample row - narrower column tiles lose DRAM efficiency fast: 128 B -> 0.7x, 64 B -> 0.3x,
+// MSD radix select over [n, M] for ALL requested ranks at once, ONE launch: histogram sweeps of 8 + 6 + 6 + 6 + 6
+// bits until every (cell, rank) of the tile has <= KA_CAP elements left under its prefix, then one collecting
+// sweep and a rank count over the survivors (ka_collect) - 3 sweeps on typical data up to n ~ 2000, 4 at
+// n = 4096, all 5 histogram sweeps only under heavy ties.  A 1024-thread workgroup owns 64 adjacent cells
+// (256 B of every sample row - narrower column tiles lose DRAM efficiency fast: 128 B -> 0.7x, 64 B -> 0.3x,
 // tools/exp/colread.hip): lane = cell everywhere.
 //   sweep:  one wave = one row, so the 64 LDS atomics of a wave-instruction never hit the same
-//           counter.  Counters are 16 bit (n < 65536), two cells per word; histogram row r
-//           (= slot*bins + bin) is 32 words, rotated by r across the banks.  Per cell there is one
-//           histogram per *distinct* prefix among its ranks ("slot"; ranks ascend, so equal prefixes
-//           are adjacent); the first sweep has one slot and spends the LDS on 512 bins.
+//           counter.  Counters are 16 bit (n < 65536), cells c and c+32 share a word; histogram row r
+//           (= slot*bins + bin) is 32 words.  Per cell there is one histogram per *distinct* prefix among
+//           its ranks ("slot"; ranks ascend, so equal prefixes are adjacent); the first sweep has one slot.
 //   narrow: thread (cell c = tid & 63, rank j = tid >> 6) owns the state (prefix, residual rank) of
 //           its pair in registers and walks the bins of its slot serially - 640 independent walks,
-//           no cross-lane traffic (the first sweep's 512 bins are pre-summed in 16 groups by all
+//           no cross-lane traffic (the first sweep's 256 bins are pre-summed in 16 groups by all
 //           1024 threads).  New prefixes reach the sweeping waves through the idle histogram memory.
 // 80 KiB of LDS: two workgroups per CU (tools/exp/ldsocc.hip), one sweeps while the other narrows.
-// For small n the tile (n * 256 B) stays L2-resident between sweeps, so HBM sees it about once.
+// The kernel is VALU-bound (a wave64 instruction holds its SIMD16 for 4 cycles), so the work per
+// element is what is optimised: 3-instruction key, 3-instruction counter address, match loops sized to the
+// slots actually in use.  For small n the tile (n * 256 B) stays L2-resident between sweeps.
 constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16;
-constexpr int KA_HIST_WORDS = KA_MAXK * 64 * 32;          // 80 KiB; the first sweep uses 512*32 of them
-constexpr int KA_GROUPS_AT = 512 * 32;                    // 16 x 64 group sums of the first sweep live here
+constexpr int KA_HIST_WORDS = KA_MAXK * 64 * 32;          // 80 KiB; the first sweep uses 256*32 of them
+constexpr int KA_GROUPS_AT = 256 * 32;                    // 16 x 64 group sums of the first sweep live here
 constexpr int KA_FLAGS_AT = 1008, KA_CAP = 31;            // per-wave "many survivors" flags (640..1023 is never used otherwise)
 struct KAList { int nk; int k[KA_MAXK]; };
 
-__device__ __forceinline__ int ka_word(int row, int half) { return row * 32 + ((half + row) & 31); }
+// counter of (histogram row, cell): cells c and c+32 share a word (16-bit halves), so the 32 lanes the LDS serves
+// per cycle always hit 32 different banks whatever rows they address - no rotation needed, 3 address ops
+__device__ __forceinline__ int ka_word(int row, int lane31) { return row * 32 + lane31; }
 
 // My cell's DISTINCT prefixes (published in hist[j*64 + cell] by the previous narrowing), compacted to the
 // front: slot i = i-th distinct prefix (ranks ascend, so equal prefixes are adjacent); unused entries hold the
@@ -277,6 +282,45 @@ __device__ __forceinline__ void ka_prefixes(unsigned int *hist, int nk, int lane
     __syncthreads();
 }
 
+template <int N> struct ka_ic { static constexpr int value = N; };
+
+// slot (1-based) whose prefix equals hi, 0 if none; LM = static bound on the number of slots in use
+template <int LM>
+__device__ __forceinline__ int ka_match(unsigned int hi, const unsigned int (&pf)[KA_MAXK])
+{
+    int m = 0;
+#pragma unroll
+    for (int j = 0; j < LM; ++j) m = (hi == pf[j]) ? j + 1 : m;
+    return m;
+}
+
+// rows wave, wave+16, ... of my cell, eight loads in flight
+template <class F>
+__device__ __forceinline__ void ka_sweep(const float *__restrict__ col, bool cok, int n, long long M, int wave, F &&f)
+{
+    if (!cok) return;
+    int i = wave;
+    for (; i + 7 * KA_WAVES < n; i += 8 * KA_WAVES) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = col[(long long)(i + u * KA_WAVES) * M];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) f(v[u]);
+    }
+    for (; i < n; i += KA_WAVES) f(col[(long long)i * M]);
+}
+
+// the match against the cell's prefixes costs 2 VALU instructions per slot and element: instantiate the sweep for
+// a few static slot counts and branch (wave-uniformly) on the tile's actual maximum
+template <class G>
+__device__ __forceinline__ void ka_by_slots(int lmax, G &&g)
+{
+    if (lmax <= 2) g(ka_ic<2>{});
+    else if (lmax <= 4) g(ka_ic<4>{});
+    else if (lmax <= 7) g(ka_ic<7>{});
+    else g(ka_ic<KA_MAXK>{});
+}
+
 // Returns (block-uniform) whether some (cell, rank) of the tile still has more than KA_CAP elements under its
 // prefix after this sweep.
 template <int BITS, int SLOTS>
@@ -296,31 +340,20 @@ __device__ __forceinline__ bool ka_pass(const float *__restrict__ col, bool cok,
     for (int i = tid; i < SLOTS * NB * 32; i += 1024) hist[i] = 0u;
     __syncthreads();
 
-    const unsigned int inc = 1u << (16 * (lane & 1));
-    const int half = lane >> 1, sh16 = 16 * (lane & 1);
-    auto count = [&](float v) __attribute__((always_inline)) {
-        const unsigned int key = f2key(v);
-        const int dig = (int)((key >> shift) & (NB - 1));
-        int m = 1;
-        if (SLOTS > 1) {
-            const unsigned int hi = key & mask;
-            m = 0;
-#pragma unroll
-            for (int j = 0; j < KA_MAXK; ++j)
-                if (j < lmax) m = (hi == pf[j]) ? j + 1 : m;
-        }
-        if (m) atomicAdd(&hist[ka_word((m - 1) * NB + dig, half)], inc);
-    };
-    if (cok) {
-        int i = wave;
-        for (; i + 7 * KA_WAVES < n; i += 8 * KA_WAVES) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = col[(long long)(i + u * KA_WAVES) * M];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) count(v[u]);
-        }
-        for (; i < n; i += KA_WAVES) count(col[(long long)i * M]);
+    const unsigned int inc = 1u << (16 * (lane >> 5));
+    const int half = lane & 31, sh16 = 16 * (lane >> 5);
+    if (SLOTS == 1) {
+        ka_sweep(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+            atomicAdd(&hist[ka_word((int)((f2key(v) >> shift) & (NB - 1)), half)], inc);
+        });
+    } else {
+        ka_by_slots(lmax, [&](auto lm) __attribute__((always_inline)) {
+            ka_sweep(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+                const unsigned int key = f2key(v);
+                const int m = ka_match<decltype(lm)::value>(key & mask, pf);
+                if (m) atomicAdd(&hist[ka_word((m - 1) * NB + (int)((key >> shift) & (NB - 1)), half)], inc);
+            });
+        });
     }
     __syncthreads();
 
@@ -330,21 +363,22 @@ __device__ __forceinline__ bool ka_pass(const float *__restrict__ col, bool cok,
     unsigned int cum = 0;
     bool many = false;                     // more than KA_CAP elements share my (now longer) prefix
     if (SLOTS == 1) {
-        // 512 bins: 16 groups of 32 are summed by all 1024 threads first
+        // first sweep (one slot, NB bins): 16 groups of NB/16 bins are summed by all 1024 threads first
+        constexpr int GB = NB / KA_WAVES;
         unsigned int gs = 0;
 #pragma unroll 8
-        for (int u = 0; u < 32; ++u) gs += cnt(wave * 32 + u);
+        for (int u = 0; u < GB; ++u) gs += cnt(wave * GB + u);
         hist[KA_GROUPS_AT + wave * 64 + lane] = gs;
         __syncthreads();
         if (state) {
             int g = 0;
-            for (; g < 15; ++g) {
+            for (; g < KA_WAVES - 1; ++g) {
                 const unsigned int x = hist[KA_GROUPS_AT + g * 64 + lane];
                 if (cum + x > myr) break;
                 cum += x;
             }
-            bin0 = g * 32;
-            bin1 = bin0 + 32;
+            bin0 = g * GB;
+            bin1 = bin0 + GB;
         }
     }
     if (state) {
@@ -386,28 +420,16 @@ __device__ __forceinline__ void ka_collect(const float *__restrict__ col, bool c
     for (int i = tid; i < KA_HIST_WORDS; i += 1024) hist[i] = ((i >> 6) & 31) == KA_CAP ? 0u : 0xffffffffu;   // counters / sentinels
     __syncthreads();
 
-    auto take = [&](float v) __attribute__((always_inline)) {
-        const unsigned int key = f2key(v), hi = key & mask;
-        int m = 0;
-#pragma unroll
-        for (int j = 0; j < KA_MAXK; ++j)
-            if (j < lmax) m = (hi == pf[j]) ? j + 1 : m;
-        if (m) {
-            const unsigned int pos = atomicAdd(&hist[ka_list(m - 1, KA_CAP, lane)], 1u);
-            hist[ka_list(m - 1, (int)pos, lane)] = key;      // pos < KA_CAP: the histogram counted these elements
-        }
-    };
-    if (cok) {
-        int i = wave;
-        for (; i + 7 * KA_WAVES < n; i += 8 * KA_WAVES) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = col[(long long)(i + u * KA_WAVES) * M];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) take(v[u]);
-        }
-        for (; i < n; i += KA_WAVES) take(col[(long long)i * M]);
-    }
+    ka_by_slots(lmax, [&](auto lm) __attribute__((always_inline)) {
+        ka_sweep(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+            const unsigned int key = f2key(v);
+            const int m = ka_match<decltype(lm)::value>(key & mask, pf);
+            if (m) {
+                const unsigned int pos = atomicAdd(&hist[ka_list(m - 1, KA_CAP, lane)], 1u);
+                hist[ka_list(m - 1, (int)pos, lane)] = key;      // pos < KA_CAP: the histogram counted these elements
+            }
+        });
+    });
     __syncthreads();
 
     if (wave < nk) {
@@ -438,13 +460,15 @@ __global__ void __launch_bounds__(1024, 8) kth_axis0_kernel(const float *__restr
     const float *col = s + c;
     const bool state = wave < nk;
     unsigned int myp = 0u, myr = state ? (unsigned)kl.k[wave] : 0u;
-    int known = 23;                        // lowest known bit when the tile switches from counting to collecting
-    bool many = ka_pass<9, 1>(col, cok, n, M, nk, 23, hist, myp, myr, lane, wave, tid);
-    if (many) { many = ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 17, hist, myp, myr, lane, wave, tid); known = 17; }
-    if (many) { many = ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 11, hist, myp, myr, lane, wave, tid); known = 11; }
-    if (many) { many = ka_pass<6, KA_MAXK>(col, cok, n, M, nk, 5, hist, myp, myr, lane, wave, tid); known = 5; }
-    if (many) ka_pass<5, KA_MAXK>(col, cok, n, M, nk, 0, hist, myp, myr, lane, wave, tid);
-    else ka_collect(col, cok, n, M, nk, known, hist, myp, myr, lane, wave, tid);
+    // 8 + 6 + 6 + 6 + 6 bits; stop counting as soon as the survivors fit the lists
+    int known = 24;                        // lowest known bit so far
+    bool many = ka_pass<8, 1>(col, cok, n, M, nk, 24, hist, myp, myr, lane, wave, tid);
+#pragma unroll 1
+    for (int shift = 18; many && shift >= 0; shift -= 6) {
+        many = ka_pass<6, KA_MAXK>(col, cok, n, M, nk, shift, hist, myp, myr, lane, wave, tid);
+        known = shift;
+    }
+    if (known > 0) ka_collect(col, cok, n, M, nk, known, hist, myp, myr, lane, wave, tid);   // else all 32 bits are counted
     if (state && cok) out[(long long)wave * M + c] = key2f(myp);
 }
 

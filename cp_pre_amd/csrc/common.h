@@ -26,8 +26,8 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks)
 // Order-preserving map fp32 -> uint32 (ascending floats <-> ascending uints), and back.
 __device__ __forceinline__ uint32_t f2key(float f)
 {
-    uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    const uint32_t u = __float_as_uint(f);
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);      // negative: flip all bits; else: set the sign bit
 }
 __device__ __forceinline__ float key2f(uint32_t k)
 {
