@@ -122,6 +122,30 @@ def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
         _lib.load_fft()
 
 
+def test_compat_import_paths_resolve_to_the_product_classes():
+    """cp_pre_amd/compat on sys.path gives the reference's own import lines (INTEGRATION.md level 1)."""
+    import importlib
+    import sys
+    from cp_pre_amd import residuals
+    compat = os.path.join(ROOT, "cp_pre_amd", "compat")
+    sys.path.insert(0, compat)
+    try:
+        names = ["Utils.ConvOps_2d", "Utils.ConvOps_1d", "Utils.VectorConvOps", "Utils.ConvOps_Spatial", "Utils.boundary_conditions",
+                 "Utils.VectorConvOps_Spatial", "Neural_PDE.UQ.inductive_cp", "ConvOps_2d", "ConvOps_1d", "PRE_estimations"]
+        mods = {n: importlib.import_module(n) for n in names}
+        assert mods["Utils.ConvOps_2d"].ConvOperator is Conv2D and mods["ConvOps_2d"].ConvOperator is Conv2D
+        assert mods["Utils.ConvOps_1d"].ConvOperator is Conv1D and mods["ConvOps_1d"].ConvOperator is Conv1D
+        assert mods["PRE_estimations"].PRE_NS is residuals.PRE_NS
+        for fn in ("calibrate", "modulation_func", "ncf_metric_joint", "emp_cov", "emp_cov_joint"):
+            assert getattr(mods["Neural_PDE.UQ.inductive_cp"], fn) is getattr(icp, fn)
+        for cls in ("Divergence", "Gradient", "Curl", "Laplace", "dot", "cross", "vectorize"):
+            assert hasattr(mods["Utils.VectorConvOps"], cls)
+    finally:
+        sys.path.remove(compat)
+        for n in [k for k in sys.modules if k.split(".")[0] in ("Utils", "Neural_PDE", "ConvOps_2d", "ConvOps_1d", "PRE_estimations")]:
+            del sys.modules[n]
+
+
 def test_rank_arithmetic_matches_numpy_higher():
     for n in (7, 100, 256, 4096, 8192, 65536):
         for a in oc.ALPHA_LEVELS:
