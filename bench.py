@@ -244,6 +244,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
         group = dist.group.WORLD
+        # create the communicator (and its xGMI rings) now, not inside the first timed collective
+        warm = torch.zeros(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(warm)
+        dist.all_gather([torch.empty_like(warm) for _ in range(dist.get_world_size())], warm)
+        torch.cuda.synchronize()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     if args.config != "c3":
