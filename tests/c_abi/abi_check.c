@@ -1,0 +1,141 @@
+/* A C99 client of libcp_pre_hip.so: no Python, no torch - only the HIP runtime for device memory.
+ * Shows what a maintainer binding the library from another language sees, and checks each call
+ * against plain C loops written here (the reference's arithmetic: zero-padded cross-correlation,
+ * Utils/ConvOps_2d.py:149; the NS momentum expression, Marginal/NS_Residuals_CP.py:231-240; an order
+ * statistic per cell).  Built and run by tests/test_gpu_parity.py::test_c_abi_client.  Exit code 0 = all ok.
+ *
+ *   hipcc -x c tests/c_abi/abi_check.c -Iinclude -Lcp_pre_amd -lcp_pre_hip -Wl,-rpath,$PWD/cp_pre_amd -o abi_check
+ */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cp_pre_hip.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d at %s:%d\n", (int)e_, __FILE__, __LINE__); return 2; } } while (0)
+#define EXPECT(cond, what) do { if (!(cond)) { printf("FAIL: %s (%s:%d)\n", what, __FILE__, __LINE__); ++failures; } else { printf("ok:   %s\n", what); } } while (0)
+
+enum { B = 3, T = 6, X = 10, Y = 64, N = B * T * X * Y };
+
+static float frand(unsigned *s) { *s = *s * 1664525u + 1013904223u; return (float)(*s >> 8) / 16777216.0f + 0.5f; }
+
+/* zero-padded cross-correlation with a dense 3x3x3 kernel, axes (Nt,Nx,Ny) */
+static void xcorr27(const float *f, const float *K, float *out)
+{
+    for (int b = 0; b < B; ++b) for (int t = 0; t < T; ++t) for (int x = 0; x < X; ++x) for (int y = 0; y < Y; ++y) {
+        double acc = 0.0;
+        for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) for (int d = 0; d < 3; ++d) {
+            const int tt = t + a - 1, xx = x + c - 1, yy = y + d - 1;
+            if (tt >= 0 && tt < T && xx >= 0 && xx < X && yy >= 0 && yy < Y)
+                acc += (double)K[(a * 3 + c) * 3 + d] * f[((b * T + tt) * X + xx) * Y + yy];
+        }
+        out[((b * T + t) * X + x) * Y + y] = (float)acc;
+    }
+}
+
+static double rel_err(const float *a, const float *b, int n)
+{
+    double num = 0.0, den = 0.0;
+    for (int i = 0; i < n; ++i) { const double d = fabs((double)a[i] - b[i]); if (d > num) num = d; if (fabs(b[i]) > den) den = fabs(b[i]); }
+    return den > 0 ? num / den : num;
+}
+
+static int cmp_float(const void *a, const void *b) { const float x = *(const float *)a, y = *(const float *)b; return (x > y) - (x < y); }
+
+int main(void)
+{
+    int failures = 0;
+    EXPECT(pre_abi_version() == 2, "pre_abi_version() == 2");
+
+    /* ---- the reference's kernels: kernel_3d(stencil, axis) with the stencil on slab 1 (Utils/ConvOps_2d.py:67-79) */
+    float Kt[27] = {0}, Kx[27] = {0}, Ky[27] = {0}, Kl[27] = {0};
+    Kt[(0 * 3 + 1) * 3 + 1] = -1.f; Kt[(2 * 3 + 1) * 3 + 1] = 1.f;               /* 't', 1                        */
+    Kx[(1 * 3 + 0) * 3 + 1] = -1.f; Kx[(1 * 3 + 2) * 3 + 1] = 1.f;               /* 'x', 1                        */
+    memcpy(Ky, Kt, sizeof Kt);                                                     /* 'y', 1 == 't', 1 (:72-73)     */
+    Kl[(1 * 3 + 0) * 3 + 1] = Kl[(1 * 3 + 2) * 3 + 1] = Kl[(1 * 3 + 1) * 3 + 0] = Kl[(1 * 3 + 1) * 3 + 2] = 1.f;
+    Kl[(1 * 3 + 1) * 3 + 1] = -4.f;                                                /* ('x','y'), 2                  */
+
+    static float hu[N], hv[N], hp[N], want[N], got[N], tmp[10][N];
+    unsigned seed = 12345u;
+    for (int i = 0; i < N; ++i) { hu[i] = frand(&seed); hv[i] = frand(&seed); hp[i] = frand(&seed); }
+    float *du, *dv, *dp, *dout;
+    CHECK_HIP(hipMalloc((void **)&du, sizeof hu)); CHECK_HIP(hipMalloc((void **)&dv, sizeof hv));
+    CHECK_HIP(hipMalloc((void **)&dp, sizeof hp)); CHECK_HIP(hipMalloc((void **)&dout, sizeof got));
+    CHECK_HIP(hipMemcpy(du, hu, sizeof hu, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(dv, hv, sizeof hv, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(dp, hp, sizeof hp, hipMemcpyHostToDevice));
+    hipStream_t st;
+    CHECK_HIP(hipStreamCreate(&st));
+    const pre_field_t fu = {du, (int64_t)T * X * Y, (int64_t)X * Y, Y, 1}, fv = {dv, (int64_t)T * X * Y, (int64_t)X * Y, Y, 1},
+                      fp = {dp, (int64_t)T * X * Y, (int64_t)X * Y, Y, 1};
+    const pre_out_t fo = {dout, (int64_t)T * X * Y, (int64_t)X * Y, Y, 1};
+
+    /* ---- a4: ConvOperator.convolution with the Laplacian as a tap list, then with PRE_FLAG_ABS */
+    {
+        float w[5] = {1.f, 1.f, -4.f, 1.f, 1.f};
+        int32_t off[15] = {0, -1, 0, 0, 0, -1, 0, 0, 0, 0, 0, 1, 0, 1, 0};
+        int rc = pre_stencil3d_f32(&fu, &fo, w, off, 5, B, T, X, Y, 0, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        xcorr27(hu, Kl, want);
+        EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-5, "pre_stencil3d_f32: 5-point Laplacian vs C loops (<= 1e-5)");
+        rc = pre_stencil3d_f32(&fu, &fo, w, off, 5, B, T, X, Y, PRE_FLAG_ABS, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; ++i) want[i] = fabsf(want[i]);
+        EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-5, "pre_stencil3d_f32: PRE_FLAG_ABS epilogue");
+    }
+
+    /* ---- a9: fused NS momentum residual vs the operator-by-operator expression */
+    {
+        const float dt = 0.01f, dx = 0.1f, dy = 0.2f, nu = 0.001f;
+        int rc = pre_residual_ns_momentum_f32(&fu, &fv, &fp, &fo, Kt, Kx, Ky, Kl, dt, dx, dy, nu, B, T, X, Y, 0, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        xcorr27(hu, Kt, tmp[0]); xcorr27(hu, Kx, tmp[1]); xcorr27(hu, Ky, tmp[2]); xcorr27(hu, Kl, tmp[3]); xcorr27(hp, Kx, tmp[4]);
+        xcorr27(hv, Kt, tmp[5]); xcorr27(hv, Kx, tmp[6]); xcorr27(hv, Ky, tmp[7]); xcorr27(hv, Kl, tmp[8]); xcorr27(hp, Ky, tmp[9]);
+        for (int i = 0; i < N; ++i) {
+            const float rx = tmp[0][i] * dx * dy + hu[i] * tmp[1][i] * dt * dy + hv[i] * tmp[2][i] * dt * dx - nu * tmp[3][i] * dt + tmp[4][i] * dt * dy;
+            const float ry = tmp[5][i] * dx * dy + hu[i] * tmp[6][i] * dt * dx + hv[i] * tmp[7][i] * dt * dy - nu * tmp[8][i] * dt + tmp[9][i] * dt * dx;
+            want[i] = rx + ry;
+        }
+        EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-5, "pre_residual_ns_momentum_f32 vs operator-by-operator C loops (<= 1e-5)");
+        float Kbad[27];
+        memcpy(Kbad, Kl, sizeof Kl);
+        Kbad[0] = 1.f;                                                             /* a corner tap: off the star */
+        rc = pre_residual_ns_momentum_f32(&fu, &fv, &fp, &fo, Kt, Kx, Ky, Kbad, dt, dx, dy, nu, B, T, X, Y, 0, st);
+        EXPECT(rc == PRE_E_UNSUPPORTED, "fused residual declines a non-star kernel with PRE_E_UNSUPPORTED");
+    }
+
+    /* ---- a10/a11: |u - v| scores and the per-cell order statistics, exact */
+    {
+        enum { n = B * T, M = X * Y };                                             /* view the field as [n, M] scores */
+        CHECK_HIP(hipStreamSynchronize(st));
+        int rc = pre_absdiff_f32(du, dv, dout, N, st);
+        int32_t ks[3] = {0, n / 2, n - 1};
+        float *dq;
+        static float hq[3 * M], col[n];
+        CHECK_HIP(hipMalloc((void **)&dq, sizeof hq));
+        int rc2 = pre_kth_axis0_f32(dout, n, M, ks, 3, dq, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(hq, dq, sizeof hq, hipMemcpyDeviceToHost));
+        int exact = 1;
+        for (int c = 0; c < M; ++c) {
+            for (int i = 0; i < n; ++i) col[i] = fabsf(hu[i * M + c] - hv[i * M + c]);
+            qsort(col, n, sizeof(float), cmp_float);
+            for (int j = 0; j < 3; ++j) exact &= (hq[j * M + c] == col[ks[j]]);
+        }
+        EXPECT(rc == PRE_OK && rc2 == PRE_OK && exact, "pre_absdiff_f32 + pre_kth_axis0_f32: bit-exact vs qsort per cell");
+        int32_t bad[2] = {5, 2};
+        EXPECT(pre_kth_axis0_f32(dout, n, M, bad, 2, dq, st) == PRE_E_RANGE, "descending ranks -> PRE_E_RANGE");
+        EXPECT(pre_kth_axis0_f32(NULL, n, M, ks, 3, dq, st) == PRE_E_NULL, "null pointer -> PRE_E_NULL");
+        CHECK_HIP(hipFree(dq));
+    }
+
+    CHECK_HIP(hipStreamDestroy(st));
+    CHECK_HIP(hipFree(du)); CHECK_HIP(hipFree(dv)); CHECK_HIP(hipFree(dp)); CHECK_HIP(hipFree(dout));
+    printf(failures ? "%d check(s) FAILED\n" : "all checks passed\n", failures);
+    return failures ? 1 : 0;
+}

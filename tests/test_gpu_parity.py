@@ -702,6 +702,16 @@ def test_marginal_step_is_hip_graph_capturable(gpu):
     assert torch.equal(q, step())
 
 
+def test_c_abi_client(gpu, tmp_path):
+    """tests/c_abi/abi_check.c: a C99 program (gcc, HIP runtime only) drives the library and checks stencil,
+    fused NS residual, |a-b| and per-cell order statistics against its own C loops, plus the error codes."""
+    import subprocess
+    from test_host_cpu import _build_c_client
+    exe = _build_c_client(tmp_path / "abi_check")
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "all checks passed" in run.stdout, run.stdout + run.stderr
+
+
 def test_graft_smoke(gpu):
     import __graft_entry__ as ge
     ge.smoke()

@@ -110,6 +110,24 @@ def test_no_cpu_fallback_without_gpu():
         icp.calibrate(np.zeros(5, np.float32), 5, 0.5)
 
 
+def _build_c_client(out):
+    """gcc -std=c99: the header and the library are consumable from plain C (no C++, no torch)."""
+    import subprocess
+    lib = os.path.join(ROOT, "cp_pre_amd")
+    for h in ("cp_pre_hip.h", "cp_pre_fft.h"):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c",
+                               os.path.join(ROOT, "include", h)])
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "c_abi", "abi_check.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-L" + lib, "-lcp_pre_hip", "-L/opt/rocm/lib",
+                           "-lamdhip64", "-lm", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", str(out)])
+    return str(out)
+
+
+def test_c99_client_compiles_and_links(tmp_path):
+    _lib.load()                                     # the library must exist (built by __graft_entry__.build())
+    assert os.path.exists(_build_c_client(tmp_path / "abi_check"))
+
+
 def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
     """No silent fallback when libcp_pre_hip.so / libcp_pre_fft.so are absent: loading raises ImportError."""
     monkeypatch.setattr(_lib, "_lib", None)
