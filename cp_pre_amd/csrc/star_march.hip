@@ -440,7 +440,7 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const 
     g.tSeg = tSeg;
     g.nTSeg = (g.T + tSeg - 1) / tSeg;
     tiles *= g.nTSeg;
-    if (tiles <= 0 || tiles > 0x7fffffffLL) return PRE_E_SHAPE;
+    if (tiles <= 0 || tiles * TYQ > 0xffffffffLL) return PRE_E_SHAPE;      // the dispatch packet counts work-items in 32 bits
     if constexpr (BC) {
         hipLaunchKernelGGL((march_kernel<Fn, NR, TYQ, true>), dim3((unsigned)tiles), dim3(TYQ, NR), 0, st, g, prm, *bc);
     } else {
