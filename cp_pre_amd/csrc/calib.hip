@@ -449,13 +449,13 @@ __device__ __forceinline__ void ka_collect(const float *__restrict__ col, bool c
     }
 }
 
-__global__ void __launch_bounds__(1024, 8) kth_axis0_kernel(const float *__restrict__ s, int n, long long M, const KAList kl,
-                                                            float *__restrict__ out)
+__global__ void __launch_bounds__(1024, 8) kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile0,
+                                                            const KAList kl, float *__restrict__ out)
 {
     __shared__ unsigned int hist[KA_HIST_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nk = kl.nk;
-    const long long c0 = (long long)blockIdx.x * KA_W, c = c0 + lane;
+    const long long c0 = (tile0 + blockIdx.x) * KA_W, c = c0 + lane;
     const bool cok = c < M;
     const float *col = s + c;
     const bool state = wave < nk;
@@ -549,7 +549,7 @@ int pre_absdiff_f32(const float *a, const float *b, float *out, int64_t n, void 
 int pre_std_axis0_f32(const float *a, const float *b, int64_t n, int64_t M, float eps, float *mod, void *stream)
 {
     if (!a || !mod || n <= 0 || M <= 0) return PRE_E_NULL;
-    if (n > 0x7fffffff) return PRE_E_SHAPE;
+    if (n > 0x7fffffff || M > 0xffffff00LL) return PRE_E_SHAPE;        // one thread per cell, 32-bit work-item count
     hipLaunchKernelGGL(std_axis0_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), a, b, (int)n,
                        (long long)M, eps, mod);
     PRE_LAUNCH_CHECK();
@@ -560,7 +560,7 @@ int pre_moments_axis0_f64(const float *a, const float *b, int64_t n, int64_t M, 
                           double *sumsq, void *stream)
 {
     if (!a || !sum || !sumsq || n <= 0 || M <= 0 || row_stride < M) return PRE_E_NULL;
-    if (n > 0x7fffffff) return PRE_E_SHAPE;
+    if (n > 0x7fffffff || M > 0xffffff00LL) return PRE_E_SHAPE;        // one thread per cell, 32-bit work-item count
     const long long bx = (M + 255) / 256;
     // enough workgroups to fill 256 CUs even when M is small: split the batch axis
     long long splits = 1;
@@ -577,6 +577,7 @@ int pre_std_from_moments_f32(const double *sum, const double *sumsq, int64_t n_t
                              void *stream)
 {
     if (!sum || !sumsq || !mod || n_total <= 0 || M <= 0) return PRE_E_NULL;
+    if (M > 0xffffff00LL) return PRE_E_SHAPE;                           // one thread per cell, 32-bit work-item count
     hipLaunchKernelGGL(std_from_moments_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), sum, sumsq,
                        (double)n_total, (long long)M, eps, mod);
     PRE_LAUNCH_CHECK();
@@ -626,14 +627,17 @@ int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *
         if (j > 0 && ks[j] < ks[j - 1]) return PRE_E_RANGE;      // ascending (slots rely on it)
     }
     const long long tiles = (M + KA_W - 1) / KA_W;
-    if (tiles > 0x7fffffffLL) return PRE_E_SHAPE;
+    const long long per_launch = 1LL << 21;                     // x 1024 threads: the dispatch packet counts work-items in 32 bits
     for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < kl.nk; ++j) kl.k[j] = ks[j0 + j];
-        hipLaunchKernelGGL(kth_axis0_kernel, dim3((unsigned)tiles), dim3(1024), 0, as_stream(stream), scores, (int)n,
-                           (long long)M, kl, out + (long long)j0 * M);
-        PRE_LAUNCH_CHECK();
+        for (long long t0 = 0; t0 < tiles; t0 += per_launch) {
+            const long long nt = tiles - t0 < per_launch ? tiles - t0 : per_launch;
+            hipLaunchKernelGGL(kth_axis0_kernel, dim3((unsigned)nt), dim3(1024), 0, as_stream(stream), scores, (int)n,
+                               (long long)M, t0, kl, out + (long long)j0 * M);
+            PRE_LAUNCH_CHECK();
+        }
     }
     return PRE_OK;
 }
