@@ -30,6 +30,7 @@ reference's own F.conv3d arithmetic, timed on this box's host cores; N=1 only).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -83,6 +84,27 @@ def parse():
     return args
 
 
+def synth_(field, seed, positive=False):
+    """Fill one fp32 field [B, T, X(, Y)] in place with the synthetic data of SURVEY 8(d): a smooth mode
+    sin(2 pi kx x) cos(2 pi ky y) cos(w t) plus 0.01 N(0,1) noise per cell (strictly positive U(0.5,1.5) for
+    densities / pressures).  Generated on the device, no temporary of the field's size."""
+    g = torch.Generator(device=field.device).manual_seed(seed)
+    if positive:
+        return field.uniform_(0.5, 1.5, generator=g)
+    field.normal_(0.0, 0.01, generator=g)
+    dims = field.shape[1:]
+    kx, ky, w = 1 + seed % 3, 1 + (seed // 3) % 3, 1 + (seed // 9) % 2
+    ax = [torch.linspace(0, 1, n, device=field.device) for n in dims]
+    smooth = torch.cos(2 * math.pi * w * ax[0]).reshape(-1, *([1] * (len(dims) - 1)))
+    smooth = smooth * torch.sin(2 * math.pi * kx * ax[1]).reshape(1, -1, *([1] * (len(dims) - 2)))
+    if len(dims) == 3:
+        smooth = smooth * torch.cos(2 * math.pi * ky * ax[2]).reshape(1, 1, -1)
+    return field.add_(smooth)                               # broadcast over the batch axis
+
+
+SYNTH = "synthetic smooth-plus-noise fields (sin*cos*cos mode + 0.01 N(0,1); U(0.5,1.5) for rho, p), generated on device"
+
+
 def run_secondary(args, cfg, dev, group, rank, world):
     """c1/c2/c4/c5: whole per-rank tensor resident; one step = fused residual + calibration."""
     from cp_pre_amd import inductive_cp as icp
@@ -94,17 +116,20 @@ def run_secondary(args, cfg, dev, group, rank, world):
     torch.manual_seed(1234 + rank)
     kind = cfg["kind"]
     if kind in ("advection", "burgers"):
-        u = torch.empty(B, T, X, device=dev).uniform_(0.5, 1.5)
+        u = synth_(torch.empty(B, T, X, device=dev), 100 * rank + 1)
+        u += 1.0                                            # advected / Burgers quantity of order one
         op = R.Advection(1.0, 0.005, 0.01, disc=2) if kind == "advection" else R.Burgers(2.0 / X, 1.25 / T, 0.002)
         evaluate = lambda: op.residual(u, boundary=True, absolute=absolute).unsqueeze(1)      # [B,1,T,X]
         crop, cells = (0, 1, 1), B * T * X
     elif kind == "wave":
-        u = torch.empty(B, T, X, Y, device=dev).uniform_(0.5, 1.5)
+        u = synth_(torch.empty(B, T, X, Y, device=dev), 100 * rank + 2)
         op = R.PRE_Wave(dt=0.005, dx=0.01, c=1.0)
         evaluate = lambda: op.residual(u, boundary=True, absolute=absolute)
         crop, cells = (1, 1, 1), B * T * X * Y
     else:
-        v = torch.empty(B, 6, T, X, Y, device=dev).uniform_(0.5, 1.5)
+        v = torch.empty(B, 6, T, X, Y, device=dev)              # rho, u, v, p, Bx, By (Marginal/MHD_Residuals_CP.py:225)
+        for i in range(6):
+            synth_(v[:, i], 100 * rank + 10 + i, positive=i in (0, 3))
         op = R.MHD()
         evaluate = lambda: op.residual_induction(v, boundary=True, absolute=absolute)
         crop, cells = (1, 1, 1), B * T * X * Y
@@ -150,7 +175,7 @@ def run_secondary(args, cfg, dev, group, rank, world):
             "metric": "residual-cells/s (PRE eval+calibrate)", "value": cells * world * args.steps / elapsed,
             "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic U(0.5,1.5) fields, whole per-rank tensor resident",
+            "dtype": "f32", "data": SYNTH + "; whole per-rank tensor resident",
             "config": {"workload": f"{cfg['title']} {shape} per rank, {args.mode} CP, 10 alpha levels", "mode": args.mode,
                        "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": cfg["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -272,7 +297,7 @@ def main():
     torch.manual_seed(1234 + rank)
     vars_ = torch.empty(B, 3, T, X, Y, dtype=torch.float32, device=dev)
     for i in range(3):
-        vars_[:, i].uniform_(0.5, 1.5)
+        synth_(vars_[:, i], 100 * rank + 20 + i)
     res = torch.empty(B, T, X, Y, dtype=torch.float32, device=dev)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -330,7 +355,7 @@ def main():
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic U(0.5,1.5) fields; one resident t-slab reused for the 8 slab positions",
+            "data": SYNTH + "; one resident t-slab reused for the 8 slab positions",
             "config": {"workload": f"C3 2D Navier-Stokes momentum residual [{B},{args.nt},{X},{Y}] x3 fields per rank, "
                                    f"{args.mode} CP, 10 alpha levels; streamed as {n_slabs} t-slabs of [{B},{T},{X},{Y}]",
                        "mode": args.mode, "batch_per_rank": B, "parallelism": f"batch-sharded x{world}"},
