@@ -371,28 +371,39 @@ __device__ __forceinline__ bool ka_pass(const float *__restrict__ col, bool cok,
         hist[KA_GROUPS_AT + wave * 64 + lane] = gs;
         __syncthreads();
         if (state) {
+            // group of my rank = number of groups whose inclusive running count is <= myr (branch-free: the 16
+            // LDS reads are independent and pipeline; a `break` loop serialised them behind their latency)
+            unsigned int run = 0;
             int g = 0;
-            for (; g < KA_WAVES - 1; ++g) {
-                const unsigned int x = hist[KA_GROUPS_AT + g * 64 + lane];
-                if (cum + x > myr) break;
-                cum += x;
+#pragma unroll
+            for (int u = 0; u < KA_WAVES; ++u) {
+                run += hist[KA_GROUPS_AT + u * 64 + lane];
+                const bool le = run <= myr;
+                g += le;
+                cum = le ? run : cum;
             }
+            g = min(g, KA_WAVES - 1);
             bin0 = g * GB;
             bin1 = bin0 + GB;
         }
     }
     if (state) {
-        unsigned int digit = (unsigned)(bin1 - 1), before = cum;
-        bool found = false;
+        // digit = number of bins (from bin0) whose inclusive running count is <= myr; `cum` ends as the count
+        // before the chosen bin.  Branch-free for the same reason as above.
         const int base = (SLOTS == 1 ? 0 : myslot) * NB;
+        unsigned int run = cum;
+        int d = 0;
 #pragma unroll 8
         for (int bin = bin0; bin < bin1; ++bin) {
-            const unsigned int h = cnt(base + bin);
-            if (!found && cum + h > myr) { digit = (unsigned)bin; before = cum; many = h > (unsigned)KA_CAP; found = true; }
-            cum += h;
+            run += cnt(base + bin);
+            const bool le = run <= myr;
+            d += le;
+            cum = le ? run : cum;
         }
-        myp |= digit << shift;
-        myr -= before;
+        const int digit = bin0 + min(d, bin1 - bin0 - 1);
+        many = cnt(base + digit) > (unsigned)KA_CAP;
+        myp |= (unsigned)digit << shift;
+        myr -= cum;
     }
     const bool wmany = __ballot(many) != 0;
     __syncthreads();                       // everyone is done reading the histograms
