@@ -6,6 +6,8 @@ Tolerances (north_star): residual tensors within 1e-5 tensor-scale relative erro
 (max|a-b|/max|b|, SURVEY.md 7 'hard parts'); conformal q-hat within 1e-6 relative - and in
 fact bit-exact wherever the scores are bit-exact, because a radix select returns an input.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1041,3 +1043,56 @@ def test_full_size_properties_c2(gpu):
     for j in (0, 4, 9):
         cov = icp.emp_cov_joint([-(qj[j] * mod)[1:-1, 1:-1, 1:-1], (qj[j] * mod)[1:-1, 1:-1, 1:-1]], inner)
         assert cov >= (icp.kth_index(n, n, alphas[j]) + 1) / n - 2.0 / n    # knife-edge samples sit exactly on the bound
+
+
+def _sharded_worker(rank, world, port, n_local, shape, out_dir):
+    """One of two ranks sharing cuda:0 (gloo rendezvous; RCCL refuses two ranks per device): the product back end
+    (pipeline.HipOps) under batch sharding."""
+    import torch.distributed as dist
+    from cp_pre_amd import pipeline
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        full = torch.from_numpy(np.load(os.path.join(out_dir, "res.npy")))
+        mine = full[rank * n_local:(rank + 1) * n_local].to(dev)
+        alphas = [0.1, 0.3, 0.5, 0.7, 0.9]
+        jc = pipeline.JointCalibration(n_local, dev, group=dist.group.WORLD)
+        T = shape[0]
+        for s in range(2):                                              # two t-slabs with halo planes
+            jc.add_slab(mine[:, s * (T - 2) // 2:s * (T - 2) // 2 + (T - 2) // 2 + 2].contiguous(), crop=(1, 1, 1))
+        q = jc.finish(alphas)
+        qm = pipeline.marginal_qhat(mine.abs().contiguous(), alphas, group=dist.group.WORLD, stage_bytes=4 * n_local * world * 1000)
+        np.save(os.path.join(out_dir, f"q_{rank}.npy"), q.cpu().numpy())
+        np.save(os.path.join(out_dir, f"qm_{rank}.npy"), qm.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_calibration_two_ranks_on_one_gpu(gpu, tmp_path):
+    """Joint (all-reduce of moments + all-gather of scores) and marginal (all-to-all in bounded runs) calibration
+    with the HIP back end on two batch shards == the single-process result on the whole batch."""
+    import socket
+    import torch.multiprocessing as mp
+    from cp_pre_amd import pipeline
+    world, n_local, shape = 2, 48, (10, 12, 64)
+    rng = np.random.default_rng(5)
+    res = (rng.standard_normal((world * n_local,) + shape) * (1 + rng.random(shape))).astype(np.float32)
+    np.save(tmp_path / "res.npy", res)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sharded_worker, args=(world, port, n_local, shape, str(tmp_path)), nprocs=world, join=True)
+    alphas = [0.1, 0.3, 0.5, 0.7, 0.9]
+    whole = torch.from_numpy(res).to(gpu)
+    jc = pipeline.JointCalibration(world * n_local, gpu)
+    T = shape[0]
+    for s in range(2):
+        jc.add_slab(whole[:, s * (T - 2) // 2:s * (T - 2) // 2 + (T - 2) // 2 + 2].contiguous(), crop=(1, 1, 1))
+    q_ref = jc.finish(alphas).cpu().numpy()
+    qm_ref = pipeline.marginal_qhat(whole.abs().contiguous(), alphas).cpu().numpy()
+    for r in range(world):
+        q = np.load(tmp_path / f"q_{r}.npy")
+        assert np.max(np.abs(q - q_ref) / np.abs(q_ref)) <= 1e-6, (q, q_ref)       # fp64 moments, different summation split
+        assert np.array_equal(np.load(tmp_path / f"qm_{r}.npy"), qm_ref)           # order statistics: exact
