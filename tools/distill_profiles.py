@@ -84,11 +84,17 @@ if ("FETCH_SIZE", MK) in pm and ("WRITE_SIZE", MK) in pm:
                "source": f"{out}/pmc_hbm_c3.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 gfx950 correction)"},
               open(f"{out}/pmc_hbm_c3.json", "w"), indent=1)
 
-sq = {**counters("sq1"), **counters("sq2")}
-if sq:
-    with open(f"{out}/pmc_sq_c3.txt", "w") as o:
-        o.write("rocprofv3 --pmc <SQ counters, two passes> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --batch 1024\n"
-                "(C3 joint, quarter batch: [1024,10,512,512] per launch; per-dispatch sums over all SEs/XCDs, averaged over dispatches)\n\n")
+for tag, srcs, mode in (("pmc_sq_c3.txt", ("sq1", "sq2"), "joint"), ("pmc_sq_c3_marginal.txt", ("sq1m", "sq2m", "fetchm"), "marginal")):
+    sq = {}
+    for src in srcs:
+        sq.update(counters(src))
+    if not sq:
+        continue
+    with open(f"{out}/{tag}", "w") as o:
+        o.write(f"rocprofv3 --pmc <counters, one group per pass> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --batch 1024"
+                f"{' --mode marginal' if mode == 'marginal' else ''}\n"
+                f"(C3 {mode}, quarter batch: [1024,10,512,512] per launch; per-dispatch sums over all SEs/XCDs, averaged over dispatches;\n"
+                f" FETCH_SIZE in KiB, x2 for bytes on gfx950)\n\n")
         kernels = sorted({k for (_, k) in sq if k.startswith(OURS)})
         for k in kernels:
             o.write(k + "\n")

@@ -21,6 +21,10 @@ run write    --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write" -
 # SQ counters on a quarter batch (same per-wave behaviour, shorter run); one small group per pass
 run sq1      --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d "$P/sq1" -- $B --steps 1 --warmup 0 --batch 1024
 run sq2      --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d "$P/sq2" -- $B --steps 1 --warmup 0 --batch 1024
+# the per-cell select (marginal mode): instruction mix and HBM fetch, quarter batch
+run sq1m     --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d "$P/sq1m" -- $B --steps 1 --warmup 0 --batch 1024 --mode marginal
+run sq2m     --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d "$P/sq2m" -- $B --steps 1 --warmup 0 --batch 1024 --mode marginal
+run fetchm   --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetchm" -- $B --steps 1 --warmup 0 --batch 1024 --mode marginal
 for c in c2 c4 c5; do
     run trace_$c --kernel-trace --stats --output-format csv -d "$P/trace_$c" -- $B --config $c --steps 3 --warmup 1
 done
