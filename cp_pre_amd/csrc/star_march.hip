@@ -33,6 +33,7 @@ struct Geom {
                                  // (the <= 3 remaining columns of an odd-width grid go to the generic kernel)
     int tSeg, nTSeg, nXT, nYT;
     int flags;
+    int flat;                    // 1: short contiguous axis merged with the next one (flat_march_kernel)
 };
 
 // c, t-, t+, x-, x+, y-, y+
@@ -451,9 +452,147 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const 
     }
 }
 
+// ------------------------------------------------------------------ flat form: short contiguous axis
+// Kernel axes (t, x, y) with a SHORT y extent Ty whose rows follow each other in memory (x stride == Ty): the
+// (x, y) plane is one contiguous row of L = X*Ty cells.  A workgroup owns a chunk of 512 quads of that merged
+// row and marches over t exactly as above (register window, prefetch), but the neighbours within the plane are
+// all taken from the flat LDS copy of the chunk (+ a halo of 16 quads per side):
+//   x -/+  =  Ty cells back / ahead in the merged row (beyond the row = the zero padding of x = -1 / X),
+//   y -/+  =  the previous / next cell, masked where that cell belongs to the neighbouring x row (y = -1 / Ty).
+// Every lane works whatever Ty is, and Ty itself need not be a multiple of 4 (only L).  Used for the surrogate's
+// native Nt-fastest layout with Nt < 64 (after the axis relabelling: t = Nx, x = Ny, y = Nt).
+constexpr int FLAT_NT = 512, FLAT_H = 16;
+
+template <class Fn>
+__global__ void __launch_bounds__(FLAT_NT, MinWaves<Fn>::value)
+flat_march_kernel(const Geom g, const typename Fn::Params prm)
+{
+    constexpr int F = Fn::F;
+    __shared__ float4 lds[2][F][FLAT_NT + 2 * FLAT_H];
+    const int q = threadIdx.x;
+    unsigned Lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int ch = Lb % g.nYT; Lb /= g.nYT;
+    const int ts = Lb % g.nTSeg;
+    const int b = Lb / g.nTSeg;
+    const int Ty = g.Y, L = g.X * g.Y;
+    const int m0 = ch * FLAT_NT * 4, m = m0 + 4 * q;
+    const bool inb = m < L;
+    const int t0 = ts * g.tSeg, t1 = min(t0 + g.tSeg, g.T);
+
+    // halo duty: the first / last FLAT_H threads fetch one quad left / right of the chunk (L % 4 == 0: a quad is
+    // entirely inside the row or entirely padding)
+    const bool hl = q < FLAT_H, hr = q >= FLAT_NT - FLAT_H;
+    const int hm = hl ? m0 - 4 * FLAT_H + 4 * q : m0 + 4 * FLAT_NT + 4 * (q - (FLAT_NT - FLAT_H));
+    const bool hok = (hl || hr) && hm >= 0 && hm < L;
+    const int hslot = hl ? q : q + 2 * FLAT_H;      // right halo quad k sits at FLAT_H + FLAT_NT + k, k = q - (FLAT_NT - FLAT_H)
+
+    // which of my four cells have a y- / y+ neighbour inside their own x row
+    bool lok[4], rok[4];
+    {
+        int ph = m % Ty;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lok[j] = ph != 0;
+            rok[j] = ph != Ty - 1;
+            ph = ph + 1 == Ty ? 0 : ph + 1;
+        }
+    }
+
+    const float *own[F], *hal[F];
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        const float *base = g.f[i] + (long long)b * g.sB[i];
+        own[i] = base + m;
+        hal[i] = base + hm;
+    }
+    float *outp = g.out + (long long)b * g.oB + m;
+    const long long oT = g.oT;
+
+    auto load_own = [&](int t, float4(&dst)[F]) __attribute__((always_inline)) {
+        const bool ok = inb && (t >= 0) && (t < g.T);
+#pragma unroll
+        for (int i = 0; i < F; ++i) dst[i] = ok ? ldg4(own[i] + (long long)t * g.sT[i]) : f4(0.f);
+    };
+    auto load_halo = [&](int t, float4(&dst)[F]) __attribute__((always_inline)) {
+        const bool ok = hok && (t >= 0) && (t < g.T);
+#pragma unroll
+        for (int i = 0; i < F; ++i) dst[i] = ok ? ldg4(hal[i] + (long long)t * g.sT[i]) : f4(0.f);
+    };
+
+    auto step = [&](int t, float4(&P)[F], float4(&C)[F], float4(&N)[F], float4(&D)[F], float4(&hc)[F],
+                    float4(&hn)[F]) __attribute__((always_inline)) {
+        const int bi = (t - t0) & 1;
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            lds[bi][i][FLAT_H + q] = C[i];
+            if (hl || hr) lds[bi][i][hslot] = hc[i];
+        }
+        load_halo(t + 1, hn);
+        load_own(t + 2, D);
+        lds_barrier();
+
+        Nbr n[F];
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            const float *row = reinterpret_cast<const float *>(&lds[bi][i][0]) + 4 * (FLAT_H + q);      // my first cell
+            n[i].c = C[i];
+            n[i].tm = P[i];
+            n[i].tp = N[i];
+            if ((Ty & 3) == 0) {                     // wave-uniform: the x neighbours are whole quads
+                n[i].xm = lds[bi][i][FLAT_H + q - (Ty >> 2)];
+                n[i].xp = lds[bi][i][FLAT_H + q + (Ty >> 2)];
+            } else {
+                n[i].xm = make_float4(row[-Ty], row[1 - Ty], row[2 - Ty], row[3 - Ty]);
+                n[i].xp = make_float4(row[Ty], row[Ty + 1], row[Ty + 2], row[Ty + 3]);
+            }
+            const float lft = row[-1], rgt = row[4];
+            n[i].ym = make_float4(lok[0] ? lft : 0.f, lok[1] ? C[i].x : 0.f, lok[2] ? C[i].y : 0.f, lok[3] ? C[i].z : 0.f);
+            n[i].yp = make_float4(rok[0] ? C[i].y : 0.f, rok[1] ? C[i].z : 0.f, rok[2] ? C[i].w : 0.f, rok[3] ? rgt : 0.f);
+        }
+        float4 r = Fn::eval(n, prm);
+        if (g.flags & PRE_FLAG_ABS) r = fabs4(r);
+        if (inb) stg4(outp + (long long)t * oT, r);
+    };
+
+    float4 w0[F], w1[F], w2[F], w3[F], h0[F], h1[F];
+    load_own(t0 - 1, w0);
+    load_own(t0, w1);
+    load_own(t0 + 1, w2);
+    load_halo(t0, h0);
+    for (int t = t0; t < t1; t += 4) {
+        step(t, w0, w1, w2, w3, h0, h1);
+        if (t + 1 >= t1) break;
+        step(t + 1, w1, w2, w3, w0, h1, h0);
+        if (t + 2 >= t1) break;
+        step(t + 2, w2, w3, w0, w1, h0, h1);
+        if (t + 3 >= t1) break;
+        step(t + 3, w3, w0, w1, w2, h1, h0);
+    }
+}
+
+template <class Fn>
+int launch_flat(Geom &g, const typename Fn::Params &prm, hipStream_t st)
+{
+    static_assert(2 * Fn::F * (FLAT_NT + 2 * FLAT_H) * 16 <= 160 * 1024, "chunk does not fit the 160 KiB LDS");
+    g.nXT = 1;
+    g.nYT = (int)(((long long)g.X * g.Y / 4 + FLAT_NT - 1) / FLAT_NT);
+    long long tiles = (long long)g.B * g.nYT;
+    int tSeg = g.T;
+    while (tiles * ((g.T + tSeg - 1) / tSeg) < 2048 && tSeg > 16) tSeg = (tSeg + 1) / 2;
+    g.tSeg = tSeg;
+    g.nTSeg = (g.T + tSeg - 1) / tSeg;
+    tiles *= g.nTSeg;
+    if (tiles <= 0 || tiles * FLAT_NT > 0xffffffffLL) return PRE_E_SHAPE;
+    hipLaunchKernelGGL((flat_march_kernel<Fn>), dim3((unsigned)tiles), dim3(FLAT_NT), 0, st, g, prm);
+    PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
+
 template <class Fn, bool BC = false>
 int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st, const BCInfo *bc = nullptr)
 {
+    if constexpr (!BC)
+        if (g.flat) return launch_flat<Fn>(g, prm, st);
     // 512 threads per workgroup; rows of the tile trade halo re-reads (2/NR) against columns covered
     // 8 rows x 256 columns: measured best of {4,8,16} rows (16 rows = 1024 threads, one workgroup per CU: -5 %)
     // (also measured: 16x128 and 32x64 tiles at 512 threads, -2..-7 % on every functor)
@@ -472,7 +611,8 @@ int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st, const BCInfo
 // arithmetic is unchanged - zero-copy for the layouts real callers hand in.  Returns
 // PRE_E_UNSUPPORTED when no common unit-stride axis / alignment exists.
 int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const pre_out_t *out,
-            int64_t B, int64_t T, int64_t X, int64_t Y, int flags, Star *const *stars, int nstars, bool relaxed = false)
+            int64_t B, int64_t T, int64_t X, int64_t Y, int flags, Star *const *stars, int nstars, bool relaxed = false,
+            bool allow_flat = true)
 {
     if (!out || !out->ptr || B <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
     if (B > 0x7fffffff || T > 0x7fffffff || X > 0x7fffffff || Y > 0x7fffffff) return PRE_E_SHAPE;
@@ -496,14 +636,20 @@ int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const
     // relaxed (single-field linear operators): any contiguous extent >= 4 (the last extent % 4 columns are
     // left to the caller); fused multi-field kernels need extent % 4 == 0.  No alignment requirement
     // beyond the 4 bytes of a float: the float4 accesses are unaligned-capable (F4u).
-    if (relaxed ? D[p[2]] < 4 : D[p[2]] % 4 != 0) return PRE_E_UNSUPPORTED;
+    // A SHORT contiguous axis (the surrogate's Nt = 10..40 in its native [BS,F,Nx,Ny,Nt] layout) would leave most
+    // lanes of a row idle.  When the next axis is contiguous with it (stride == extent) the two are merged into
+    // one long axis for the flat form of the kernel: only their product has to be a multiple of 4.
+    bool flat = allow_flat && D[p[2]] <= 64 && ostride(p[1]) == D[p[2]] && (D[p[1]] * D[p[2]]) % 4 == 0 && D[p[1]] > 1;
+    for (int i = 0; i < nf; ++i) flat = flat && stride(fs[i], p[1]) == D[p[2]];
+    g.flat = flat;
+    if (!flat && (relaxed ? D[p[2]] < 4 : D[p[2]] % 4 != 0)) return PRE_E_UNSUPPORTED;
     for (int i = 0; i < nf; ++i) {
         g.f[i] = fs[i]->ptr; g.sB[i] = fs[i]->sB; g.sT[i] = stride(fs[i], p[0]); g.sX[i] = stride(fs[i], p[1]);
     }
     for (int i = nf; i < MAXF; ++i) { g.f[i] = nullptr; g.sB[i] = g.sT[i] = g.sX[i] = 0; }
     g.out = out->ptr; g.oB = out->sB; g.oT = ostride(p[0]); g.oX = ostride(p[1]);
     g.B = (int)B; g.T = (int)D[p[0]]; g.X = (int)D[p[1]]; g.Y = (int)D[p[2]];
-    g.Yc = g.Y & ~3;
+    g.Yc = flat ? g.Y : (g.Y & ~3);
     g.flags = relabeled ? (flags & ~PRE_FLAG_INTERIOR_T) : flags;     // the skipped rim is on the LOGICAL t axis
     if (relabeled)
         for (int k = 0; k < nstars; ++k) {
@@ -711,7 +857,7 @@ int pre_spatial2d_bc_f32(const float *in, const int64_t in_strides[3], float *ou
     if (rc) return rc;
     Geom g;
     int rel;
-    rc = prepare(g, rel, fs, 1, &o, 1, B, X, Y, flags & ~PRE_FLAG_INTERIOR_T, nullptr, 0);
+    rc = prepare(g, rel, fs, 1, &o, 1, B, X, Y, flags & ~PRE_FLAG_INTERIOR_T, nullptr, 0, false, false);
     if (rc) return rc;
     return launch<Linear1, true>(g, prm, as_stream(stream), &info);
 }
@@ -733,7 +879,7 @@ int pre_spatial2d_linear2_bc_f32(const float *in0, const int64_t s0[3], const fl
     if (rc) return rc;
     Geom g;
     int rel;
-    rc = prepare(g, rel, fs, 2, &o, 1, B, X, Y, flags & ~PRE_FLAG_INTERIOR_T, nullptr, 0);
+    rc = prepare(g, rel, fs, 2, &o, 1, B, X, Y, flags & ~PRE_FLAG_INTERIOR_T, nullptr, 0, false, false);
     if (rc) return rc;
     return launch<Linear2, true>(g, prm, as_stream(stream), &info);
 }
