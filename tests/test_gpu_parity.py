@@ -1096,3 +1096,35 @@ def test_sharded_calibration_two_ranks_on_one_gpu(gpu, tmp_path):
         q = np.load(tmp_path / f"q_{r}.npy")
         assert np.max(np.abs(q - q_ref) / np.abs(q_ref)) <= 1e-6, (q, q_ref)       # fp64 moments, different summation split
         assert np.array_equal(np.load(tmp_path / f"qm_{r}.npy"), qm_ref)           # order statistics: exact
+
+
+@pytest.mark.parametrize("T", [10, 20, 30, 64])
+def test_short_nt_surrogate_layout_flat_form(gpu, T):
+    """The surrogate's native [BS,F,Nx,Ny,Nt] layout with the reference's T_out values (20, 30, 40; 10 = a C3 slab):
+    Nt is the contiguous axis and is short, so the flat (merged-axis) form of the marching kernel runs - fused
+    residuals and single operators, zero-copy, output in the input's memory order."""
+    from cp_pre_amd import residuals as R
+    from cp_pre_amd.convops_2d import ConvOperator
+    from oracle import residuals as orr
+    from oracle.cstencil import xcorr_c
+    g = torch.Generator().manual_seed(100 + T)
+    phys = torch.rand(3, 6, 18, 26, T, generator=g) + 0.5                 # [BS,F,Nx,Ny,Nt]
+    v = phys.permute(0, 1, 4, 2, 3)                                       # Marginal/NS_Residuals_CP.py:282
+    vd = phys.to(gpu).permute(0, 1, 4, 2, 3)
+    dt, dx, dy = 0.01, 0.05, 0.04
+    cases = [(R.NavierStokes(dt, dx, dy).residual_momentum(vd[:, :3], True), orr.ns_momentum(v[:, :3], dt, dx, dy, boundary=True)),
+             (R.NavierStokes(dt, dx, dy).residual_continuity(vd[:, :2], True), orr.ns_continuity(v[:, :2], dx, dy, boundary=True)),
+             (R.MHD().residual_induction(vd, True), orr.mhd_induction(v, boundary=True)),
+             (R.MHD().residual_energy(vd, True), orr.mhd_energy(v, boundary=True)),
+             (R.PRE_Wave(dt=dt, dx=dx, c=1.0).residual(vd[:, :1], boundary=True), orr.wave_residual(v[:, 0], 1.0, dt, dx, boundary=True))]
+    for i, (got, want) in enumerate(cases):
+        assert got.stride()[1:] == vd[:, 0].stride()[1:], i               # same memory order as the input view (dense batch)
+        assert rel_err(got.cpu().numpy(), want.numpy()) <= RES_TOL, (T, i)
+    for dom, order in (("t", 1), ("x", 2), (("x", "y"), 2)):
+        D = ConvOperator(dom, order)
+        got = D(vd[:, 0])
+        assert rel_err(got.cpu().numpy(), xcorr_c(v[:, 0].contiguous().numpy(), D.kernel.numpy())) <= RES_TOL, (T, dom)
+    # the reference layout with a narrow grid takes the same form
+    small = torch.rand(2, 3, 7, 22, max(T // 2, 6), generator=g) + 0.5
+    got = R.NavierStokes(dt, dx, dy).residual_momentum(small.to(gpu), True)
+    assert rel_err(got.cpu().numpy(), orr.ns_momentum(small, dt, dx, dy, boundary=True).numpy()) <= RES_TOL
