@@ -477,7 +477,11 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
     const int Ty = g.Y, L = g.X * g.Y;
     const int m0 = ch * FLAT_NT * 4, m = m0 + 4 * q;
     const bool inb = m < L;
-    const int t0 = ts * g.tSeg, t1 = min(t0 + g.tSeg, g.T);
+    int t0 = ts * g.tSeg, t1 = min(t0 + g.tSeg, g.T);
+    if (g.flags & PRE_FLAG_INTERIOR_T) {       // the caller crops the t rim: neither compute nor store it
+        t0 = max(t0, 1);
+        t1 = min(t1, g.T - 1);
+    }
 
     // halo duty: the first / last FLAT_H threads fetch one quad left / right of the chunk (L % 4 == 0: a quad is
     // entirely inside the row or entirely padding)

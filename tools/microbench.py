@@ -131,7 +131,7 @@ def bench_copy():
 
 def bench_permuted():
     """Residuals on the surrogate's native layout [BS,F,Nx,Ny,Nt] (zero-copy axis relabelling)."""
-    for (B, T, X, Y) in [(256, 64, 256, 256), (64, 64, 512, 512)]:
+    for (B, T, X, Y) in [(256, 64, 256, 256), (64, 64, 512, 512), (800, 20, 256, 256), (1600, 10, 256, 256), (128, 128, 256, 256)]:
         cells = B * T * X * Y
         sur = torch.empty(B, 6, X, Y, T, device=dev).uniform_(0.5, 1.5)
         v = sur.permute(0, 1, 4, 2, 3)
