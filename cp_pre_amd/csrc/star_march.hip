@@ -456,12 +456,14 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const 
 // Kernel axes (t, x, y) with a SHORT y extent Ty whose rows follow each other in memory (x stride == Ty): the
 // (x, y) plane is one contiguous row of L = X*Ty cells.  A workgroup owns a chunk of 512 quads of that merged
 // row and marches over t exactly as above (register window, prefetch), but the neighbours within the plane are
-// all taken from the flat LDS copy of the chunk (+ a halo of 16 quads per side):
+// all taken from the flat LDS copy of the chunk (+ a halo of 32 quads per side):
 //   x -/+  =  Ty cells back / ahead in the merged row (beyond the row = the zero padding of x = -1 / X),
 //   y -/+  =  the previous / next cell, masked where that cell belongs to the neighbouring x row (y = -1 / Ty).
 // Every lane works whatever Ty is, and Ty itself need not be a multiple of 4 (only L).  Used for the surrogate's
-// native Nt-fastest layout with Nt < 64 (after the axis relabelling: t = Nx, x = Ny, y = Nt).
-constexpr int FLAT_NT = 512, FLAT_H = 16;
+// native Nt-fastest layout with Nt < 96 (after the axis relabelling: t = Nx, x = Ny, y = Nt) and for narrow grids in
+// the reference layout (below 96 columns the regular kernel is down to its 64-column tile: measured at 80 columns
+// wave 3.7 -> 4.9, MHD induction 3.4 -> 4.4 TB/s, NS momentum 3.7 -> 3.5; from 100 columns up the regular tiles win).
+constexpr int FLAT_NT = 512, FLAT_H = 32;
 
 template <class Fn>
 __global__ void __launch_bounds__(FLAT_NT, MinWaves<Fn>::value)
@@ -643,7 +645,7 @@ int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const
     // A SHORT contiguous axis (the surrogate's Nt = 10..40 in its native [BS,F,Nx,Ny,Nt] layout) would leave most
     // lanes of a row idle.  When the next axis is contiguous with it (stride == extent) the two are merged into
     // one long axis for the flat form of the kernel: only their product has to be a multiple of 4.
-    bool flat = allow_flat && D[p[2]] <= 64 && ostride(p[1]) == D[p[2]] && (D[p[1]] * D[p[2]]) % 4 == 0 && D[p[1]] > 1;
+    bool flat = allow_flat && D[p[2]] < 96 && ostride(p[1]) == D[p[2]] && (D[p[1]] * D[p[2]]) % 4 == 0 && D[p[1]] > 1;
     for (int i = 0; i < nf; ++i) flat = flat && stride(fs[i], p[1]) == D[p[2]];
     g.flat = flat;
     if (!flat && (relaxed ? D[p[2]] < 4 : D[p[2]] % 4 != 0)) return PRE_E_UNSUPPORTED;
