@@ -124,16 +124,24 @@ __device__ __forceinline__ void js_update(float av, float sv, float &m, float &t
 
 __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                           const float *__restrict__ mod, int T, int X, int Y,
-                                                          int ct, int cx, int cy, float *__restrict__ scores)
+                                                          int ct, int cx, int cy, int groups, float *__restrict__ scores)
 {
     const long long plane = (long long)X * Y, vol = plane * T;
     const int smp = blockIdx.y;
     const float *pa = a + smp * vol, *pb = b ? b + smp * vol : nullptr;
-    const long long r0 = (long long)blockIdx.x * JS_RB, nrows = (long long)T * X;
+    const long long nrows = (long long)T * X;
     const bool vec = (Y % 4 == 0) && !(((uintptr_t)a | (uintptr_t)mod | (uintptr_t)(b ? b : a)) & 15);
     __shared__ unsigned int rowmask;
     __shared__ float red[4];
-    if (threadIdx.x < 64) {      // which of this block's rows survive the (t, x) crop
+    float m = 0.f, thr = 0.f;
+    bool any = false;
+    // `groups` spans of JS_RB rows per block (short rows - e.g. the surrogate's Nt = 10 cells - would otherwise
+    // leave a block with a few hundred cells and one atomic each)
+    for (int gi = 0; gi < groups; ++gi) {
+    const long long r0 = ((long long)blockIdx.x * groups + gi) * JS_RB;
+    if (r0 >= nrows) break;
+    __syncthreads();             // the previous span's rowmask has been read by everyone
+    if (threadIdx.x < 64) {      // which of this span's rows survive the (t, x) crop
         const long long r = r0 + threadIdx.x;
         bool ok = threadIdx.x < JS_RB && r < nrows;
         if (ok) {
@@ -145,7 +153,7 @@ __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restric
     }
     __syncthreads();
     const unsigned int rows = rowmask;
-    float m = 0.f, thr = 0.f;
+    any = any || rows != 0u;
     if (rows && vec) {
         // the block's rows are one contiguous span: walk it as float4 items, all 256 lanes busy
         const int Y4 = Y / 4, dr = 256 / Y4, dy = 256 % Y4;
@@ -168,20 +176,26 @@ __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restric
             if (y4 >= Y4) { y4 -= Y4; ++row; }
         }
     } else if (rows) {
-        for (int rr = 0; rr < JS_RB; ++rr) {
-            if (!((rows >> rr) & 1u)) continue;
-            const long long ro = (r0 + rr) * Y;
-            for (int y = cy + threadIdx.x; y < Y - cy; y += blockDim.x) {
-                float v = pa[ro + y];
-                if (pb) v -= pb[ro + y];
-                js_update(fabsf(v), mod[ro + y], m, thr);
+        // same walk cell by cell (Y % 4 != 0 or unaligned: e.g. the surrogate's Nt-fastest order, rows of Nt = 10 cells)
+        const int dr = 256 / Y, dy = 256 % Y;
+        int row = threadIdx.x / Y, y = threadIdx.x % Y;
+        while (row < JS_RB) {
+            if (((rows >> row) & 1u) && y >= cy && y < Y - cy) {
+                const long long o = (r0 + row) * Y + y;
+                float v = pa[o];
+                if (pb) v -= pb[o];
+                js_update(fabsf(v), mod[o], m, thr);
             }
+            y += dy;
+            row += dr;
+            if (y >= Y) { y -= Y; ++row; }
         }
     }
+    }   // spans
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0 && rows) {
+    if (threadIdx.x == 0 && any) {
         m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         // non-negative floats order like their bit patterns
         atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, __float_as_uint(m));
@@ -601,14 +615,19 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod, int64_
     if (!a || !mod || !scores || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
     if (crop_t < 0 || crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
     if (n > 65535 * 1024LL || T * X > 0x7fffffffLL * JS_RB || Y > 0x7fffffff) return PRE_E_SHAPE;
-    const long long chunks = (T * X + JS_RB - 1) / JS_RB;
+    // spans of JS_RB rows; a block takes as many as give it >= ~8 k cells (but leaves >= ~2 k blocks when possible)
+    const long long spans = (T * X + JS_RB - 1) / JS_RB;
+    long long groups = 8192 / (JS_RB * Y);
+    if (groups < 1) groups = 1;
+    while (groups > 1 && (spans / groups) * n < 2048) groups /= 2;
+    const long long chunks = (spans + groups - 1) / groups;
     // gridDim.y is limited to 65535: walk the batch axis in slices
     for (int64_t s0 = 0; s0 < n; s0 += 65535) {
         const int64_t ns = (n - s0) < 65535 ? (n - s0) : 65535;
         const long long vol = (long long)T * X * Y;
         hipLaunchKernelGGL(joint_score_kernel, dim3((unsigned)chunks, (unsigned)ns), dim3(256), 0, as_stream(stream),
                            a + s0 * vol, b ? b + s0 * vol : nullptr, mod, (int)T, (int)X, (int)Y, crop_t, crop_x, crop_y,
-                           scores + s0);
+                           (int)groups, scores + s0);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;

@@ -191,7 +191,12 @@ def ncf_metric_joint(a, b, modulation, crop=0):
         T, X, Y = da.shape[1:]                      # extents in memory order; the crop is the same on each axis
         ct = cx = cy = int(crop)
     else:
-        T, X, Y, ct, cx, cy = 1, 1, da.numel() // n, 0, 0, 0
+        # no crop: any rows x columns factorisation of the cells will do; one row of M cells would leave a single
+        # workgroup per sample (measured 0.16 TB/s at n = 100) and a short innermost axis (the surrogate's Nt) would
+        # defeat the float4 path: rows of the largest power of two that divides M
+        M = da.numel() // n
+        Y = next((c for c in (4096, 2048, 1024, 512, 256, 128, 64, 32, 16, 8, 4) if M % c == 0), da.shape[-1])
+        T, X, ct, cx, cy = 1, M // Y, 0, 0, 0
     scores = torch.zeros(n, dtype=torch.float32, device=da.device)
     with torch.cuda.device(da.device):
         _lib.check(_lib.load().pre_joint_score_f32(_lib.ptr(da), _lib.ptr(db), _lib.ptr(dm), n, T, X, Y, ct, cx, cy,
@@ -214,26 +219,30 @@ def _directed_f32(a, up):
 
 
 def _bounds(pred_sets, y, outside=False):
-    dy = _dev(y)[0].contiguous()
-    # inside test: y >= lo & y <= hi; outside test: y <= lo | y >= hi  (opposite rounding directions)
-    lo = _dev(_directed_f32(pred_sets[0], up=not outside))[0].contiguous()
-    hi = _dev(_directed_f32(pred_sets[1], up=outside))[0].contiguous()
+    """y as [n, M] rows in MEMORY order (no copy for dense permuted layouts, e.g. the surrogate's Nt-fastest
+    one) and the two bounds laid out the same way, per cell ([M]) or per sample and cell ([n, M])."""
+    ydev = _dev(y)[0]
+    logical = tuple(ydev.shape)                             # [n, *cells] as the caller sees it
+    dy, order = canon(ydev)
     n, M = dy.shape[0], dy.numel() // dy.shape[0]
-    per_sample = []
-    for t in (lo, hi):
-        if t.numel() == M:
-            per_sample.append(0)
-        elif t.numel() == n * M:
-            per_sample.append(1)
-        else:                                   # scalar / other broadcast: materialise per cell
-            per_sample.append(-1)
-    if per_sample[0] != per_sample[1] or -1 in per_sample:
-        shape = dy.shape if 1 in per_sample else dy.shape[1:]
-        lo = lo.expand(shape).contiguous() if lo.numel() != math.prod(shape) else lo
-        hi = hi.expand(shape).contiguous() if hi.numel() != math.prod(shape) else hi
-        ps = 1 if 1 in per_sample else 0
+
+    def lay(t):
+        # inside test: y >= lo & y <= hi; outside test: y <= lo | y >= hi  (opposite rounding directions)
+        if t.numel() == M and t.dim() >= 1:
+            return canon_cells(t.reshape(logical[1:]), order), 0
+        if t.numel() == n * M:
+            return _same_layout(t.reshape(logical), order), 1
+        return None, -1                                      # scalar / other broadcast: materialise below
+    lo_t = _dev(_directed_f32(pred_sets[0], up=not outside))[0]
+    hi_t = _dev(_directed_f32(pred_sets[1], up=outside))[0]
+    (lo, pl), (hi, ph) = lay(lo_t), lay(hi_t)
+    if pl != ph or pl < 0:
+        ps = 1 if 1 in (pl, ph) else 0
+        shape = logical if ps else logical[1:]
+        lo = lay(lo_t.expand(shape).contiguous())[0]
+        hi = lay(hi_t.expand(shape).contiguous())[0]
     else:
-        ps = per_sample[0]
+        ps = pl
     return dy, lo, hi, n, M, ps
 
 
