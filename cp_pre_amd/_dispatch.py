@@ -112,16 +112,44 @@ class _XCorrFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             g = gout.to(field.device) if gout.device != field.device else gout
             x = field[:, 0] if field.dim() == nd + 2 else field
-            gk = torch.zeros_like(kernel, dtype=torch.float32, device=g.device)
-            ext = x.shape[1:]
-            for idx in torch.cartesian_prod(*[torch.arange(s) for s in kernel.shape]).tolist():
-                off = [i - s // 2 for i, s in zip(idx, kernel.shape)]
-                src = tuple(slice(max(0, o), e + min(0, o)) for o, e in zip(off, ext))
-                dst = tuple(slice(max(0, -o), e - max(0, o)) for o, e in zip(off, ext))
-                if all(sl.stop > sl.start for sl in src):
-                    gk[tuple(idx)] = (g[(slice(None),) + dst] * x[(slice(None),) + src]).sum()
+            g = g[:, 0] if g.dim() == nd + 2 else g
+            gk = _kernel_grad_hip(x, g, kernel, nd)
+            if gk is None:                                  # extents other than 1/3, or no unit stride: shifted products
+                gk = torch.zeros_like(kernel, dtype=torch.float32, device=g.device)
+                ext = x.shape[1:]
+                for idx in torch.cartesian_prod(*[torch.arange(s) for s in kernel.shape]).tolist():
+                    off = [i - s // 2 for i, s in zip(idx, kernel.shape)]
+                    src = tuple(slice(max(0, o), e + min(0, o)) for o, e in zip(off, ext))
+                    dst = tuple(slice(max(0, -o), e - max(0, o)) for o, e in zip(off, ext))
+                    if all(sl.stop > sl.start for sl in src):
+                        gk[tuple(idx)] = (g[(slice(None),) + dst] * x[(slice(None),) + src]).sum()
             gk = gk.to(kernel.device)
         return gf, gk, None
+
+
+def _kernel_grad_hip(x, g, kernel, nd):
+    """d loss / d kernel in ONE pass (``pre_stencil3d_wgrad_f32``) for device tensors and kernel extents in {1, 3};
+    None if the library declines (the caller then composes k^nd shifted products from torch ops)."""
+    if not (x.is_cuda and g.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32):
+        return None
+    if any(s not in (1, 3) for s in kernel.shape):
+        return None
+    if nd == 2:                                             # [B,T,X] with a (kt,kx) kernel == [1,B,T,X] with (1,kt,kx)
+        x4, g4, ext = x.unsqueeze(0), g.unsqueeze(0), (1,) + tuple(kernel.shape)
+    else:
+        x4, g4, ext = x, g, tuple(kernel.shape)
+    if x4.stride(-1) != 1:
+        x4 = x4.contiguous()
+    if g4.stride(-1) != 1:
+        g4 = g4.contiguous()
+    gk = torch.zeros(ext, dtype=torch.float64, device=x.device)
+    fx, fg = _lib.field(x4), _lib.field(g4)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().pre_stencil3d_wgrad_f32(ctypes.byref(fx), ctypes.byref(fg), *ext, *x4.shape, _lib.ptr(gk), _lib.stream())
+    if rc == _lib.PRE_E_UNSUPPORTED:
+        return None
+    _lib.check(rc, "pre_stencil3d_wgrad_f32")
+    return gk.to(torch.float32).reshape(tuple(kernel.shape))
 
 
 def xcorr(field, kernel, nd, flags=0):

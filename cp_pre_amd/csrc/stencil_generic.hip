@@ -148,11 +148,98 @@ __global__ void __launch_bounds__(256) generic_tile_kernel(const float *__restri
     }
 }
 
+// ---- kernel gradient of the zero-padded cross-correlation (autograd: d loss / d kernel) -------------------
+// gk[dt][dx][dy] += sum over cells of g[c] * x[c + (dt,dx,dy)] for a (kt,kx,ky) kernel with extents in {1,3}:
+// one pass over g, the three x planes staged in LDS as above, 27 accumulators per thread, block reduction,
+// one double atomic per tap and block.  (torch composes this as kt*kx*ky sliced multiply-and-sum passes.)
+__global__ void __launch_bounds__(256) wgrad27_kernel(const float *__restrict__ xin, long long sB, long long sT, long long sX,
+                                                      const float *__restrict__ gin, long long gB, long long gT, long long gX,
+                                                      int B, int T, int X, int Y, int rt, int rx, int ry, int nstrips,
+                                                      double *__restrict__ gk)
+{
+    __shared__ float4 tile[TILE_R + 2][LDS_Q];
+    __shared__ float red[4][27];
+    const int strip = blockIdx.x % nstrips, rowgrp = blockIdx.x / nstrips;
+    const int x0 = rowgrp * TILE_R, y0 = strip * TILE_C;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+    for (int b = blockIdx.z; b < B; b += gridDim.z)
+    for (int t = blockIdx.y; t < T; t += gridDim.y) {
+        // my 4 rows x 4 cells of the upstream gradient (zero outside the domain)
+        float gq[4][4];
+        const int y = y0 + 4 * lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + wv + 4 * k;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                gq[k][j] = (x < X && y + j < Y) ? gin[b * gB + t * gT + x * gX + y + j] : 0.f;
+        }
+        for (int dt = -rt; dt <= rt; ++dt) {
+            __syncthreads();
+            const int tt = t + dt;
+            for (int q = threadIdx.x; q < (TILE_R + 2) * LDS_Q; q += 256) {
+                const int rr = q / LDS_Q, qc = q % LDS_Q;
+                const int gx = x0 + rr - 1, gy = y0 + 4 * qc - 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tt >= 0 && tt < T && gx >= 0 && gx < X) {
+                    const float *src = xin + b * sB + tt * sT + gx * sX + gy;
+                    if (gy >= 0 && gy < Y) v.x = src[0];
+                    if (gy + 1 >= 0 && gy + 1 < Y) v.y = src[1];
+                    if (gy + 2 >= 0 && gy + 2 < Y) v.z = src[2];
+                    if (gy + 3 >= 0 && gy + 3 < Y) v.w = src[3];
+                }
+                tile[rr][qc] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int dxi = 0; dxi < 3; ++dxi) {
+                const int dx = dxi - 1;
+                if (dx < -rx || dx > rx) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 *row = tile[wv + 4 * k + dx + 1];
+                    const float4 L = row[lane], C = row[lane + 1], R = row[lane + 2];
+                    const float e[12] = {L.x, L.y, L.z, L.w, C.x, C.y, C.z, C.w, R.x, R.y, R.z, R.w};
+#pragma unroll
+                    for (int dyi = 0; dyi < 3; ++dyi) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) sum += gq[k][j] * e[4 + j + dyi - 1];
+                        // the t index of the accumulator is not a compile-time constant: add to all three, masked
+#pragma unroll
+                        for (int dti = 0; dti < 3; ++dti)
+                            acc[(dti * 3 + dxi) * 3 + dyi] += (dti - 1 == dt) ? sum : 0.f;
+                    }
+                }
+            }
+        }
+    }
+    // block reduction, then one double atomic per tap
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        const int k = threadIdx.x, dt = k / 9 - 1, dx = (k / 3) % 3 - 1, dy = k % 3 - 1;
+        if (dt >= -rt && dt <= rt && dx >= -rx && dx <= rx && dy >= -ry && dy <= ry) {
+            const double v = (double)red[0][k] + red[1][k] + red[2][k] + red[3][k];
+            atomicAdd(&gk[((dt + rt) * (2 * rx + 1) + (dx + rx)) * (2 * ry + 1) + (dy + ry)], v);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-int pre_abi_version(void) { return 2; }
+int pre_abi_version(void) { return 3; }
 
 int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *tap_w, const int32_t *tap_off, int ntaps,
                       int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)
@@ -239,6 +326,25 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *
                        (long long)in->sT, (long long)in->sX, (long long)in->sY, out->ptr, (long long)out->sB,
                        (long long)out->sT, (long long)out->sX, (long long)out->sY, (int)B, (int)T, (int)X, (int)Y, box[0], box[1],
                        box[2], wsh, (int)nstrips, flags, taps);
+    PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
+
+int pre_stencil3d_wgrad_f32(const pre_field_t *x, const pre_field_t *g, int kt, int kx, int ky, int64_t B, int64_t T, int64_t X,
+                            int64_t Y, double *gk, void *stream)
+{
+    if (!x || !x->ptr || !g || !g->ptr || !gk) return PRE_E_NULL;
+    if (B <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
+    if ((kt != 1 && kt != 3) || (kx != 1 && kx != 3) || (ky != 1 && ky != 3)) return PRE_E_UNSUPPORTED;
+    if (x->sY != 1 || g->sY != 1) return PRE_E_UNSUPPORTED;
+    if (B > 0x7fffffff || T > 0x7fffffff || X > 0x7fffffff || Y > 0x7fffffff) return PRE_E_SHAPE;
+    const long long nstrips = (Y + TILE_C - 1) / TILE_C, tiles = nstrips * ((X + TILE_R - 1) / TILE_R);
+    if (tiles >= (1 << 23)) return PRE_E_SHAPE;
+    // few, fat blocks along (t, batch): every block ends with 27 atomics
+    const dim3 grid((unsigned)tiles, (unsigned)(T < 64 ? T : 64), (unsigned)(B < 64 ? B : 64));
+    hipLaunchKernelGGL(wgrad27_kernel, grid, dim3(256), 0, as_stream(stream), x->ptr, (long long)x->sB, (long long)x->sT,
+                       (long long)x->sX, g->ptr, (long long)g->sB, (long long)g->sT, (long long)g->sX, (int)B, (int)T, (int)X,
+                       (int)Y, kt / 2, kx / 2, ky / 2, (int)nstrips, gk);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }

@@ -51,7 +51,7 @@ typedef struct {
     int64_t sB, sT, sX, sY;
 } pre_out_t;
 
-int pre_abi_version(void);     /* 2 */
+int pre_abi_version(void);     /* 3 */
 
 /* ---- a4/a5/a6: ConvOperator.convolution ---------------------------------------------
  * Utils/ConvOps_2d.py:135-150  F.conv3d(field[:,None], K[None,None], padding=k//2)
@@ -69,6 +69,14 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out,
 int pre_stencil2d_f32(const float *in, const int64_t in_strides[3], float *out, const int64_t out_strides[3],
                       const float *tap_w /*host*/, const int32_t *tap_off /*host*/, int ntaps,
                       int64_t B, int64_t T, int64_t X, int flags, void *stream);
+
+/* Gradient of pre_stencil3d_f32 with respect to a dense (kt,kx,ky) kernel, extents in {1,3} (autograd: the
+ * reference puts ConvOperator in a physics-informed loss and sets D.kernel.requires_grad = True,
+ * Physics_Informed/Wave_FNO_PI.py:202-228):  gk[dt][dx][dy] += sum_cells g[c] * x[c + (dt,dx,dy)], zero padding.
+ * x, g: device views with unit stride along Y; gk: device doubles [kt*kx*ky], zeroed by the caller.
+ * PRE_E_UNSUPPORTED for other extents / layouts (the caller composes the products). */
+int pre_stencil3d_wgrad_f32(const pre_field_t *x, const pre_field_t *g, int kt, int kx, int ky,
+                            int64_t B, int64_t T, int64_t X, int64_t Y, double *gk /*device*/, void *stream);
 
 /* ---- a9: fused PDE residuals --------------------------------------------------------
  * Operators are passed as the DENSE 3x3x3 kernels the caller's ConvOperator objects hold

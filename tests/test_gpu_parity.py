@@ -515,6 +515,32 @@ def test_autograd_matches_torch_conv(gpu):
         assert not C2("x", 1)(vd[:, 0]).requires_grad
 
 
+def test_kernel_gradient_single_pass(gpu):
+    """pre_stencil3d_wgrad_f32 (d loss / d kernel in one pass, used by autograd when the kernel requires grad -
+    Physics_Informed/Wave_FNO_PI.py:206 sets it) against torch's conv backward, 3-D and 2-D, odd and ragged sizes,
+    a strided input view, and a 5^3 kernel that takes the composed route."""
+    import torch.nn.functional as F
+    from cp_pre_amd.convops_1d import ConvOperator as Conv1D
+    from cp_pre_amd.convops_2d import ConvOperator
+    g = torch.Generator().manual_seed(41)
+    for shape, kshape in (((3, 7, 19, 70), (3, 3, 3)), ((2, 5, 33, 300), (3, 3, 3)), ((1, 2, 17, 515), (3, 3, 3)),
+                          ((4, 20, 130), (3, 3)), ((2, 4, 9, 20), (5, 5, 5))):
+        nd = len(kshape)
+        x, k = torch.randn(*shape, generator=g), torch.randn(*kshape, generator=g)
+        wide = torch.zeros(shape[:-1] + (shape[-1] + 3,))
+        wide[..., 2:-1] = x
+        xd = wide.to(gpu)[..., 2:-1].requires_grad_(True)                 # offset, non-dense rows
+        kd = k.to(gpu).requires_grad_(True)
+        D = (ConvOperator if nd == 3 else Conv1D)()
+        D.kernel = kd
+        (D(xd) ** 2).sum().backward()
+        xc, kc = x.clone().requires_grad_(True), k.clone().requires_grad_(True)
+        conv = F.conv3d if nd == 3 else F.conv2d
+        (conv(xc[:, None], kc[None, None], padding=kshape[0] // 2) ** 2).sum().backward()
+        assert rel_err(kd.grad.cpu().numpy(), kc.grad.numpy()) <= 1e-5, (shape, kshape)
+        assert rel_err(xd.grad.cpu().numpy(), xc.grad.numpy()) <= 1e-5, (shape, kshape)
+
+
 def test_permuted_surrogate_layout_large(gpu):
     """[BS,F,Nx,Ny,Nt] surrogate output seen through permute(0,1,4,2,3): large views are re-laid
     out on the device and take the streaming kernels; results equal the oracle on the same view."""
