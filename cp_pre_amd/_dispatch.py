@@ -164,6 +164,40 @@ def xcorr(field, kernel, nd, flags=0):
     return _xcorr_impl(field, kernel, nd, flags)
 
 
+class _Recompute(torch.autograd.Function):
+    """Attach a result computed by a fused (non-differentiable) HIP pass to the autograd graph.  If backward is
+    ever called, the same expression is recomputed through the composed, differentiable route (single-operator
+    HIP passes + torch ops) and differentiated; a forward that is never differentiated - the common case: model
+    outputs that merely carry ``requires_grad``, the reference's always-grad-requiring spatial kernels - costs
+    nothing extra."""
+
+    @staticmethod
+    def forward(ctx, out, composed, *tensors):
+        ctx.composed = composed
+        ctx.save_for_backward(*tensors)
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        needs = ctx.needs_input_grad[2:]
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(n) for t, n in zip(ctx.saved_tensors, needs)]
+            y = ctx.composed(*ins)
+            wanted = [i for i, n in zip(ins, needs) if n]
+            grads = iter(torch.autograd.grad(y, wanted, gout.to(y.device), allow_unused=True)) if wanted else iter(())
+        return (None, None) + tuple(next(grads) if n else None for n in needs)
+
+
+def fused_or_composed(fused, composed, *tensors):
+    """``fused()``: the one-pass HIP route, or None if it declines.  ``composed(*tensors)``: the same expression
+    from differentiable pieces.  The fused result is used whenever it exists; gradients stay available."""
+    with torch.no_grad():
+        out = fused()
+    if out is None:
+        return composed(*tensors)
+    return _Recompute.apply(out, composed, *tensors) if needs_grad(*tensors) else out
+
+
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 

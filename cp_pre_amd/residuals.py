@@ -77,9 +77,21 @@ class _Residual2D:
         return None if any(k is None for k in ks) else ks
 
     def _want_fused(self, *tensors):
-        """Fused kernels have no backward; a caller that needs gradients gets the composed route."""
-        return self.fused and not _dispatch.needs_grad(*tensors, *[getattr(o, "kernel", None) for o in
-                                                                   (self.D_t, self.D_x, self.D_y, self.D_xx_yy)])
+        """The fused kernels run whatever the fields' ``requires_grad`` (``_attach`` keeps the result
+        differentiable by recomputation); only operator KERNELS that require grad force the composed route, so
+        that their gradients flow."""
+        return self.fused and not _dispatch.needs_grad(*[getattr(o, "kernel", None) for o in
+                                                         (self.D_t, self.D_x, self.D_y, self.D_xx_yy)])
+
+
+def _attach(res, fields, composed, absolute):
+    """``res``: a fused result (with |.| already applied if ``absolute``), or None.  If a field requires grad the
+    result is hooked into autograd: a backward recomputes ``composed`` (operator by operator) and differentiates
+    that; a forward that is never differentiated pays nothing."""
+    if res is None or not _dispatch.needs_grad(*fields):
+        return res
+    fn = (lambda *f: _on_device(f, composed).abs()) if absolute else (lambda *f: _on_device(f, composed))
+    return _dispatch._Recompute.apply(res, fn, *fields)
 
 
 def _finish(res, boundary, crop, absolute, already_abs):
@@ -115,28 +127,30 @@ class NavierStokes(_Residual2D):
         (``PRE_FLAG_INTERIOR_T``; their content is then unspecified)."""
         u, v, p = vars[:, 0], vars[:, 1], vars[:, 2]
         dt, dx, dy, nu = self.dt, self.dx, self.dy, self.nu
-        ks = self._k27(self.D_t, self.D_x, self.D_y, self.D_xx_yy) if self._want_fused(vars) else None
-        if ks is not None:
-            (du, dv, dp), origin = _stage((u, v, p))
-            if out is None:
-                out = _lib.empty_like_layout(du)
-            elif not (out.is_cuda and out.shape == du.shape and out.dtype == torch.float32):
-                raise ValueError("out must be an fp32 device tensor of the field shape")
-            fu, fv, fp, fo = _lib.field(du), _lib.field(dv), _lib.field(dp), _lib.field(out)
-            with torch.cuda.device(du.device):
-                ok = _fused_call("pre_residual_ns_momentum_f32", lambda: _lib.load().pre_residual_ns_momentum_f32(
-                    ctypes.byref(fu), ctypes.byref(fv), ctypes.byref(fp), ctypes.byref(fo), *ks,
-                    float(dt), float(dx), float(dy), float(nu), *du.shape,
-                    (_lib.PRE_FLAG_ABS if absolute else 0) | (_lib.PRE_FLAG_INTERIOR_T if skip_t_rim else 0),
-                    _lib.stream()))
-            if ok:
-                return _finish(_dispatch.from_device(out, origin), boundary, _CROP3, absolute, True)
         D_t, D_x, D_y, D_xx_yy = self.D_t, self.D_x, self.D_y, self.D_xx_yy
 
         def composed(u, v, p):
             res_x = D_t(u)*dx*dy + u*D_x(u)*dt*dy + v*D_y(u)*dt*dx - nu*D_xx_yy(u)*dt + D_x(p)*dt*dy
             res_y = D_t(v)*dx*dy + u*D_x(v)*dt*dx + v*D_y(v)*dt*dy - nu*D_xx_yy(v)*dt + D_y(p)*dt*dx
             return res_x + res_y
+        ks = self._k27(self.D_t, self.D_x, self.D_y, self.D_xx_yy) if self._want_fused(vars) else None
+        if ks is not None:
+            with torch.no_grad():
+                (du, dv, dp), origin = _stage((u, v, p))
+                if out is None:
+                    out = _lib.empty_like_layout(du)
+                elif not (out.is_cuda and out.shape == du.shape and out.dtype == torch.float32):
+                    raise ValueError("out must be an fp32 device tensor of the field shape")
+                fu, fv, fp, fo = _lib.field(du), _lib.field(dv), _lib.field(dp), _lib.field(out)
+                with torch.cuda.device(du.device):
+                    ok = _fused_call("pre_residual_ns_momentum_f32", lambda: _lib.load().pre_residual_ns_momentum_f32(
+                        ctypes.byref(fu), ctypes.byref(fv), ctypes.byref(fp), ctypes.byref(fo), *ks,
+                        float(dt), float(dx), float(dy), float(nu), *du.shape,
+                        (_lib.PRE_FLAG_ABS if absolute else 0) | (_lib.PRE_FLAG_INTERIOR_T if skip_t_rim else 0),
+                        _lib.stream()))
+            if ok:
+                res = _attach(_dispatch.from_device(out, origin), (u, v, p), composed, absolute)
+                return _finish(res, boundary, _CROP3, absolute, True)
         return _finish(_on_device((u, v, p), composed), boundary, _CROP3, absolute, False)
 
     def periodic_bc_residual(self, u, wall='right'):
@@ -173,7 +187,8 @@ class MHD(_Residual2D):
         ks = self._k27(self.D_t, self.D_x, self.D_y) if self._want_fused(vars) else None
         if ks is None or vars.shape[1] < 6:
             return None
-        fields, origin = _stage([vars[:, i] for i in range(6)])
+        with torch.no_grad():
+            fields, origin = _stage([vars[:, i] for i in range(6)])
         out = _lib.empty_like_layout(fields[0])
         arr = (_lib.PreField * 6)(*[_lib.field(f) for f in fields])
         fo = _lib.field(out)
@@ -184,51 +199,53 @@ class MHD(_Residual2D):
         return _dispatch.from_device(out, origin) if ok else None
 
     def residual_continuity(self, vars, boundary=False, absolute=False):
-        res = self._fused('continuity', vars, absolute)
+        D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
+        fields = (vars[:, 0], vars[:, 1], vars[:, 2])
+
+        def composed(rho, u, v):
+            return D_t(rho) + u*D_x(rho) + rho*D_x(u) + v*D_y(rho) + rho*D_y(v)
+        res = _attach(self._fused('continuity', vars, absolute), fields, composed, absolute)
         if res is None:
-            D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
-            res = _on_device((vars[:, 0], vars[:, 1], vars[:, 2]), lambda rho, u, v:
-                             D_t(rho) + u*D_x(rho) + rho*D_x(u) + v*D_y(rho) + rho*D_y(v))
-            return _finish(res, boundary, _CROP3, absolute, False)
+            return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)
 
     def residual_momentum(self, vars, boundary=False, absolute=False):
-        res = self._fused('momentum', vars, absolute)
-        if res is None:
-            D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
+        D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
+        fields = tuple(vars[:, i] for i in range(6))
 
-            def composed(rho, u, v, p, Bx, By):
-                res_x = D_t(u) + u*D_x(u) + (1/rho)*D_x(p) - 2*(Bx/rho)*D_x(Bx) + v*D_y(u) - (By/rho)*D_y(Bx) - (Bx/rho)*D_y(By)
-                res_y = D_t(v) + u*D_x(v) + (1/rho)*D_y(p) - 2*(By/rho)*D_y(By) + v*D_y(v) - (By/rho)*D_x(Bx) - (Bx/rho)*D_x(By)
-                return res_x + res_y
-            res = _on_device([vars[:, i] for i in range(6)], composed)
-            return _finish(res, boundary, _CROP3, absolute, False)
+        def composed(rho, u, v, p, Bx, By):
+            res_x = D_t(u) + u*D_x(u) + (1/rho)*D_x(p) - 2*(Bx/rho)*D_x(Bx) + v*D_y(u) - (By/rho)*D_y(Bx) - (Bx/rho)*D_y(By)
+            res_y = D_t(v) + u*D_x(v) + (1/rho)*D_y(p) - 2*(By/rho)*D_y(By) + v*D_y(v) - (By/rho)*D_x(Bx) - (Bx/rho)*D_x(By)
+            return res_x + res_y
+        res = _attach(self._fused('momentum', vars, absolute), fields, composed, absolute)
+        if res is None:
+            return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)
 
     def residual_energy(self, vars, boundary=False, absolute=False):
-        res = self._fused('energy', vars, absolute)
-        if res is None:
-            D_t, D_x, D_y, gamma = self.D_t, self.D_x, self.D_y, self.gamma
+        D_t, D_x, D_y, gamma = self.D_t, self.D_x, self.D_y, self.gamma
+        fields = tuple(vars[:, i] for i in range(6))
 
-            def composed(rho, u, v, p, Bx, By):
-                p_gas = p - 0.5*(Bx**2 + By**2)
-                return (D_t(rho) + u*D_x(p) + v*D_y(p) + (gamma-2)*(u*Bx+v*By)*(D_x(Bx) + D_y(By))
-                        + (gamma*p_gas+By**2)*D_x(u) + (gamma*p_gas+Bx**2)*D_y(v) - Bx*By*(D_y(u) + D_x(v)))
-            res = _on_device([vars[:, i] for i in range(6)], composed)
-            return _finish(res, boundary, _CROP3, absolute, False)
+        def composed(rho, u, v, p, Bx, By):
+            p_gas = p - 0.5*(Bx**2 + By**2)
+            return (D_t(rho) + u*D_x(p) + v*D_y(p) + (gamma-2)*(u*Bx+v*By)*(D_x(Bx) + D_y(By))
+                    + (gamma*p_gas+By**2)*D_x(u) + (gamma*p_gas+Bx**2)*D_y(v) - Bx*By*(D_y(u) + D_x(v)))
+        res = _attach(self._fused('energy', vars, absolute), fields, composed, absolute)
+        if res is None:
+            return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)
 
     def residual_induction(self, vars, boundary=False, absolute=False):
-        res = self._fused('induction', vars, absolute)
-        if res is None:
-            D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
+        D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
+        fields = (vars[:, 1], vars[:, 2], vars[:, 4], vars[:, 5])
 
-            def composed(u, v, Bx, By):
-                res_x = D_t(Bx) - By*D_y(u) + Bx*D_y(v) - v*D_y(Bx) + u*D_y(By)
-                res_y = D_t(By) + By*D_x(u) - Bx*D_x(v) - v*D_x(Bx) + u*D_x(By)
-                return res_x + res_y
-            res = _on_device((vars[:, 1], vars[:, 2], vars[:, 4], vars[:, 5]), composed)
-            return _finish(res, boundary, _CROP3, absolute, False)
+        def composed(u, v, Bx, By):
+            res_x = D_t(Bx) - By*D_y(u) + Bx*D_y(v) - v*D_y(Bx) + u*D_y(By)
+            res_y = D_t(By) + By*D_x(u) - Bx*D_x(v) - v*D_x(Bx) + u*D_x(By)
+            return res_x + res_y
+        res = _attach(self._fused('induction', vars, absolute), fields, composed, absolute)
+        if res is None:
+            return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)
 
     def residual_gauss(self, vars, boundary=False, absolute=False):
@@ -301,10 +318,14 @@ class Burgers:
 
     def residual(self, uu, boundary=False, absolute=False):
         dx, dt, nu = self.dx, self.dt, self.nu
-        fused = self.fused and not _dispatch.needs_grad(uu, self.D_t.kernel, self.D_x.kernel, self.D_xx.kernel)
+        def composed(uu):
+            dxd, dtd, nud = (c.to(uu.device) for c in (dx, dt, nu))
+            return dxd * self.D_t(uu) + dtd * uu * self.D_x(uu) - nud * self.D_xx(uu) * (2 * dtd / dxd)
+        fused = self.fused and not _dispatch.needs_grad(self.D_t.kernel, self.D_x.kernel, self.D_xx.kernel)
         ks = [_dispatch.dense9(o.kernel) for o in (self.D_t, self.D_x, self.D_xx)] if fused else [None]
         if all(k is not None for k in ks) and uu.dim() == 3:
-            (du,), origin = _stage((uu,))
+            with torch.no_grad():
+                (du,), origin = _stage((uu,))
             out = _lib.empty_like_layout(du)
             c3 = float(2 * dt / dx)                       # evaluated in fp32 like the reference
             with torch.cuda.device(du.device):
@@ -313,10 +334,6 @@ class Burgers:
                     float(dx), float(dt), float(nu), c3,
                     *du.shape, _lib.PRE_FLAG_ABS if absolute else 0, _lib.stream()))
             if ok:
-                res = _dispatch.from_device(out, origin)
+                res = _attach(_dispatch.from_device(out, origin), (uu,), composed, absolute)
                 return res if boundary else res[_CROP2]
-
-        def composed(uu):
-            dxd, dtd, nud = (c.to(uu.device) for c in (dx, dt, nu))
-            return dxd * self.D_t(uu) + dtd * uu * self.D_x(uu) - nud * self.D_xx(uu) * (2 * dtd / dxd)
         return _finish(_on_device((uu,), composed), boundary, _CROP2, absolute, False)

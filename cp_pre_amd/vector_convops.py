@@ -30,10 +30,7 @@ def vectorize(a, b):
     return torch.stack((a, b))
 
 
-def linear2(f0, k0, f1, k1, ratio=1.0, flags=0):
-    """``K0(f0) + ratio*K1(f1)`` in one streaming pass; None if the fused kernel declines."""
-    if _dispatch.needs_grad(f0, f1, k0, k1):
-        return None                     # fused kernels have no backward: compose
+def _linear2_fused(f0, k0, f1, k1, ratio, flags):
     d0, d1 = _dispatch.dense27(k0), _dispatch.dense27(k1)
     if d0 is None or d1 is None or f0.shape != f1.shape or f0.dim() != 4:
         return None
@@ -52,6 +49,22 @@ def linear2(f0, k0, f1, k1, ratio=1.0, flags=0):
         return None
     _lib.check(rc, "pre_residual_linear2_f32")
     return _dispatch.from_device(out, origin)
+
+
+def linear2(f0, k0, f1, k1, ratio=1.0, flags=0):
+    """``K0(f0) + ratio*K1(f1)`` in one streaming pass; None if the fused kernel declines.  Differentiable: a
+    backward recomputes the two single-operator passes (``_dispatch.fused_or_composed``)."""
+    if not isinstance(k0, torch.Tensor) or not isinstance(k1, torch.Tensor):
+        return None
+    with torch.no_grad():
+        out = _linear2_fused(f0, k0, f1, k1, ratio, flags)
+    if out is None or not _dispatch.needs_grad(f0, f1, k0, k1):
+        return out
+
+    def composed(a, ka, b, kb):
+        r = _dispatch.xcorr(a, ka, 3) + ratio * _dispatch.xcorr(b, kb, 3)
+        return r.abs() if flags & _lib.PRE_FLAG_ABS else r
+    return _dispatch._Recompute.apply(out, composed, f0, k0, f1, k1)
 
 
 class _Pair(ConvOperator):

@@ -21,7 +21,7 @@ import torch
 
 from . import _dispatch, _lib
 from .boundary_conditions import BoundaryManager
-from .convops_spatial import ConvOperator
+from .convops_spatial import ConvOperator, valid_conv
 
 _BC_MODE = {'dirichlet': 0, 'neumann': 1, 'outflow': 1, 'periodic': 2, 'symmetric': 3}
 
@@ -79,7 +79,7 @@ def _fused1(x, op, bc):
     """op(bc.pad_signal(x)) in one pass, or None."""
     st = _bc_struct(bc)
     k = _dispatch.dense9(op.kernel) if hasattr(op, "kernel") else None
-    if st is None or k is None or _dispatch.needs_grad(x, op.kernel) or _plane_view(x) is None:
+    if st is None or k is None or _plane_view(x) is None:
         return None
     dev, origin = _dispatch.to_device(x)
     v = _plane_view(dev)
@@ -99,7 +99,7 @@ def _fused2(x0, op0, x1, op1, ratio, bc):
     if st is None or not (hasattr(op0, "kernel") and hasattr(op1, "kernel")):
         return None
     k0, k1 = _dispatch.dense9(op0.kernel), _dispatch.dense9(op1.kernel)
-    if k0 is None or k1 is None or _dispatch.needs_grad(x0, x1, op0.kernel, op1.kernel):
+    if k0 is None or k1 is None:
         return None
     if _plane_view(x0) is None or _plane_view(x1) is None or x0.shape != x1.shape:
         return None
@@ -118,8 +118,20 @@ def _fused2(x0, op0, x1, op1, ratio, bc):
 
 
 def _apply(x, op, bc):
-    r = _fused1(x, op, bc)
-    return r if r is not None else op(bc.pad_signal(x))
+    """op(bc.pad_signal(x)): fused pad + stencil pass; differentiable through the pad-then-conv recipe."""
+    if not hasattr(op, "kernel") or op.conv != op.convolution:          # kernel-less operator, or conv='spectral'
+        return op(bc.pad_signal(x))
+    return _dispatch.fused_or_composed(lambda: _fused1(x, op, bc), lambda xx, kk: valid_conv(bc.pad_signal(xx), kk), x, op.kernel)
+
+
+def _apply2(x0, op0, x1, op1, ratio, bc):
+    """op0(pad(x0)) + ratio * op1(pad(x1)), fused when possible, differentiable either way."""
+    if not (hasattr(op0, "kernel") and hasattr(op1, "kernel")) or op0.conv != op0.convolution or op1.conv != op1.convolution:
+        return op0(bc.pad_signal(x0)) + ratio * op1(bc.pad_signal(x1))
+    return _dispatch.fused_or_composed(
+        lambda: _fused2(x0, op0, x1, op1, ratio, bc),
+        lambda a, ka, b, kb: valid_conv(bc.pad_signal(a), ka) + ratio * valid_conv(bc.pad_signal(b), kb),
+        x0, op0.kernel, x1, op1.kernel)
 
 
 class _WithBC(ConvOperator):
@@ -168,11 +180,7 @@ class Divergence(_WithBC):        # 2 -> 1
         self._set_bc(taylor_order, boundary_cond)
 
     def __call__(self, input_x, input_y):
-        r = _fused2(input_x, self.grad_x, input_y, self.grad_y, 1.0, self.bc)
-        if r is not None:
-            return r
-        px, py = self.bc.pad_signal(input_x), self.bc.pad_signal(input_y)
-        return self.grad_x(px) + self.grad_y(py)
+        return _apply2(input_x, self.grad_x, input_y, self.grad_y, 1.0, self.bc)
 
 
 class Curl(_WithBC):              # 2 -> 1
@@ -184,11 +192,7 @@ class Curl(_WithBC):              # 2 -> 1
         self._set_bc(taylor_order, boundary_cond)
 
     def __call__(self, input_x, input_y):
-        r = _fused2(input_y, self.grad_x, input_x, self.grad_y, -1.0, self.bc)      # grad_x(y) - grad_y(x)
-        if r is not None:
-            return r
-        px, py = self.bc.pad_signal(input_x), self.bc.pad_signal(input_y)
-        return self.grad_x(py) - self.grad_y(px)
+        return _apply2(input_y, self.grad_x, input_x, self.grad_y, -1.0, self.bc)      # grad_x(y) - grad_y(x)
 
 
 class Vector_Gradient(_WithBC):   # 2 -> 1

@@ -515,6 +515,32 @@ def test_autograd_matches_torch_conv(gpu):
         assert not C2("x", 1)(vd[:, 0]).requires_grad
 
 
+def test_fused_residuals_stay_differentiable(gpu):
+    """Fields that require grad (a surrogate's output outside torch.no_grad(), a physics-informed loss) still take
+    the fused HIP forward; a backward recomputes the composed route.  Forward == the fused result, gradients ==
+    those of the operator-by-operator expression (fused=False)."""
+    from cp_pre_amd import residuals as R
+    g = torch.Generator().manual_seed(77)
+    v = (torch.rand(2, 6, 6, 12, 64, generator=g) + 0.5).to(gpu)
+    u1 = (torch.rand(3, 10, 64, generator=g) + 0.5).to(gpu)
+    cases = [("ns_momentum", lambda f, x: R.NavierStokes(0.01, 0.05, 0.04, fused=f).residual_momentum(x[:, :3], True), v),
+             ("ns_continuity", lambda f, x: R.NavierStokes(0.01, 0.05, 0.04, fused=f).residual_continuity(x[:, :2], True), v),
+             ("mhd_induction", lambda f, x: R.MHD(fused=f).residual_induction(x, True, absolute=True), v),
+             ("mhd_energy", lambda f, x: R.MHD(fused=f).residual_energy(x, False), v),
+             ("burgers", lambda f, x: R.Burgers(0.03, 0.06, 0.002, fused=f).residual(x, True), u1)]
+    for name, fn, x in cases:
+        with torch.no_grad():
+            plain = fn(True, x)
+        xa = x.clone().requires_grad_(True)
+        ya = fn(True, xa)
+        assert ya.requires_grad and torch.equal(ya.detach(), plain), name          # the fused forward, bit for bit
+        w = torch.randn(ya.shape, generator=g).to(gpu)
+        (ya * w).sum().backward()
+        xb = x.clone().requires_grad_(True)
+        (fn(False, xb) * w).sum().backward()
+        assert rel_err(xa.grad.cpu().numpy(), xb.grad.cpu().numpy()) <= 1e-5, name
+
+
 def test_kernel_gradient_single_pass(gpu):
     """pre_stencil3d_wgrad_f32 (d loss / d kernel in one pass, used by autograd when the kernel requires grad -
     Physics_Informed/Wave_FNO_PI.py:206 sets it) against torch's conv backward, 3-D and 2-D, odd and ragged sizes,
@@ -933,11 +959,18 @@ def test_spatial_family_matches_reference_golden(gpu):
         Ls = V.Laplace(device=gpu)
         Ls.bc.set_boundary_type("left", "symmetric")                       # left symmetric + right periodic: no fused mapping
         assert V._fused1(big.to(gpu), Ls.laplace, Ls.bc) is None
-    assert V._fused1(big.to(gpu), L.laplace, L.bc) is None                # grad mode: composed (differentiable) route
-    # gradients flow through the composed route (CNS.py trains through these operators)
-    xg = big.to(gpu).requires_grad_(True)
-    V.Divergence(scale=2.0, device=gpu)(xg, xg).pow(2).sum().backward()
-    assert xg.grad is not None and torch.isfinite(xg.grad).all()
+    # grad mode: the forward is still the fused pass; a backward recomputes through the differentiable pad + stencil
+    # recipe (CNS.py trains through these operators), so gradients equal those of the composed route
+    Dv = V.Divergence(scale=2.0, device=gpu)
+    xg, yg = big.to(gpu).requires_grad_(True), (0.5 * big).to(gpu).requires_grad_(True)
+    out = Dv(xg, yg)
+    assert out.requires_grad
+    out.pow(2).sum().backward()
+    xc, yc = big.to(gpu).requires_grad_(True), (0.5 * big).to(gpu).requires_grad_(True)
+    Dc = V.Divergence(scale=2.0, device=gpu)        # a second instance: the kernels are non-leaf (scale * stencil) tensors
+    (Dc.grad_x(Dc.bc.pad_signal(xc)) + Dc.grad_y(Dc.bc.pad_signal(yc))).pow(2).sum().backward()
+    assert rel_err(xg.grad.cpu().numpy(), xc.grad.cpu().numpy()) <= 1e-5
+    assert rel_err(yg.grad.cpu().numpy(), yc.grad.cpu().numpy()) <= 1e-5
 
 
 def test_spectral_family_matches_reference_golden(gpu):
