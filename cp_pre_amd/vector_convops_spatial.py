@@ -75,15 +75,16 @@ def _plane_view(x):
     return x[:, 0]
 
 
-def _fused1(x, op, bc):
-    """op(bc.pad_signal(x)) in one pass, or None."""
+def _fused1(x, op, bc, dst=None):
+    """op(bc.pad_signal(x)) in one pass, or None.  ``dst``: optional [BS,1,Nx,Ny] device view to write into (a
+    channel of a stacked result)."""
     st = _bc_struct(bc)
     k = _dispatch.dense9(op.kernel) if hasattr(op, "kernel") else None
     if st is None or k is None or _plane_view(x) is None:
         return None
     dev, origin = _dispatch.to_device(x)
     v = _plane_view(dev)
-    out = torch.empty(dev.shape, dtype=torch.float32, device=dev.device)
+    out = torch.empty(dev.shape, dtype=torch.float32, device=dev.device) if dst is None else dst
     with torch.cuda.device(dev.device):
         rc = _lib.load().pre_spatial2d_bc_f32(_lib.ptr(v), _lib.iarr64(v.stride()), _lib.ptr(out),
                                               _lib.iarr64(out[:, 0].stride()), k, ctypes.byref(st), *v.shape, 0, _lib.stream())
@@ -124,6 +125,23 @@ def _apply(x, op, bc):
     return _dispatch.fused_or_composed(lambda: _fused1(x, op, bc), lambda xx, kk: valid_conv(bc.pad_signal(xx), kk), x, op.kernel)
 
 
+def _stack2(x0, op0, x1, op1, bc):
+    """cat(op0(pad(x0)), op1(pad(x1)), dim=1): both fused passes write straight into the two channels."""
+    def composed(a, ka, b, kb):
+        return torch.cat((valid_conv(bc.pad_signal(a), ka), valid_conv(bc.pad_signal(b), kb)), dim=1)
+    ok = all(hasattr(o, "kernel") and o.conv == o.convolution for o in (op0, op1)) and x0.shape == x1.shape \
+        and x0.dim() == 4 and x0.shape[1] == 1 and x0.is_cuda and x1.is_cuda and x0.device == x1.device
+    if not ok:
+        return torch.cat((_apply(x0, op0, bc), _apply(x1, op1, bc)), dim=1)
+
+    def fused():
+        out = torch.empty((x0.shape[0], 2) + tuple(x0.shape[2:]), dtype=torch.float32, device=x0.device)
+        if _fused1(x0, op0, bc, out[:, 0:1]) is None or _fused1(x1, op1, bc, out[:, 1:2]) is None:
+            return None
+        return out
+    return _dispatch.fused_or_composed(fused, composed, x0, op0.kernel, x1, op1.kernel)
+
+
 def _apply2(x0, op0, x1, op1, ratio, bc):
     """op0(pad(x0)) + ratio * op1(pad(x1)), fused when possible, differentiable either way."""
     if not (hasattr(op0, "kernel") and hasattr(op1, "kernel")) or op0.conv != op0.convolution or op1.conv != op1.convolution:
@@ -151,7 +169,7 @@ class Gradient(_WithBC):          # 1 -> 2
     def __call__(self, input_x, input_y=None):
         if input_y is None:
             input_y = input_x
-        return torch.cat((_apply(input_x, self.grad_x, self.bc), _apply(input_y, self.grad_y, self.bc)), dim=1)
+        return _stack2(input_x, self.grad_x, input_y, self.grad_y, self.bc)
 
 
 class Laplace(_WithBC):           # 1 -> 1 (scalar) or 2 -> 2 (vector)
@@ -163,12 +181,11 @@ class Laplace(_WithBC):           # 1 -> 1 (scalar) or 2 -> 2 (vector)
         self._set_bc(taylor_order, boundary_cond)
 
     def __call__(self, input_x, input_y=None):
-        lx = _apply(input_x, self.laplace, self.bc)
         if self.scalar == True:                    # noqa: E712
-            return lx
+            return _apply(input_x, self.laplace, self.bc)
         if input_y is None:
             input_y = input_x
-        return torch.cat((lx, _apply(input_y, self.laplace, self.bc)), dim=1)
+        return _stack2(input_x, self.laplace, input_y, self.laplace, self.bc)
 
 
 class Divergence(_WithBC):        # 2 -> 1
