@@ -94,8 +94,10 @@ def test_fuzz_fused_residuals_against_oracle(gpu):
     rng = np.random.default_rng(7)
     gen = torch.Generator().manual_seed(7)
     for case in range(max(8, CASES // 4)):
-        B, T, X = int(rng.integers(1, 4)), int(rng.integers(1, 9)), int(rng.integers(1, 30))
+        B, T, X = int(rng.integers(1, 4)), int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 15, 21, 30, 47, 64, 95])), int(rng.integers(1, 30))
         Y = int(rng.choice([4, 8, 12, 60, 64, 68, 128, 200, 256, 260, 510, 512]))
+        if T > 8 and Y > 128:
+            Y = int(rng.choice([4, 8, 12, 60, 64, 68, 128]))            # keep the CPU oracle quick
         boundary = bool(rng.random() < 0.5)
         if not boundary and min(T, X, Y) < 3:
             boundary = True
