@@ -202,7 +202,8 @@ def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
-def _xcorr_impl(field, kernel, nd, flags=0):
+def _xcorr_impl(field, kernel, nd, flags=0, out=None):
+    """``out``: optional fp32 device tensor of the field's shape to write into (e.g. one slot of a stacked result)."""
     _check_field(field)
     karr = host_kernel(kernel)
     if karr.ndim != nd:
@@ -216,7 +217,10 @@ def _xcorr_impl(field, kernel, nd, flags=0):
         raise RuntimeError(f"expected a {nd + 1}-D field [BS,Nt,Nx{',Ny' if nd == 3 else ''}], got {tuple(field.shape)}")
     lib = _lib.load()
     dev, origin = to_device(field)
-    out = _lib.empty_like_layout(dev)
+    if out is None:
+        out = _lib.empty_like_layout(dev)
+    elif not (out.is_cuda and out.shape == dev.shape and out.dtype == torch.float32):
+        raise ValueError("out must be an fp32 device tensor of the field's shape")
     if out.numel() == 0:
         return from_device(out, origin)
     wv = _lib.farr(w) if len(w) else (ctypes.c_float * 1)()

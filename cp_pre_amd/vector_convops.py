@@ -80,11 +80,24 @@ class Divergence(_Pair):
         return fused if fused is not None else self.grad_x(input_x) + self.grad_y(input_y)
 
 
+def _stack2(x0, op0, x1, op1):
+    """torch.stack((op0(x0), op1(x1))): when nothing needs a gradient and the fields live on the device, the two
+    stencil passes write straight into the two slots of the result."""
+    ok = all(hasattr(o, "kernel") and o.conv == o.convolution for o in (op0, op1)) and x0.shape == x1.shape and x0.dim() == 4 \
+        and x0.is_cuda and x1.is_cuda and not _dispatch.needs_grad(x0, x1, op0.kernel, op1.kernel)
+    if not ok:
+        return torch.stack((op0(x0), op1(x1)))
+    out = torch.empty((2,) + tuple(x0.shape), dtype=torch.float32, device=x0.device)
+    _dispatch._xcorr_impl(x0, op0.kernel, 3, 0, out=out[0])
+    _dispatch._xcorr_impl(x1, op1.kernel, 3, 0, out=out[1])
+    return out
+
+
 class Gradient(_Pair):
     def __call__(self, input_x, input_y=None):
         if input_y is None:
             input_y = input_x
-        return torch.stack((self.grad_x(input_x), self.grad_y(input_y)))
+        return _stack2(input_x, self.grad_x, input_y, self.grad_y)
 
 
 class Curl(_Pair):
@@ -102,4 +115,4 @@ class Laplace(ConvOperator):
     def __call__(self, input_x, input_y=None):
         if input_y is None:
             input_y = input_x
-        return torch.stack((self.laplace(input_x), self.laplace(input_y)))
+        return _stack2(input_x, self.laplace, input_y, self.laplace)
