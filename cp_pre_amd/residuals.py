@@ -80,6 +80,8 @@ class _Residual2D:
         """The fused kernels run whatever the fields' ``requires_grad`` (``_attach`` keeps the result
         differentiable by recomputation); only operator KERNELS that require grad force the composed route, so
         that their gradients flow."""
+        if any(isinstance(t, torch.Tensor) and t.numel() == 0 for t in tensors):
+            return False                                    # empty batch: the composed route returns empty tensors
         return self.fused and not _dispatch.needs_grad(*[getattr(o, "kernel", None) for o in
                                                          (self.D_t, self.D_x, self.D_y, self.D_xx_yy)])
 
@@ -321,7 +323,7 @@ class Burgers:
         def composed(uu):
             dxd, dtd, nud = (c.to(uu.device) for c in (dx, dt, nu))
             return dxd * self.D_t(uu) + dtd * uu * self.D_x(uu) - nud * self.D_xx(uu) * (2 * dtd / dxd)
-        fused = self.fused and not _dispatch.needs_grad(self.D_t.kernel, self.D_x.kernel, self.D_xx.kernel)
+        fused = self.fused and uu.numel() > 0 and not _dispatch.needs_grad(self.D_t.kernel, self.D_x.kernel, self.D_xx.kernel)
         ks = [_dispatch.dense9(o.kernel) for o in (self.D_t, self.D_x, self.D_xx)] if fused else [None]
         if all(k is not None for k in ks) and uu.dim() == 3:
             with torch.no_grad():

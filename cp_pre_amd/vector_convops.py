@@ -32,7 +32,7 @@ def vectorize(a, b):
 
 def _linear2_fused(f0, k0, f1, k1, ratio, flags):
     d0, d1 = _dispatch.dense27(k0), _dispatch.dense27(k1)
-    if d0 is None or d1 is None or f0.shape != f1.shape or f0.dim() != 4:
+    if d0 is None or d1 is None or f0.shape != f1.shape or f0.dim() != 4 or f0.numel() == 0:
         return None
     _dispatch._check_field(f0)
     _dispatch._check_field(f1)

@@ -448,6 +448,17 @@ def test_edge_shapes_and_layouts(gpu):
     assert Z(torch.randn(1, 2, 3, 4, generator=g).to(gpu)).abs().max().item() == 0.0
 
 
+def test_empty_batches_through_the_residual_classes(gpu):
+    """A zero-sample batch returns empty tensors of the right shape (as the reference's torch expressions do)."""
+    from cp_pre_amd import residuals as R
+    v = torch.zeros(0, 6, 5, 8, 16, device=gpu)
+    assert R.NavierStokes(0.01, 0.1, 0.1).residual_momentum(v[:, :3], True).shape == (0, 5, 8, 16)
+    assert R.NavierStokes(0.01, 0.1, 0.1).residual_continuity(v[:, :2]).shape == (0, 3, 6, 14)
+    assert R.MHD().residual_induction(v, True).shape == (0, 5, 8, 16)
+    assert R.Burgers(0.1, 0.1, 0.01).residual(torch.zeros(0, 6, 16, device=gpu), True).shape == (0, 6, 16)
+    assert R.PRE_Wave(0.01, 0.02).residual(v[:, :1], boundary=True).shape == (0, 5, 8, 16)
+
+
 def test_calibration_edge_cases(gpu):
     """n=1, all-equal scores (ties everywhere), M not a multiple of the 64-cell tile, ranks 0 and n-1,
     more ranks than one launch group (12 > 10), negative and mixed-sign scores."""
