@@ -3,10 +3,12 @@
 signatures: ``calibrate``, ``modulation_func``, ``ncf_metric_joint``, ``emp_cov``,
 ``emp_cov_joint`` (+ ``filter_sims_joint``, ``Joint/Burgers_Residuals_CP.py:298-300``).
 
-PARITY UNPINNED: that module is an un-vendored, un-pinned submodule absent from the
-reference snapshot; the definitions implemented here are the standard split-CP forms
-inferred from the call sites and from ``Tests/test_advection_inv_sampling_marginal.py:428-431,465``
-(SURVEY.md 8a a11-a14, 8c).  They are tested against numpy (``oracle/conformal.py``).
+That module is an un-vendored, un-pinned submodule absent from the reference snapshot.
+``modulation_func``, ``ncf_metric_joint`` and joint coverage are pinned to vectors produced by
+executing the reference's in-tree restatement (``Tests/test_advection_inv_sampling_marginal.py:428,
+430-431,464-465`` -> ``tests/golden/conformal_ref.npz``); ``calibrate`` has no source or restatement
+anywhere in the reference (PARITY UNPINNED, permanently): it is the standard split-CP quantile
+inferred from the call sites, tested against numpy.
 
     calibrate(scores, n, alpha)        = np.quantile(scores, ceil((n+1)(1-alpha))/n, axis=0, method='higher')
     modulation_func(a, b)              = np.std(a - b, axis=0)

@@ -1,15 +1,20 @@
 """Oracle (TEST INFRASTRUCTURE): split-conformal calibration in numpy.
 
-PARITY UNPINNED.  The reference imports these five functions from
-``Neural_PDE.UQ.inductive_cp`` (``Marginal/NS_Residuals_CP.py:58``,
-``Joint/Burgers_Residuals_CP.py:56-59``), an un-vendored submodule
-(``.gitmodules:1-3``) that is empty in the reference snapshot; no reference test
-pins a number at this boundary.  The forms below are the standard split-CP
-definitions, inferred from the call sites
-(``Marginal/Wave_Residuals_CP.py:253,288-290``,
-``Joint/Burgers_Residuals_CP.py:219-220,257-259,283-285,298-300``) and
-corroborated by the only in-repo restatement,
-``Tests/test_advection_inv_sampling_marginal.py:428-431,465``.
+The reference imports these functions from ``Neural_PDE.UQ.inductive_cp``
+(``Marginal/NS_Residuals_CP.py:58``, ``Joint/Burgers_Residuals_CP.py:56-59``), an un-vendored
+submodule (``.gitmodules:1-3``) that is empty in the reference snapshot.  Pin status per function:
+
+* ``modulation_func``, ``ncf_metric_joint``, ``filter_sims_joint`` / ``emp_cov_joint``: **PINNED** to
+  outputs of the reference's own in-tree statements -
+  ``Tests/test_advection_inv_sampling_marginal.py:428`` (modulation), ``:430-431``
+  (``conf_metric_joint``), ``:464-465`` (prediction sets + joint coverage) and
+  ``Joint/Burgers_Residuals_CP.py:298-300`` (``filter_sims_joint``), compiled from those files and
+  executed by ``tests/golden/make_golden.py`` -> ``tests/golden/conformal_ref.npz``, ``filters.npz``.
+* ``filter_sims_within_bounds``: PINNED (``Active_Learning/Advection_AL_Marginal.py:169-198``).
+* ``calibrate`` (and ``emp_cov``, its marginal counterpart): **PARITY UNPINNED, permanently** - no
+  source and no restatement exists anywhere in the reference tree.  The form below is the standard
+  split-CP quantile inferred from the call sites (``Marginal/Wave_Residuals_CP.py:253,288-290``,
+  ``Joint/Burgers_Residuals_CP.py:257,283``); it is tested against numpy only.
 """
 from __future__ import annotations
 

@@ -20,9 +20,14 @@ What is executed from the reference (nothing of it is copied into this repo):
     compiled from it the same way -> filters.npz
   * ``Utils/ConvOps_Spatial.py``, ``Utils/boundary_conditions.py``, ``Utils/VectorConvOps_Spatial.py``
     - imported on CPU -> spatial.npz
-  * conformal.npz is BUILD-DEFINED (numpy, oracle/conformal.py): the reference's
-    ``Neural_PDE.UQ.inductive_cp`` is absent, so these vectors pin the oracle to numpy,
-    not to the reference ("parity unpinned").
+  * the inline joint-CP recipe of ``Tests/test_advection_inv_sampling_marginal.py`` - the only place the
+    reference tree itself states what modulation / joint score / joint coverage compute: the
+    ``modulation = np.std(...)`` assignment (:428), the ``conf_metric_joint`` def (:430-431) and the
+    prediction-set + coverage statements of the alpha loop (:464-465), compiled from that file with
+    ``ast`` and executed on seeded arrays -> conformal_ref.npz (pins a12, a13 and joint coverage)
+  * conformal.npz is BUILD-DEFINED (numpy, oracle/conformal.py) and now matters for ``calibrate``
+    only: its source, ``Neural_PDE.UQ.inductive_cp``, is absent and nothing in the reference tree
+    restates it, so q-hat's rank convention stays "parity unpinned".
 """
 import ast
 import importlib.util
@@ -120,6 +125,19 @@ def ref_assign_value(relpath, target_src):
     raise KeyError(target_src)
 
 
+def ref_loop_body(relpath, must_contain, skip_targets=()):
+    """Compile the body of the first top-level ``for`` loop whose source contains ``must_contain``,
+    leaving out assignments to ``skip_targets`` (names the caller supplies instead)."""
+    path = os.path.join(REF, relpath)
+    tree = ast.parse(open(path).read(), path)
+    for n in tree.body:
+        if isinstance(n, ast.For) and must_contain in ast.unparse(n):
+            body = [b for b in n.body
+                    if not (isinstance(b, ast.Assign) and ast.unparse(b.targets[0]) in skip_targets)]
+            return compile(ast.Module(body=body, type_ignores=[]), path, "exec"), [ast.unparse(b) for b in body]
+    raise KeyError(must_contain)
+
+
 def ops2d():
     return dict(D_t=Ref2D(domain="t", order=1), D_x=Ref2D(domain="x", order=1),
                 D_y=Ref2D(domain="y", order=1), D_xx_yy=Ref2D(domain=("x", "y"), order=2))
@@ -180,7 +198,8 @@ def gen_conformal():
     """BUILD-DEFINED vectors (numpy): not reference-derived."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     from oracle import conformal as oc
-    out = {"_note": np.array("build-defined, not reference-derived (Neural_PDE.UQ.inductive_cp absent)")}
+    out = {"_note": np.array("build-defined, not reference-derived (Neural_PDE.UQ.inductive_cp absent); authoritative for "
+                             "calibrate only - modulation / joint score / joint coverage are pinned by conformal_ref.npz")}
     rng = np.random.default_rng(7)
     for n in (7, 100, 256):
         s = np.abs(rng.standard_normal((n, 5, 6))).astype(np.float32)
@@ -202,6 +221,53 @@ def gen_conformal():
             except ValueError:
                 out[f"k|{n}|{i}"] = np.array(-1)             # level > 1: numpy raises
     np.savez_compressed(os.path.join(HERE, "conformal.npz"), **out)
+
+
+def gen_conformal_ref():
+    """REFERENCE-EXECUTED vectors for modulation / joint score / joint prediction sets / joint coverage.
+
+    ``Tests/test_advection_inv_sampling_marginal.py`` cannot be imported (top-level ``from Neural_PDE...``,
+    data and weights absent), so its statements are compiled one by one from the file and run on seeded
+    [n, Nt, Nx] residual arrays.  ``calibrate`` is absent from the reference, so q-hat is SUPPLIED (fixed
+    values and, per alpha, the build's numpy q-hat): what is pinned is everything around it."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import conformal as oc
+    rel = "Tests/test_advection_inv_sampling_marginal.py"
+    mod_rhs = ref_assign_value(rel, "modulation")                        # :428 (first top-level assignment)
+    score_def = ref_defs(rel, ["conf_metric_joint"])                     # :430-431
+    loop, stmts = ref_loop_body(rel, ".all(axis", skip_targets=("qhat",))   # :464-465
+    assert len(stmts) == 2 and stmts[0].startswith("prediction_sets") and "emp_cov_res.append" in stmts[1], stmts
+    out = {"_note": np.array("executed from the reference: Tests/test_advection_inv_sampling_marginal.py:428,430-431,464-465; "
+                             "q-hat supplied (calibrate is absent from the reference)")}
+    rng = np.random.default_rng(23)
+    for n in (7, 100, 256):
+        shape = (n, 9, 14)
+        cal = rng.standard_normal(shape).astype(np.float32) * np.linspace(0.5, 2.0, 14, dtype=np.float32)
+        pred = rng.standard_normal((31,) + shape[1:]).astype(np.float32) * 0.05
+        val = (pred + 0.8 * rng.standard_normal(pred.shape) * np.linspace(0.5, 2.0, 14)).astype(np.float32)
+        ns = {"np": np, "cal_residual": torch.from_numpy(cal), "pred_residual": torch.from_numpy(pred),
+              "val_residual": torch.from_numpy(val)}
+        ns["modulation"] = eval(mod_rhs, ns)
+        exec(score_def, ns)
+        scores = ns["conf_metric_joint"](ns["cal_residual"][:, 1:-1, 1:-1].numpy())
+        out[f"cal|{n}"], out[f"pred|{n}"], out[f"val|{n}"] = cal, pred, val
+        out[f"mod|{n}"], out[f"jscore|{n}"] = ns["modulation"], scores
+        qs = [1.0, 2.5, 4.0]
+        for a in oc.ALPHA_LEVELS:
+            try:
+                qs.append(float(oc.calibrate(scores, n, a)))
+            except ValueError:
+                pass
+        out[f"qhats|{n}"] = np.array(qs, np.float64)
+        covs = []
+        for i, q in enumerate(qs):
+            ns["qhat"], ns["emp_cov_res"] = np.float32(q), []
+            exec(loop, ns)
+            covs.append(ns["emp_cov_res"][0])
+            if i < 3:
+                out[f"lo|{n}|{i}"], out[f"hi|{n}|{i}"] = ns["prediction_sets"]
+        out[f"cov_joint|{n}"] = np.array(covs, np.float64)
+    np.savez_compressed(os.path.join(HERE, "conformal_ref.npz"), **out)
 
 
 def gen_filters():
@@ -301,6 +367,12 @@ if __name__ == "__main__":
     if "spectral" in sys.argv[1:]:
         gen_spectral()
         sys.exit(0)
+    if "conformal" in sys.argv[1:]:
+        gen_conformal()
+        sys.exit(0)
+    if "conformal_ref" in sys.argv[1:]:
+        gen_conformal_ref()
+        sys.exit(0)
     if "filters" in sys.argv[1:]:
         gen_filters()
         sys.exit(0)
@@ -311,6 +383,7 @@ if __name__ == "__main__":
     gen_apply(ks)
     gen_residuals()
     gen_conformal()
+    gen_conformal_ref()
     gen_filters()
     gen_spatial()
     gen_spectral()

@@ -300,6 +300,38 @@ def test_conformal_golden_vectors(gpu, golden):
             j += 1
 
 
+def test_conformal_reference_executed_vectors(gpu):
+    """a12 modulation_func, a13 ncf_metric_joint and joint coverage against vectors produced by EXECUTING the
+    reference's own statements (Tests/test_advection_inv_sampling_marginal.py:428,430-431,464-465; see
+    tests/golden/make_golden.py::gen_conformal_ref).  Bit-exact: fp32 numpy-order std, IEEE division, max."""
+    from conftest import load_golden
+    from cp_pre_amd import inductive_cp as icp
+    g = load_golden("conformal_ref.npz")
+    for n in (7, 100, 256):
+        cal, pred, val = g[f"cal|{n}"], g[f"pred|{n}"], g[f"val|{n}"]
+        cal_c, pred_c, val_c = (np.ascontiguousarray(a[:, 1:-1, 1:-1]) for a in (cal, pred, val))
+        for b in (None, np.zeros_like(cal_c)):                       # "no second argument", both spellings
+            mod = icp.modulation_func(cal_c, b)
+            assert mod.dtype == np.float32 and np.array_equal(mod, g[f"mod|{n}"]), n
+            js = icp.ncf_metric_joint(cal_c, b, mod)
+            assert js.dtype == np.float32 and np.array_equal(js, g[f"jscore|{n}"]), n
+        # device tensors, uncropped input + fused interior crop: same numbers
+        cal_d = torch.from_numpy(cal).to(gpu)
+        mod_d = icp.modulation_func(cal_d[:, 1:-1, 1:-1], None)
+        assert np.array_equal(mod_d.cpu().numpy(), g[f"mod|{n}"])
+        js_d = icp.ncf_metric_joint(cal_d[:, 1:-1, 1:-1], None, mod_d)
+        assert np.array_equal(js_d.cpu().numpy(), g[f"jscore|{n}"])
+        qs, covs = g[f"qhats|{n}"], g[f"cov_joint|{n}"]
+        for i, q in enumerate(qs):
+            sets = [pred_c - np.float32(q) * mod, pred_c + np.float32(q) * mod]
+            assert icp.emp_cov_joint(sets, val_c) == float(covs[i]), (n, i)
+            assert np.array_equal(icp.filter_sims_joint(sets, val_c),
+                                  (val_c >= sets[0]).all(axis=(1, 2)) & (val_c <= sets[1]).all(axis=(1, 2)))
+        # the scripts' modulation_func(res, np.zeros(res.shape)) promotes to float64: <= 1e-6 of the pinned fp32 value
+        mod64 = icp.modulation_func(cal_c, np.zeros(cal_c.shape))
+        assert mod64.dtype == np.float64 and np.max(np.abs(mod64 - g[f"mod|{n}"]) / g[f"mod|{n}"]) <= 2e-6
+
+
 @pytest.mark.parametrize("n,cells", [(33, (5, 7)), (129, (70,)), (256, (9, 33)), (512, (3, 40, 50)), (1000, (4099,)), (4096, (2, 16, 48))])
 def test_marginal_qhat_bit_exact_vs_numpy(gpu, n, cells):
     """Per-cell radix select over the batch axis: ragged cell counts, ties, negatives, +-0, inf."""

@@ -135,6 +135,30 @@ def test_conformal_build_defined_vectors(golden):
             assert float(oc.emp_cov_joint([-qj * mod, qj * mod], r)) == float(g[f"cov_joint|{n}|{i}"])
 
 
+def test_conformal_reference_executed_vectors():
+    """a12 / a13 / joint coverage PINNED: the oracle against what the reference's own statements
+    (Tests/test_advection_inv_sampling_marginal.py:428 modulation, :430-431 conf_metric_joint, :464-465
+    prediction sets + coverage), compiled from that file by tests/golden/make_golden.py, produced."""
+    from conftest import load_golden
+    g = load_golden("conformal_ref.npz")
+    assert "executed from the reference" in str(g["_note"])
+    for n in (7, 100, 256):
+        cal, pred, val = g[f"cal|{n}"], g[f"pred|{n}"], g[f"val|{n}"]
+        cal_c, pred_c, val_c = cal[:, 1:-1, 1:-1], pred[:, 1:-1, 1:-1], val[:, 1:-1, 1:-1]
+        mod = oc.modulation_func(cal_c, np.zeros_like(cal_c))
+        assert mod.dtype == np.float32 and np.array_equal(mod, g[f"mod|{n}"])
+        js = oc.ncf_metric_joint(cal_c, np.zeros_like(cal_c), mod)
+        assert js.dtype == np.float32 and np.array_equal(js, g[f"jscore|{n}"])
+        qs, covs = g[f"qhats|{n}"], g[f"cov_joint|{n}"]
+        assert len(qs) == len(covs) >= 3 + 9
+        for i, q in enumerate(qs):
+            sets = [pred_c - np.float32(q) * mod, pred_c + np.float32(q) * mod]
+            if i < 3:
+                assert np.array_equal(sets[0], g[f"lo|{n}|{i}"]) and np.array_equal(sets[1], g[f"hi|{n}|{i}"])
+            assert float(oc.emp_cov_joint(sets, val_c)) == float(covs[i]), (n, i)
+        assert covs.min() < covs.max() <= 1.0 and len(np.unique(covs)) >= 3      # the vectors discriminate
+
+
 def test_inline_joint_recipe_of_reference_tests():
     """Tests/test_advection_inv_sampling_marginal.py:428-431,465 restated with numpy only."""
     rng = np.random.default_rng(0)
