@@ -5,12 +5,13 @@ Workload (BASELINE.json configs[2], the one the north_star target is quoted on):
 Navier-Stokes momentum residual of (u, v, p) on [4096, 64, 512, 512] fp32 per rank, followed
 by conformal calibration over the 4096 samples at the reference's 10 alpha levels.
 
-One field of that shape is 275 GB, so the tensor is streamed as 8 t-slabs of
-[4096, 10, 512, 512] (8 interior planes + the 2 halo planes their stencils read); the three
-input slabs (129 GB) and the residual slab (43 GB) are resident in HBM before the timed
-region.  Synthetic data: one resident slab of B + 7 samples stands in for the 8 slab positions, slab
-position s reading the batch window [s, s + B) of it (825 GB of distinct input cannot be resident; the
-arithmetic and traffic per slab do not depend on the values).  One STEP = the whole [4096,64,512,512] job = 8 slab passes of
+One field of that shape is 275 GB, so the tensor is streamed as t-slabs: --slab S interior planes
+(default 13 -> 5 slabs of 13,13,13,13,12 planes) + the 2 halo planes their stencils read; the three
+input slabs [B,S+2,512,512] (194 GB) and the residual buffer [B,S,512,512] (56 GB: interior planes only,
+PRE_FLAG_OUT_INTERIOR_T) are resident in HBM before the timed region.  Synthetic data: one resident
+slab of B + n_slabs - 1 samples stands in for the slab positions, slab position s reading the batch
+window [s, s + B) of it (825 GB of distinct input cannot be resident; the arithmetic and traffic per
+slab do not depend on the values).  One STEP = the whole [4096,64,512,512] job = n_slabs passes of
     fused NS-momentum residual (one HIP launch)  ->  calibration on the resident residual slab
 and the final q-hat selection.  cells/step = 4096*64*512*512 (uncropped grid).
 
@@ -24,8 +25,15 @@ and the final q-hat selection.  cells/step = 4096*64*512*512 (uncropped grid, SU
 tensor resident, no slabs); they are secondary measurements quoted in DESIGN.md, not the
 contract line.  Default: c3.
 
+--gpus N: one process per GPU.  Launched by the driver under torch.distributed.run (WORLD_SIZE set) the
+process is one rank; launched bare with N > 1 it SPAWNS the N ranks itself (a fresh
+`python -m torch.distributed.run --standalone` child, before anything touches the GPU) and exits with
+the child's code; WORLD_SIZE != N is an error (exit 2).  --scaling weak (default): --batch samples per
+rank; strong: the --batch samples are split over the ranks.
+
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (fused
-residual kernel, HIP events on its stream) and `cpu_baseline` (the CPU oracle = the
+residual kernel, HIP events on its stream; `achieved` = SURVEY 8(d) bytes: 16 B x the interior
+cells one launch computes, halo planes NOT counted) and `cpu_baseline` (the CPU oracle = the
 reference's own F.conv3d arithmetic, timed on this box's host cores; N=1 only).
 """
 import argparse
@@ -70,7 +78,11 @@ def parse():
     ap.add_argument("--nt", type=int, default=None)
     ap.add_argument("--nx", type=int, default=None)
     ap.add_argument("--ny", type=int, default=None)
-    ap.add_argument("--slab", type=int, default=8, help="interior planes per t-slab")
+    ap.add_argument("--slab", type=int, default=13, help="interior planes per t-slab (c3)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch samples per rank; strong: --batch samples in total, split over the ranks")
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="initialise the process group, run one all-reduce, print the rank count and exit (no compute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     args = ap.parse_args()
@@ -82,6 +94,28 @@ def parse():
     args.nx = args.nx or shp[2]
     args.ny = args.ny or (shp[3] if len(shp) == 4 else 0)
     return args
+
+
+def launch_plan(gpus, environ, argv, script=None):
+    """What `bench.py --gpus N` has to do given the environment, decided before any GPU call:
+    ("run", world)   - this process is one of `world` ranks (or the only one);
+    ("spawn", cmd)   - bare `--gpus N` with N > 1: start N ranks under torch.distributed.run and relay the exit code;
+    ("error", text)  - WORLD_SIZE contradicts --gpus (exit 2: a wrong-size run must never report a number)."""
+    ws = environ.get("WORLD_SIZE")
+    if ws is None:
+        if gpus <= 1:
+            return "run", 1
+        return "spawn", [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+                         "--nnodes=1", "--nproc-per-node", str(gpus), script or os.path.abspath(__file__), *argv]
+    if int(ws) != gpus:
+        return "error", f"bench.py: WORLD_SIZE={ws} but --gpus {gpus}: launch with --nproc-per-node {gpus} (or pass --gpus {ws})"
+    return "run", int(ws)
+
+
+def split_slabs(nt, slab):
+    """Interior planes per t-slab: nt planes in ceil(nt/slab) slabs of nearly equal size (64, 13 -> 13,13,13,13,12)."""
+    n = max(1, -(-nt // slab))
+    return [nt // n + (1 if i < nt % n else 0) for i in range(n)]
 
 
 def synth_(field, seed, positive=False):
@@ -105,7 +139,7 @@ def synth_(field, seed, positive=False):
 SYNTH = "synthetic smooth-plus-noise fields (sin*cos*cos mode + 0.01 N(0,1); U(0.5,1.5) for rho, p), generated on device"
 
 
-def run_secondary(args, cfg, dev, group, rank, world):
+def run_secondary(args, cfg, dev, group, rank, world, par):
     """c1/c2/c4/c5: whole per-rank tensor resident; one step = fused residual + calibration."""
     from cp_pre_amd import inductive_cp as icp
     from cp_pre_amd import pipeline
@@ -174,10 +208,9 @@ def run_secondary(args, cfg, dev, group, rank, world):
         print(json.dumps({
             "metric": "residual-cells/s (PRE eval+calibrate)", "value": cells * world * args.steps / elapsed,
             "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": SYNTH + "; whole per-rank tensor resident",
-            "config": {"workload": f"{cfg['title']} {shape} per rank, {args.mode} CP, 10 alpha levels", "mode": args.mode,
-                       "parallelism": f"batch-sharded x{world}"},
+            "config": {"workload": f"{cfg['title']} {shape} per rank, {args.mode} CP, 10 alpha levels", "mode": args.mode, **par},
             "roofline": {"bound": "hbm", "kernel": cfg["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": kms,
                          "algorithmic_bytes_per_launch": launch_bytes}}), flush=True)
@@ -214,13 +247,13 @@ def host_cores():
     return n
 
 
-def cpu_baseline(args, alphas):
+def cpu_baseline(args, alphas, slab):
     """The oracle (reference arithmetic: F.conv3d per operator + torch elementwise + numpy
     calibration) on a bounded sample of the same workload, on this box's host cores."""
     import numpy as np
     from oracle import conformal as oc
     from oracle import residuals as orr
-    T = args.slab + 2
+    T = slab + 2
     dt, dx, dy = 1e-2, 1.0 / args.nx, 1.0 / args.ny
     threads = host_cores()
     torch.set_num_threads(threads)
@@ -242,65 +275,115 @@ def cpu_baseline(args, alphas):
     t_probe = run(4)
     nb = int(max(4, min(256, 4 * args.cpu_seconds / max(t_probe, 1e-3))))
     t = run(nb)
-    cells = nb * args.slab * args.nx * args.ny            # useful (interior-plane) cells, as in `value`
+    cells = nb * slab * args.nx * args.ny                 # useful (interior-plane) cells, as in `value`
     return {"value": cells / t, "unit": "cells/s", "cores": threads, "kind": "port",
             "sample": f"oracle NS-momentum + {args.mode} calibrate on [{nb},{T},{args.nx},{args.ny}] x3 fields "
                       f"(one slab, {nb}/{args.batch} of the batch), {t:.1f} s on {threads} torch threads"}
 
 
-def main():
-    args = parse()
+def init_ranks(args, world):
+    """(rank, device, group, rccl_ranks).  The process group is RCCL ("nccl" on ROCm) with one rank per GPU;
+    PRE_BENCH_REHEARSE=1 puts all ranks on GPU 0 over gloo - a plumbing rehearsal of the N>1 path on a
+    single-GPU box (RCCL refuses two ranks per device), never a measurement."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
-    # PRE_BENCH_REHEARSE=1: several ranks on ONE GPU over gloo - a plumbing rehearsal of the N>1
-    # path on a single-GPU box (RCCL refuses two ranks per device); never a measurement.
     rehearse = os.environ.get("PRE_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    group = None
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not args.plumbing_check:
+        raise SystemExit("bench.py needs the MI355X (no CPU fallback)")
+    dev = torch.device("cpu")
+    if have_gpu:
+        if rehearse:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    group, ranks = None, 1
     if world > 1 or os.environ.get("PRE_BENCH_FORCE_GROUP") == "1":     # the latter: RCCL at world size 1 (plumbing check)
         import torch.distributed as dist
-        if rehearse:
+        if rehearse or not have_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
         group = dist.group.WORLD
         # create the communicator (and its xGMI rings) now, not inside the first timed collective
-        warm = torch.zeros(1, dtype=torch.float64, device=dev)
+        warm = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(warm)
         dist.all_gather([torch.empty_like(warm) for _ in range(dist.get_world_size())], warm)
-        torch.cuda.synchronize()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+        if have_gpu:
+            torch.cuda.synchronize()
+        ranks = int(warm.item())                                # every rank contributed a 1
+        assert ranks == dist.get_world_size() == world, (ranks, dist.get_world_size(), world)
+    return rank, dev, group, ranks
 
-    if args.config != "c3":
-        run_secondary(args, CONFIGS[args.config], dev, group, rank, world)
+
+def main():
+    args = parse()
+    plan, what = launch_plan(args.gpus, os.environ, sys.argv[1:])
+    if plan == "error":
+        print(what, file=sys.stderr, flush=True)
+        return 2
+    if plan == "spawn":
+        # a FRESH child, started before this process has touched the GPU (never exec after HIP init)
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        return subprocess.run(what, env=env).returncode
+    world = what
+    if args.scaling == "strong":
+        if args.batch % world:
+            print(f"bench.py: --scaling strong needs --batch ({args.batch}) divisible by the rank count ({world})",
+                  file=sys.stderr, flush=True)
+            return 2
+        args.batch //= world
+    rank, dev, group, rccl_ranks = init_ranks(args, world)
+    par = {"parallelism": f"batch-sharded x{world} ({args.scaling} scaling: {args.batch} samples per rank)",
+           "rccl_ranks": rccl_ranks}
+
+    def done():
         if group is not None:
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
-        return
+        return 0
+
+    if args.plumbing_check:
+        if rank == 0:
+            print(json.dumps({"plumbing_check": True, "n_gpus": world, "rccl_ranks": rccl_ranks, "scaling": args.scaling,
+                              "batch_per_rank": args.batch, "backend": torch.distributed.get_backend() if group else None}),
+                  flush=True)
+        return done()
+
+    if args.config != "c3":
+        run_secondary(args, CONFIGS[args.config], dev, group, rank, world, par)
+        return done()
 
     from cp_pre_amd import inductive_cp as icp
     from cp_pre_amd import pipeline
     from cp_pre_amd.residuals import NavierStokes
 
-    B, T, X, Y = args.batch, args.slab + 2, args.nx, args.ny
-    n_slabs = max(1, args.nt // args.slab)
+    B, X, Y = args.batch, args.nx, args.ny
+    slabs = split_slabs(args.nt, args.slab)                   # interior planes per slab position
+    n_slabs, S = len(slabs), max(slabs)
     alphas = [float(a) for a in icp.ALPHA_LEVELS]
     dt, dx, dy = 1e-2, 1.0 / X, 1.0 / Y
     ns = NavierStokes(dt, dx, dy, nu=1e-3)
 
-    # resident synthetic slab: vars[:, i] views of one [B,3,T,X,Y] tensor, like the reference's `vars`
+    # resident synthetic slab: vars[:, i] views of one [B,3,S+2,X,Y] tensor, like the reference's `vars`
     torch.manual_seed(1234 + rank)
     # n_slabs - 1 extra samples: slab position s reads the batch window [s, s + B), so no two slab passes of a
     # step see the same input (and no layer of the memory system could serve one from another)
-    vars_ = torch.empty(B + n_slabs - 1, 3, T, X, Y, dtype=torch.float32, device=dev)
+    need = ((B + n_slabs - 1) * 3 * (S + 2) + B * S) * X * Y * 4
+    free = torch.cuda.mem_get_info(dev)[0]
+    if need > free - (2 << 30):
+        print(f"bench.py: --slab {args.slab} needs {need / 1e9:.0f} GB resident, {free / 1e9:.0f} GB free", file=sys.stderr, flush=True)
+        return 2
+    vars_ = torch.empty(B + n_slabs - 1, 3, S + 2, X, Y, dtype=torch.float32, device=dev)
     for i in range(3):
         synth_(vars_[:, i], 100 * rank + 20 + i)
-    res = torch.empty(B, T, X, Y, dtype=torch.float32, device=dev)
+    # residual buffer: the slab's INTERIOR planes only (the slab's first and last plane are halo planes that every
+    # consumer would crop: they are neither computed nor stored, PRE_FLAG_OUT_INTERIOR_T)
+    res_buf = torch.empty(B * S * X * Y, dtype=torch.float32, device=dev)
+    res_of = {sl: res_buf[:B * sl * X * Y].view(B, sl, X, Y) for sl in set(slabs)}
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(n_slabs * (args.steps + args.warmup))]
@@ -309,17 +392,18 @@ def main():
     def step(k):
         jc = pipeline.JointCalibration(B, dev, group=group) if args.mode == "joint" else None
         q = None
-        for s in range(n_slabs):
+        for s, sl in enumerate(slabs):
+            res = res_of[sl]
             e0, e1 = ev[k * n_slabs + s]
             e0.record()
-            # the slab's first and last plane are halo planes: every consumer crops them
-            ns.residual_momentum(vars_[s:s + B], boundary=True, absolute=(args.mode == "marginal"), out=res, skip_t_rim=True)
+            ns.residual_momentum(vars_[s:s + B, :, :sl + 2], boundary=True, absolute=(args.mode == "marginal"), out=res,
+                                 skip_t_rim=True)
             e1.record()
-            ev_used.append((k, e0, e1))
+            ev_used.append((k, sl, e0, e1))
             if jc is not None:
-                jc.add_slab(res, crop=(1, 1, 1))
+                jc.add_slab(res, crop=(0, 1, 1))                         # every plane of `res` is an interior plane
             else:
-                q = pipeline.marginal_qhat(res, alphas, group=group)     # [10, T, X, Y]; caller keeps planes 1..T-2
+                q = pipeline.marginal_qhat(res, alphas, group=group)     # [10, sl, X, Y]
         return jc.finish(alphas) if jc is not None else q
 
     def sync():
@@ -341,42 +425,44 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    cells_per_step = B * n_slabs * args.slab * X * Y * world          # whole job, all ranks
+    cells_per_step = B * sum(slabs) * X * Y * world                   # whole job, all ranks
     value = cells_per_step * args.steps / elapsed
 
     if rank == 0:
-        durs = [e0.elapsed_time(e1) for (k, e0, e1) in ev_used if k >= args.warmup]     # ms, this rank
-        kms = sum(durs) / len(durs)
-        # 3 fields x T planes read, (T-2) interior planes written (the two halo planes of the slab are
-        # neither computed nor stored, PRE_FLAG_INTERIOR_T): 12 B/cell in, 4 B/cell out
-        launch_bytes = (12 * T + 4 * (T - 2)) * B * X * Y
+        timed = [(sl, e0.elapsed_time(e1)) for (k, sl, e0, e1) in ev_used if k >= args.warmup]     # ms, this rank
+        kms = sum(d for _, d in timed) / len(timed)
+        # 3 fields read + 1 residual written = 16 B per cell the launch COMPUTES (its interior
+        # planes); the two halo planes each slab re-reads are overhead, reported apart
+        launch_bytes = sum(16 * B * sl * X * Y for sl, _ in timed) / len(timed)
+        halo_bytes = sum((12 * (sl + 2) + 4 * sl) * B * X * Y for sl, _ in timed) / len(timed)
         achieved = launch_bytes / (kms * 1e-3) / 1e9
         pmc = pmc_traffic(args)
         out = {
             "metric": "residual-cells/s (PRE eval+calibrate)",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32",
             "data": SYNTH + "; one resident t-slab, slab position s reads the batch window [s, s+B) of it",
             "config": {"workload": f"C3 2D Navier-Stokes momentum residual [{B},{args.nt},{X},{Y}] x3 fields per rank, "
-                                   f"{args.mode} CP, 10 alpha levels; streamed as {n_slabs} t-slabs of [{B},{T},{X},{Y}]",
-                       "mode": args.mode, "batch_per_rank": B, "parallelism": f"batch-sharded x{world}"},
+                                   f"{args.mode} CP, 10 alpha levels; streamed as {n_slabs} t-slabs of {slabs} interior "
+                                   f"planes (+2 halo planes each)",
+                       "mode": args.mode, "batch_per_rank": B, **par},
             "roofline": {"bound": "hbm", "kernel": "march_kernel<NSMomentum<0>,8,64>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                          "traffic_source": pmc["source"] if pmc else None,
-                         "avg_launch_ms": kms, "algorithmic_bytes_per_launch": launch_bytes},
+                         "avg_launch_ms": kms, "algorithmic_bytes_per_launch": launch_bytes,
+                         "bytes_incl_slab_halo": halo_bytes,
+                         "launches_timed": len(timed)},
             "qhat_first_last": [float(qhat.reshape(len(alphas), -1)[0, 0]), float(qhat.reshape(len(alphas), -1)[-1, 0])],
         }
         if world == 1 and not args.no_cpu_baseline:
-            del vars_, res
+            del vars_, res_buf, res_of
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args, alphas)
+            out["cpu_baseline"] = cpu_baseline(args, alphas, S)
         print(json.dumps(out), flush=True)
-    if group is not None:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+    return done()
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

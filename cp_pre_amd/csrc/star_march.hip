@@ -602,6 +602,9 @@ int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st, const BCInfo
     // 512 threads per workgroup; rows of the tile trade halo re-reads (2/NR) against columns covered
     // 8 rows x 256 columns: measured best of {4,8,16} rows (16 rows = 1024 threads, one workgroup per CU: -5 %)
     // (also measured: 16x128 and 32x64 tiles at 512 threads, -2..-7 % on every functor)
+    // smaller workgroups for the register-heavy MHD functors (to fit 3 instead of 1 per CU) measured in round 2
+    // (profiles/r02/tile_ab_mhd.txt): 4x64 -2..-12 %, 8x32 -1..-14 %, 16x16 0..-7 % at [1024,64,256,256]; only at
+    // T = 10 do 8x32 / 16x16 gain (+6 % induction, +2 % momentum / energy): not worth 45 more instantiations
     if (g.Y >= 192) return launch_tiled<Fn, 8, 64, BC>(g, prm, st, bc);
     if (g.Y >= 96) return launch_tiled<Fn, 16, 32, BC>(g, prm, st, bc);
     return launch_tiled<Fn, 32, 16, BC>(g, prm, st, bc);
@@ -657,6 +660,13 @@ int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const
     g.B = (int)B; g.T = (int)D[p[0]]; g.X = (int)D[p[1]]; g.Y = (int)D[p[2]];
     g.Yc = flat ? g.Y : (g.Y & ~3);
     g.flags = relabeled ? (flags & ~PRE_FLAG_INTERIOR_T) : flags;     // the skipped rim is on the LOGICAL t axis
+    if (flags & PRE_FLAG_OUT_INTERIOR_T) {
+        // `out` holds planes 1..T-2 only: address it as if plane 0 existed one plane stride before its base; the
+        // kernels never touch planes 0 and T-1 under PRE_FLAG_INTERIOR_T
+        if (relabeled || T < 3) return PRE_E_UNSUPPORTED;
+        g.out -= g.oT;
+        g.flags |= PRE_FLAG_INTERIOR_T;
+    }
     if (relabeled)
         for (int k = 0; k < nstars; ++k) {
             const Star o = *stars[k];
@@ -755,6 +765,7 @@ int pre_residual_burgers_f32(const float *u, const int64_t in_strides[3], float 
                              int64_t B, int64_t T, int64_t X, int flags, void *stream)
 {
     if (!u || !in_strides || !out || !out_strides || !K_t || !K_x || !K_xx) return PRE_E_NULL;
+    if (flags & PRE_FLAG_OUT_INTERIOR_T) return PRE_E_UNSUPPORTED;     // [B,T,X]: the marched axis is the batch
     // [B,T,X] -> [1, B, T, X]; 3x3 kernel (a over Nt, b over Nx) -> dense27 index (1, a, b)
     pre_field_t f{u, 0, in_strides[0], in_strides[1], in_strides[2]};
     pre_out_t o{out, 0, out_strides[0], out_strides[1], out_strides[2]};
@@ -851,6 +862,7 @@ int pre_spatial2d_bc_f32(const float *in, const int64_t in_strides[3], float *ou
                          const float *K, const pre_bc_t *bc, int64_t B, int64_t X, int64_t Y, int flags, void *stream)
 {
     if (!in || !out || !in_strides || !out_strides || !K) return PRE_E_NULL;
+    if (flags & PRE_FLAG_OUT_INTERIOR_T) return PRE_E_UNSUPPORTED;
     // planes [B,X,Y] -> [1,B,X,Y]: the plane axis is the tap-free marching axis
     pre_field_t f{in, 0, in_strides[0], in_strides[1], in_strides[2]};
     pre_out_t o{out, 0, out_strides[0], out_strides[1], out_strides[2]};
@@ -873,6 +885,7 @@ int pre_spatial2d_linear2_bc_f32(const float *in0, const int64_t s0[3], const fl
                                  const pre_bc_t *bc, int64_t B, int64_t X, int64_t Y, int flags, void *stream)
 {
     if (!in0 || !in1 || !out || !s0 || !s1 || !out_strides || !K0 || !K1) return PRE_E_NULL;
+    if (flags & PRE_FLAG_OUT_INTERIOR_T) return PRE_E_UNSUPPORTED;
     pre_field_t f0{in0, 0, s0[0], s0[1], s0[2]}, f1{in1, 0, s1[0], s1[1], s1[2]};
     pre_out_t o{out, 0, out_strides[0], out_strides[1], out_strides[2]};
     if (f0.sY != 1 || f1.sY != 1 || o.sY != 1) return PRE_E_UNSUPPORTED;

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) wgrad27_kernel(const float *__restrict__ 
 
 extern "C" {
 
-int pre_abi_version(void) { return 3; }
+int pre_abi_version(void) { return 4; }
 
 int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *tap_w, const int32_t *tap_off, int ntaps,
                       int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)
@@ -247,6 +247,7 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *
     if (!in || !in->ptr || !out || !out->ptr || (ntaps > 0 && (!tap_w || !tap_off))) return PRE_E_NULL;
     if (B <= 0 || T <= 0 || X <= 0 || Y <= 0 || ntaps < 0) return PRE_E_NULL;
     if (ntaps > MAX_TAPS) return PRE_E_SHAPE;
+    if (flags & PRE_FLAG_OUT_INTERIOR_T) return PRE_E_UNSUPPORTED;      // fused residual entries only
     if (B > 0x7fffffff || T > 0x7fffffff || X > 0x7fffffff || Y > 0x7fffffff) return PRE_E_SHAPE;
     hipStream_t st = as_stream(stream);
 

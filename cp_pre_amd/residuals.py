@@ -126,7 +126,10 @@ class NavierStokes(_Residual2D):
         """``out``: optional preallocated device tensor [BS,Nt,Nx,Ny] for the uncropped residual
         (fused route only; lets a streaming driver reuse one buffer).  ``skip_t_rim``: the caller
         crops the first and last time plane anyway, so they need not be computed or stored
-        (``PRE_FLAG_INTERIOR_T``; their content is then unspecified)."""
+        (``PRE_FLAG_INTERIOR_T``; their content is then unspecified).  With ``skip_t_rim`` ``out`` may
+        also be a contiguous [BS,Nt-2,Nx,Ny] tensor: it then receives the interior planes only
+        (``PRE_FLAG_OUT_INTERIOR_T``; what a t-slab driver that feeds slabs with their two halo planes
+        wants) and the result is that tensor, cropped in x and y unless ``boundary``."""
         u, v, p = vars[:, 0], vars[:, 1], vars[:, 2]
         dt, dx, dy, nu = self.dt, self.dx, self.dy, self.nu
         D_t, D_x, D_y, D_xx_yy = self.D_t, self.D_x, self.D_y, self.D_xx_yy
@@ -141,15 +144,25 @@ class NavierStokes(_Residual2D):
                 (du, dv, dp), origin = _stage((u, v, p))
                 if out is None:
                     out = _lib.empty_like_layout(du)
-                elif not (out.is_cuda and out.shape == du.shape and out.dtype == torch.float32):
-                    raise ValueError("out must be an fp32 device tensor of the field shape")
+                interior = (skip_t_rim and out.dim() == 4 and du.shape[1] >= 3 and
+                            tuple(out.shape) == (du.shape[0], du.shape[1] - 2, du.shape[2], du.shape[3]))
+                if not (out.is_cuda and out.dtype == torch.float32 and (out.shape == du.shape or interior)):
+                    raise ValueError("out must be an fp32 device tensor of the field shape "
+                                     "(or, with skip_t_rim, of its interior planes [BS,Nt-2,Nx,Ny])")
+                if interior and not (out.is_contiguous() and origin is None and not _dispatch.needs_grad(u, v, p)):
+                    raise ValueError("an interior-plane out needs device-resident fields, a contiguous out and no autograd")
+                flags = (_lib.PRE_FLAG_ABS if absolute else 0) | (_lib.PRE_FLAG_INTERIOR_T if skip_t_rim else 0) | \
+                        (_lib.PRE_FLAG_OUT_INTERIOR_T if interior else 0)
                 fu, fv, fp, fo = _lib.field(du), _lib.field(dv), _lib.field(dp), _lib.field(out)
                 with torch.cuda.device(du.device):
                     ok = _fused_call("pre_residual_ns_momentum_f32", lambda: _lib.load().pre_residual_ns_momentum_f32(
                         ctypes.byref(fu), ctypes.byref(fv), ctypes.byref(fp), ctypes.byref(fo), *ks,
-                        float(dt), float(dx), float(dy), float(nu), *du.shape,
-                        (_lib.PRE_FLAG_ABS if absolute else 0) | (_lib.PRE_FLAG_INTERIOR_T if skip_t_rim else 0),
-                        _lib.stream()))
+                        float(dt), float(dx), float(dy), float(nu), *du.shape, flags, _lib.stream()))
+                if interior:
+                    if not ok:
+                        raise RuntimeError("pre_residual_ns_momentum_f32: an interior-plane out needs Ny-contiguous views "
+                                           "and star-shaped operator kernels")
+                    return out if boundary else out[..., 1:-1, 1:-1]
             if ok:
                 res = _attach(_dispatch.from_device(out, origin), (u, v, p), composed, absolute)
                 return _finish(res, boundary, _CROP3, absolute, True)

@@ -32,6 +32,12 @@ extern "C" {
 #define PRE_FLAG_INTERIOR_T 2  /* fused residuals / star stencils: planes t=0 and t=T-1 of `out` MAY be left
                                   unwritten - for callers that crop the t rim anyway
                                   (res[...,1:-1,1:-1,1:-1], Marginal/NS_Residuals_CP.py:240) */
+#define PRE_FLAG_OUT_INTERIOR_T 4 /* fused residuals (ns_momentum, linear2, mhd): `out` is a [B,T-2,X,Y] view that holds
+                                  ONLY the interior planes - plane t of the residual (1 <= t <= T-2) is stored at
+                                  out[b, t-1]; the rim planes are neither computed nor stored (implies
+                                  PRE_FLAG_INTERIOR_T).  For streaming drivers that feed t-slabs with their two halo
+                                  planes and keep one residual buffer of the slab's interior.  PRE_E_UNSUPPORTED when
+                                  the views are not Y-contiguous (relabelled layouts) or T < 3. */
 
 /* A strided view of one field [B,T,X,Y] (what `vars[:, i]` or a permuted surrogate
  * output is, Marginal/NS_Residuals_CP.py:282; Other_UQ/Evaluation/PRE_estimations.py:41). */
@@ -51,7 +57,7 @@ typedef struct {
     int64_t sB, sT, sX, sY;
 } pre_out_t;
 
-int pre_abi_version(void);     /* 3 */
+int pre_abi_version(void);     /* 4 */
 
 /* ---- a4/a5/a6: ConvOperator.convolution ---------------------------------------------
  * Utils/ConvOps_2d.py:135-150  F.conv3d(field[:,None], K[None,None], padding=k//2)

@@ -901,6 +901,31 @@ def test_interior_t_fast_path_equals_full_path(gpu):
     assert torch.equal(qa, qb)
     assert torch.equal(a.modulation[0][1:-1], b.modulation[0][1:-1]) and torch.isnan(a.modulation[0][0]).all()
 
+    # PRE_FLAG_OUT_INTERIOR_T: the output buffer holds the interior planes only (bench.py's t-slab driver)
+    guard = torch.full((30 * 8 * 16 * 64 + 2 * 16 * 64,), float("nan"), device=gpu)
+    inner = guard[16 * 64:-16 * 64].view(30, 8, 16, 64)
+    got = ns.residual_momentum(v, boundary=True, out=inner, skip_t_rim=True)
+    assert got.data_ptr() == inner.data_ptr() and torch.equal(got, full[:, 1:-1])
+    assert torch.isnan(guard[:16 * 64]).all() and torch.isnan(guard[-16 * 64:]).all()      # nothing written around it
+    assert torch.equal(ns.residual_momentum(v, out=inner, skip_t_rim=True), full[:, 1:-1, 1:-1, 1:-1])
+    absd = ns.residual_momentum(v, boundary=True, absolute=True, out=inner, skip_t_rim=True)
+    assert torch.equal(absd, full[:, 1:-1].abs())
+    c = pipeline.JointCalibration(30, gpu)
+    c.add_slab(ns.residual_momentum(v, boundary=True, out=inner, skip_t_rim=True), crop=(0, 1, 1))
+    assert torch.equal(c.finish(alphas), qb) and torch.equal(c.modulation[0], b.modulation[0][1:-1])
+    # a strided sub-slab of a bigger resident slab (ragged last slab position) and a batch window
+    big = (torch.rand(33, 3, 12, 16, 64, generator=g) + 0.5).to(gpu)
+    sub = big[2:32, :, :7]
+    ref = ns.residual_momentum(sub.contiguous(), boundary=True)
+    out5 = torch.empty(30, 5, 16, 64, device=gpu)
+    assert torch.equal(ns.residual_momentum(sub, boundary=True, out=out5, skip_t_rim=True), ref[:, 1:-1])
+    # not applicable: Nt-fastest views (the skipped rim is on the logical t axis), wrong shapes
+    perm = v.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+    with pytest.raises((RuntimeError, ValueError)):
+        ns.residual_momentum(perm, boundary=True, out=torch.empty(30, 8, 16, 64, device=gpu), skip_t_rim=True)
+    with pytest.raises(ValueError):
+        ns.residual_momentum(v, boundary=True, out=torch.empty(30, 7, 16, 64, device=gpu), skip_t_rim=True)
+
 
 def test_index_arithmetic_beyond_2_31_elements(gpu):
     """Tensors with more than 2^31 elements (BASELINE C3 slabs have 1e10): the last samples of a big
