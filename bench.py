@@ -202,6 +202,7 @@ def run_secondary(args, cfg, dev, group, rank, world, par):
         elapsed = float(tt.item())
     if rank == 0:
         kms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        pmc = pmc_traffic(args)
         launch_bytes = cfg["bpc"] * cells
         achieved = launch_bytes / (kms * 1e-3) / 1e9
         shape = [B, T, X] + ([Y] if Y else [])
@@ -212,24 +213,28 @@ def run_secondary(args, cfg, dev, group, rank, world, par):
             "dtype": "f32", "data": SYNTH + "; whole per-rank tensor resident",
             "config": {"workload": f"{cfg['title']} {shape} per rank, {args.mode} CP, 10 alpha levels", "mode": args.mode, **par},
             "roofline": {"bound": "hbm", "kernel": cfg["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": kms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                         "traffic_source": pmc["source"] if pmc else None, "avg_launch_ms": kms,
                          "algorithmic_bytes_per_launch": launch_bytes}}), flush=True)
 
 
 def pmc_traffic(args):
     """HBM bytes per launch of the fused residual kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN/pmc_hbm_c3.json, written by tools/distill_profiles.py).  Counters cannot be
+    (profiles/rNN/pmc_hbm_<config>.json, written by tools/distill_profiles.py).  Counters cannot be
     read from inside this process; the file is used only when it was collected on this exact
-    workload, otherwise `traffic` stays null."""
+    workload (latest round wins), otherwise `traffic` stays null."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_c3.json"))):
+    want = {"batch": args.batch, "nt": args.nt, "nx": args.nx, "ny": args.ny}
+    if args.config == "c3":
+        want["slab"] = args.slab
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_hbm_{args.config}.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         w = d.get("workload", {})
-        if (w.get("batch"), w.get("slab"), w.get("nx"), w.get("ny")) == (args.batch, args.slab, args.nx, args.ny):
+        if all(w.get(k) == v for k, v in want.items()):
             best = d
     return best
 

@@ -109,6 +109,7 @@ class _XCorrFn(torch.autograd.Function):
         gf = gk = None
         if ctx.needs_input_grad[0]:
             gf = _xcorr_impl(gout.contiguous(), torch.flip(kernel.detach(), dims=tuple(range(nd))), nd, 0)
+            gf = gf.reshape(field.shape)                    # a [BS,1,Nt,Nx] field has its channel squeezed in the output
         if ctx.needs_input_grad[1]:
             g = gout.to(field.device) if gout.device != field.device else gout
             x = field[:, 0] if field.dim() == nd + 2 else field

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) std_from_moments_kernel(const double *__r
     if (c >= M) return;
     const double mean = sum[c] / n_total;
     double var = sumsq[c] / n_total - mean * mean;
-    var = var > 0.0 ? var : 0.0;
+    var = var < 0.0 ? 0.0 : var;              // round-off below zero -> 0; NaN stays NaN (np.std propagates it)
     mod[c] = (float)sqrt(var) + eps;
 }
 
@@ -114,11 +114,15 @@ __device__ __forceinline__ float wave_max(float v)
 // that can raise the maximum pay for the exact divide, and the result is bit-identical to
 // dividing everything.
 constexpr int JS_RB = 32;
-__device__ __forceinline__ void js_update(float av, float sv, float &m, float &thr)
+// NaN: np.max propagates it.  A NaN residual or modulation fails `av <= thr*sv` and reaches the divide; 0/0 (a
+// constant cell: modulation 0 and residual 0) reaches it through `sv == 0`; a NaN quotient sets the sticky flag and
+// the sample's score becomes NaN.
+__device__ __forceinline__ void js_update(float av, float sv, float &m, float &thr, bool &nan)
 {
-    if (av > thr * sv || sv == 0.f) {
+    if (!(av <= thr * sv) || sv == 0.f) {
         const float q = av / sv;
-        if (q > m) { m = q; thr = m * 0.99999905f; }
+        if (q != q) nan = true;
+        else if (q > m) { m = q; thr = m * 0.99999905f; }
     }
 }
 
@@ -134,7 +138,7 @@ __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restric
     __shared__ unsigned int rowmask;
     __shared__ float red[4];
     float m = 0.f, thr = 0.f;
-    bool any = false;
+    bool any = false, nan = false;
     // `groups` spans of JS_RB rows per block (short rows - e.g. the surrogate's Nt = 10 cells - would otherwise
     // leave a block with a few hundred cells and one atomic each)
     for (int gi = 0; gi < groups; ++gi) {
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restric
                 const int y = 4 * y4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (y + k >= cy && y + k < Y - cy) js_update(av[k], sv[k], m, thr);
+                    if (y + k >= cy && y + k < Y - cy) js_update(av[k], sv[k], m, thr, nan);
             }
             y4 += dy;
             row += dr;
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restric
                 const long long o = (r0 + row) * Y + y;
                 float v = pa[o];
                 if (pb) v -= pb[o];
-                js_update(fabsf(v), mod[o], m, thr);
+                js_update(fabsf(v), mod[o], m, thr, nan);
             }
             y += dy;
             row += dr;
@@ -193,12 +197,15 @@ __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restric
     }
     }   // spans
     m = wave_max(m);
+    if (__ballot(nan)) m = __uint_as_float(0x7fc00000u);         // canonical quiet NaN
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0 && any) {
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        // non-negative floats order like their bit patterns
-        atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, __float_as_uint(m));
+        // non-negative floats order like their bit patterns, and the NaN pattern lies above +inf: the unsigned
+        // maximum is the float maximum with NaN sticky (across blocks and across per-slab calls)
+        const unsigned int u = max(max(__float_as_uint(red[0]), __float_as_uint(red[1])),
+                                   max(__float_as_uint(red[2]), __float_as_uint(red[3])));
+        atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, u);
     }
 }
 
@@ -211,14 +218,18 @@ __global__ void __launch_bounds__(1024) kth_kernel(const float *__restrict__ s, 
     __shared__ unsigned int hist[256];
     __shared__ unsigned int sh_prefix;
     __shared__ long long sh_rank;
+    __shared__ int sh_nan;
     const int j = blockIdx.x;
     unsigned int prefix = 0, mask = 0;
     long long rank = kl.k[j];
+    if (threadIdx.x == 0) sh_nan = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
         for (long long i = threadIdx.x; i < N; i += blockDim.x) {
-            const unsigned int key = f2key(s[i]);
+            const float v = s[i];
+            if (shift == 24 && v != v) sh_nan = 1;          // np.quantile: any NaN score makes every quantile NaN
+            const unsigned int key = f2key(v);
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -238,7 +249,7 @@ __global__ void __launch_bounds__(1024) kth_kernel(const float *__restrict__ s, 
         mask |= 255u << shift;
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[j] = key2f(prefix);
+    if (threadIdx.x == 0) out[j] = sh_nan ? __uint_as_float(0x7fc00000u) : key2f(prefix);
 }
 
 // ------------------------------------------------------------------ per-cell k-th over axis 0

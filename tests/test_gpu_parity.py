@@ -391,6 +391,57 @@ def test_joint_recipe_vs_numpy(gpu):
     assert np.array_equal(s_crop, oc.ncf_metric_joint(inner, np.zeros_like(inner), oc.modulation_func(inner, np.zeros_like(inner))))
 
 
+def test_joint_score_propagates_nan_like_numpy(gpu):
+    """np.max(np.abs(a-b)/mod) propagates NaN: a NaN residual cell, a NaN modulation, and 0/0 (a constant cell:
+    modulation 0 with residual 0) make that sample's score NaN - also through the streaming driver - and a NaN
+    score makes the scalar q-hat NaN (np.quantile); inf/0 stays inf.  Samples without such cells are unaffected."""
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    from oracle import conformal as oc
+    rng = np.random.default_rng(3)
+    n = 40
+    res = rng.standard_normal((n, 6, 10, 16)).astype(np.float32)
+    res[:, 2, 3, 4] = 0.0                                   # constant cell -> modulation 0 -> 0/0 in every sample
+    mod = oc.modulation_func(res, np.zeros_like(res))
+    assert mod[2, 3, 4] == 0.0
+    with np.errstate(all="ignore"):
+        ref = oc.ncf_metric_joint(res, np.zeros_like(res), mod)
+    assert np.isnan(ref).all()
+    got = icp.ncf_metric_joint(res, None, icp.modulation_func(res, None))
+    assert np.isnan(got).all()
+    # NaN in ONE sample only; zero modulation under a non-zero residual gives inf, not NaN
+    res2 = rng.standard_normal((n, 6, 10, 16)).astype(np.float32)
+    res2[7, 1, 5, 9] = np.nan
+    mod2 = np.abs(rng.standard_normal((6, 10, 16))).astype(np.float32) + 0.1
+    mod2[4, 4, 4] = 0.0
+    with np.errstate(all="ignore"):
+        ref2 = oc.ncf_metric_joint(res2, np.zeros_like(res2), mod2)
+    got2 = icp.ncf_metric_joint(res2, None, mod2)
+    assert np.isnan(ref2[7]) and np.isinf(np.delete(ref2, 7)).all()
+    assert np.array_equal(got2, ref2, equal_nan=True)
+    mod2[4, 4, 4] = 0.5
+    mod2[0, 0, 0] = np.nan                                  # NaN modulation at a cell the crop removes / keeps
+    with np.errstate(all="ignore"):
+        ref3 = oc.ncf_metric_joint(res2[:, 1:-1, 1:-1, 1:-1], np.zeros_like(res2[:, 1:-1, 1:-1, 1:-1]), mod2[1:-1, 1:-1, 1:-1])
+        ref4 = oc.ncf_metric_joint(res2, np.zeros_like(res2), mod2)
+    got3 = icp.ncf_metric_joint(torch.from_numpy(res2).to(gpu), None, torch.from_numpy(mod2).to(gpu), crop=1).cpu().numpy()
+    assert np.array_equal(got3, ref3, equal_nan=True) and np.isnan(ref3).sum() == 1
+    assert np.array_equal(icp.ncf_metric_joint(res2, None, mod2), ref4, equal_nan=True) and np.isnan(ref4).all()
+    # the streaming driver: a NaN residual makes that cell's modulation NaN (np.std), hence EVERY sample's score,
+    # and the NaN survives the later slabs' max-accumulation and calibrate
+    jc = pipeline.JointCalibration(n, gpu)
+    r = torch.from_numpy(res2).to(gpu)
+    for t0 in (0, 2, 4):
+        jc.add_slab(r[:, t0:t0 + 2].contiguous(), crop=(0, 1, 1))
+    q = jc.finish([0.1, 0.5])
+    with np.errstate(all="ignore"):
+        inner = res2[:, :, 1:-1, 1:-1]
+        ref5 = oc.ncf_metric_joint(inner, np.zeros_like(inner), oc.modulation_func(inner, np.zeros_like(inner)))
+    assert np.isnan(ref5).all() and torch.isnan(jc.all_scores).all() and torch.isnan(q).all()
+    with np.errstate(all="ignore"):
+        assert np.isnan(icp.calibrate(ref2, n, 0.1)) and np.isnan(np.quantile(ref2, 0.5, method="higher"))
+
+
 def test_scalar_kth_large_and_absdiff(gpu):
     from cp_pre_amd import _lib, inductive_cp as icp
     rng = np.random.default_rng(9)
@@ -547,6 +598,18 @@ def test_autograd_matches_torch_conv(gpu):
         (out * w.to(gpu)).sum().backward()
         assert rel_err(xd.grad.cpu().numpy(), x_ref.grad.numpy()) <= RES_TOL
         assert rel_err(D.kernel.grad.cpu().numpy(), k_ref.grad.numpy()) <= 1e-4      # k^nd long fp32 sums
+    # 1-D operator on a [BS,1,Nt,Nx] field (Utils/ConvOps_1d.py:130-150 accepts both): the gradient keeps the channel
+    import torch.nn.functional as F
+    x4 = torch.randn(3, 1, 6, 8, generator=g)
+    w3 = torch.randn(3, 6, 8, generator=g)
+    D1 = C1("x", 2)
+    k_ref, x_ref = D1.kernel.clone().requires_grad_(True), x4.clone().requires_grad_(True)
+    (F.conv2d(x_ref, k_ref[None, None], padding=1).squeeze(1) * w3).sum().backward()
+    D1.kernel = D1.kernel.to(gpu).requires_grad_(True)
+    x4d = x4.to(gpu).requires_grad_(True)
+    (D1(x4d) * w3.to(gpu)).sum().backward()
+    assert x4d.grad.shape == x4.shape and rel_err(x4d.grad.cpu().numpy(), x_ref.grad.numpy()) <= RES_TOL
+    assert rel_err(D1.kernel.grad.cpu().numpy(), k_ref.grad.numpy()) <= 1e-4
     # a residual used as a physics loss: fused route steps aside, gradients flow through the composition
     v = (torch.rand(2, 3, 5, 6, 16, generator=g) + 0.5)
     v_ref = v.clone().requires_grad_(True)

@@ -61,28 +61,59 @@ def counters(src):
 
 
 OURS = ("march_kernel", "moments_kernel", "joint_score_kernel", "std_from_moments_kernel", "kth_")
-pm = {**counters("fetch"), **counters("write")}
-if ("FETCH_SIZE", MK) in pm and ("WRITE_SIZE", MK) in pm:
-    B = 4096
-    cells = B * 10 * 512 * 512
-    with open(f"{out}/pmc_hbm_c3.txt", "w") as o:
+sys.path.insert(0, os.getcwd())
+import bench                                             # split_slabs / CONFIGS: the workloads the passes ran
+
+SRC_NOTE = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 gfx950 correction"
+
+
+def hbm_report(tag, fetch_src, write_src, kernel, cmd, workload, alg_bytes, halo_bytes=None, note=""):
+    pm = {**counters(fetch_src), **counters(write_src)}
+    if ("FETCH_SIZE", kernel) not in pm or ("WRITE_SIZE", kernel) not in pm:
+        return
+    with open(f"{out}/pmc_hbm_{tag}.txt", "w") as o:
         o.write("rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate passes)\n"
-                "   -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline   (C3, joint, batch 4096; MI355X)\n")
+                f"   -- python3 bench.py {cmd}   (MI355X)\n")
         o.write("counter unit KiB.  gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of a 16 B/lane\n"
                 "coalesced streaming read -> x2; WRITE_SIZE is exact for 16 B/lane streaming stores.\n\n")
         for (name, k), (n, avg) in sorted(pm.items(), key=lambda x: (x[0][1], x[0][0])):
             if k.startswith(OURS):
                 gb = avg * 1024 / 1e9 * (2 if name == "FETCH_SIZE" else 1)
                 o.write(f"{name:11s} {k:40s} dispatches={n:3d} avg_KiB={avg:.6g} corrected_GB_per_dispatch={gb:.3f}\n")
-        f = pm[("FETCH_SIZE", MK)][1] * 1024 * 2
-        w = pm[("WRITE_SIZE", MK)][1] * 1024
-        alg_r, alg_w = 12 * cells, 4 * cells * 8 // 10      # 10 planes read, 8 interior planes written
-        o.write(f"\n{MK} per launch [4096,10,512,512]: algorithmic read {alg_r/1e9:.3f} GB + write {alg_w/1e9:.3f} GB = {(alg_r+alg_w)/1e9:.3f} GB\n")
-        o.write(f"   measured HBM traffic  read {f/1e9:.3f} GB + write {w/1e9:.3f} GB = {(f+w)/1e9:.3f} GB  ({(f+w)/(alg_r+alg_w):.4f} x algorithmic)\n")
-    json.dump({"workload": {"batch": 4096, "slab": 8, "nx": 512, "ny": 512}, "kernel": MK,
-               "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "traffic_bytes_per_launch": f + w,
-               "source": f"{out}/pmc_hbm_c3.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 gfx950 correction)"},
-              open(f"{out}/pmc_hbm_c3.json", "w"), indent=1)
+        f = pm[("FETCH_SIZE", kernel)][1] * 1024 * 2
+        w = pm[("WRITE_SIZE", kernel)][1] * 1024
+        o.write(f"\n{kernel} per launch (average over the profiled launches){note}:\n")
+        o.write(f"   algorithmic bytes (SURVEY 8d: 4*(F+1) B x cells computed)       {alg_bytes/1e9:.3f} GB\n")
+        if halo_bytes:
+            o.write(f"   + the two halo planes each t-slab re-reads (overhead)            {halo_bytes/1e9:.3f} GB\n")
+        o.write(f"   measured HBM traffic  read {f/1e9:.3f} GB + write {w/1e9:.3f} GB = {(f+w)/1e9:.3f} GB  = {(f+w)/alg_bytes:.4f} x algorithmic")
+        if halo_bytes:
+            o.write(f", {(f+w)/halo_bytes:.4f} x (algorithmic + slab halo)")
+        o.write("\n")
+    json.dump({"workload": workload, "kernel": kernel, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w,
+               "traffic_bytes_per_launch": f + w, "algorithmic_bytes_per_launch": alg_bytes,
+               "source": f"{out}/pmc_hbm_{tag}.txt ({SRC_NOTE})"}, open(f"{out}/pmc_hbm_{tag}.json", "w"), indent=1)
+
+
+c3 = bench.CONFIGS["c3"]["shape"]
+slab = 13
+slabs = bench.split_slabs(c3[1], slab)
+cells_xy = c3[0] * c3[2] * c3[3]
+hbm_report("c3", "fetch", "write", MK, "--steps 1 --warmup 0 --no-cpu-baseline",
+           {"batch": c3[0], "nt": c3[1], "nx": c3[2], "ny": c3[3], "slab": slab},
+           sum(16 * sl * cells_xy for sl in slabs) / len(slabs),
+           sum((12 * (sl + 2) + 4 * sl) * cells_xy for sl in slabs) / len(slabs),
+           note=f" [4096,S+2,512,512] x3 -> [4096,S,512,512], S in {slabs}")
+for c in ("c2", "c4", "c5"):
+    cfg = bench.CONFIGS[c]
+    shp = cfg["shape"]
+    cells = 1
+    for d in shp:
+        cells *= d
+    kern = cfg["kernel"]
+    hbm_report(c, f"fetch_{c}", f"write_{c}", kern, f"--config {c} --steps 1 --warmup 0 --no-cpu-baseline",
+               {"batch": shp[0], "nt": shp[1], "nx": shp[2], "ny": shp[3] if len(shp) == 4 else 0}, cfg["bpc"] * cells,
+               note=f" {list(shp)}")
 
 for tag, srcs, mode in (("pmc_sq_c3.txt", ("sq1", "sq2"), "joint"), ("pmc_sq_c3_marginal.txt", ("sq1m", "sq2m", "fetchm"), "marginal")):
     sq = {}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
 #   gpurun --timeout 1100 -- 'bash tools/profile_round.sh'
-# then   python tools/distill_profiles.py r01   turns gpurun_out/prof/* into profiles/r01/*.
+# then   python tools/distill_profiles.py r02   turns gpurun_out/prof/* into profiles/r01/*.
 # Trace and counter passes are separate runs (PMC is never combined with other trace domains).
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -27,5 +27,7 @@ run sq2m     --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BA
 run fetchm   --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetchm" -- $B --steps 1 --warmup 0 --batch 1024 --mode marginal
 for c in c2 c4 c5; do
     run trace_$c --kernel-trace --stats --output-format csv -d "$P/trace_$c" -- $B --config $c --steps 3 --warmup 1
+    run fetch_$c --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch_$c" -- $B --config $c --steps 1 --warmup 0
+    run write_$c --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write_$c" -- $B --config $c --steps 1 --warmup 0
 done
 echo done >&2
