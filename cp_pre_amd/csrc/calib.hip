@@ -1,5 +1,5 @@
-// calib.hip - nonconformity scores, modulation, joint score, radix-select quantiles and
-// coverage for gfx950.  All kernels are HBM-bound streaming passes (4 B per element per
+// calib.hip - nonconformity scores, modulation, joint score, the scalar radix-select quantile and
+// coverage for gfx950 (the per-cell select over the batch axis lives in kth_axis0.hip).  All kernels are HBM-bound streaming passes (4 B per element per
 // pass); there is no contraction here and nothing is reshaped into one.
 //
 // Layout convention: a calibration tensor is contiguous [n, M] - n samples (batch axis,
@@ -252,262 +252,6 @@ __global__ void __launch_bounds__(1024) kth_kernel(const float *__restrict__ s, 
     if (threadIdx.x == 0) out[j] = sh_nan ? __uint_as_float(0x7fc00000u) : key2f(prefix);
 }
 
-// ------------------------------------------------------------------ per-cell k-th over axis 0
-// MSD radix select over [n, M] for ALL requested ranks at once, ONE launch: histogram sweeps of 8 + 6 + 6 + 6 + 6
-// bits until every (cell, rank) of the tile has <= KA_CAP elements left under its prefix, then one collecting
-// sweep and a rank count over the survivors (ka_collect) - 3 sweeps on typical data up to n ~ 2000, 4 at
-// n = 4096, all 5 histogram sweeps only under heavy ties.  A 1024-thread workgroup owns 64 adjacent cells
-// (256 B of every sample row - narrower column tiles lose DRAM efficiency fast: 128 B -> 0.7x, 64 B -> 0.3x,
-// tools/exp/colread.hip): lane = cell everywhere.
-//   sweep:  one wave = one row, so the 64 LDS atomics of a wave-instruction never hit the same
-//           counter.  Counters are 16 bit (n < 65536), cells c and c+32 share a word; histogram row r
-//           (= slot*bins + bin) is 32 words.  Per cell there is one histogram per *distinct* prefix among
-//           its ranks ("slot"; ranks ascend, so equal prefixes are adjacent); the first sweep has one slot.
-//   narrow: thread (cell c = tid & 63, rank j = tid >> 6) owns the state (prefix, residual rank) of
-//           its pair in registers and walks the bins of its slot serially - 640 independent walks,
-//           no cross-lane traffic (the first sweep's 256 bins are pre-summed in 16 groups by all
-//           1024 threads).  New prefixes reach the sweeping waves through the idle histogram memory.
-// 80 KiB of LDS: two workgroups per CU (tools/exp/ldsocc.hip), one sweeps while the other narrows.
-// The kernel is VALU-bound (a wave64 instruction holds its SIMD16 for 4 cycles), so the work per
-// element is what is optimised: 3-instruction key, 3-instruction counter address, match loops sized to the
-// slots actually in use.  For small n the tile (n * 256 B) stays L2-resident between sweeps.
-constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16;
-constexpr int KA_HIST_WORDS = KA_MAXK * 64 * 32;          // 80 KiB; the first sweep uses 256*32 of them
-constexpr int KA_GROUPS_AT = 256 * 32;                    // 16 x 64 group sums of the first sweep live here
-constexpr int KA_FLAGS_AT = 1008, KA_CAP = 31;            // per-wave "many survivors" flags (640..1023 is never used otherwise)
-struct KAList { int nk; int k[KA_MAXK]; };
-
-// counter of (histogram row, cell): cells c and c+32 share a word (16-bit halves), so the 32 lanes the LDS serves
-// per cycle always hit 32 different banks whatever rows they address - no rotation needed, 3 address ops
-__device__ __forceinline__ int ka_word(int row, int lane31) { return row * 32 + lane31; }
-
-// My cell's DISTINCT prefixes (published in hist[j*64 + cell] by the previous narrowing), compacted to the
-// front: slot i = i-th distinct prefix (ranks ascend, so equal prefixes are adjacent); unused entries hold the
-// sentinel 1 (low bit set: never equals a masked key).  lmax = most slots any cell of the tile has (wave-uniform
-// loop bound for the match); myslot = slot of this thread's own rank.  Ends with a barrier: hist is free again.
-__device__ __forceinline__ void ka_prefixes(unsigned int *hist, int nk, int lane, int wave, unsigned int (&pf)[KA_MAXK],
-                                            int &lmax, int &myslot)
-{
-    unsigned int *scr = hist + 1024 + wave * (KA_MAXK * 64);
-    unsigned int prev = 0;
-    int L = 0;
-#pragma unroll
-    for (int j = 0; j < KA_MAXK; ++j) {
-        const unsigned int p = j < nk ? hist[j * 64 + lane] : 0u;
-        if (j < nk && (j == 0 || p != prev)) { scr[L * 64 + lane] = p; ++L; }
-        if (j == wave) myslot = L - 1;
-        prev = p;
-    }
-#pragma unroll
-    for (int j = 0; j < KA_MAXK; ++j) pf[j] = j < L ? scr[j * 64 + lane] : 1u;
-    int m = L;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-    lmax = __builtin_amdgcn_readfirstlane(m);
-    __syncthreads();
-}
-
-template <int N> struct ka_ic { static constexpr int value = N; };
-
-// slot (1-based) whose prefix equals hi, 0 if none; LM = static bound on the number of slots in use
-template <int LM>
-__device__ __forceinline__ int ka_match(unsigned int hi, const unsigned int (&pf)[KA_MAXK])
-{
-    int m = 0;
-#pragma unroll
-    for (int j = 0; j < LM; ++j) m = (hi == pf[j]) ? j + 1 : m;
-    return m;
-}
-
-// rows wave, wave+16, ... of my cell, eight loads in flight
-template <class F>
-__device__ __forceinline__ void ka_sweep(const float *__restrict__ col, bool cok, int n, long long M, int wave, F &&f)
-{
-    if (!cok) return;
-    int i = wave;
-    for (; i + 7 * KA_WAVES < n; i += 8 * KA_WAVES) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = col[(long long)(i + u * KA_WAVES) * M];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) f(v[u]);
-    }
-    for (; i < n; i += KA_WAVES) f(col[(long long)i * M]);
-}
-
-// the match against the cell's prefixes costs 2 VALU instructions per slot and element: instantiate the sweep for
-// a few static slot counts and branch (wave-uniformly) on the tile's actual maximum
-template <class G>
-__device__ __forceinline__ void ka_by_slots(int lmax, G &&g)
-{
-    if (lmax <= 2) g(ka_ic<2>{});
-    else if (lmax <= 4) g(ka_ic<4>{});
-    else if (lmax <= 7) g(ka_ic<7>{});
-    else g(ka_ic<KA_MAXK>{});
-}
-
-// Returns (block-uniform) whether some (cell, rank) of the tile still has more than KA_CAP elements under its
-// prefix after this sweep.
-template <int BITS, int SLOTS>
-__device__ __forceinline__ bool ka_pass(const float *__restrict__ col, bool cok, int n, long long M, int nk, int shift,
-                                        unsigned int *hist, unsigned int &myp, unsigned int &myr, int lane, int wave, int tid)
-{
-    constexpr int NB = 1 << BITS;
-    const unsigned int mask = (shift + BITS == 32) ? 0u : ~0u << (shift + BITS);
-    const bool state = wave < nk;                 // this thread owns (cell = lane, rank = wave)
-
-    // my cell's DISTINCT prefixes, compacted to the front (slot i = i-th distinct prefix); the
-    // sentinel 1 (low bit set) never equals a masked key.  lmax = most slots any cell has: the
-    // match loop runs to that wave-uniform bound instead of KA_MAXK.  myslot = slot of my own rank.
-    unsigned int pf[KA_MAXK];
-    int lmax = 1, myslot = 0;
-    if (SLOTS > 1) ka_prefixes(hist, nk, lane, wave, pf, lmax, myslot);
-    for (int i = tid; i < SLOTS * NB * 32; i += 1024) hist[i] = 0u;
-    __syncthreads();
-
-    const unsigned int inc = 1u << (16 * (lane >> 5));
-    const int half = lane & 31, sh16 = 16 * (lane >> 5);
-    if (SLOTS == 1) {
-        ka_sweep(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
-            atomicAdd(&hist[ka_word((int)((f2key(v) >> shift) & (NB - 1)), half)], inc);
-        });
-    } else {
-        ka_by_slots(lmax, [&](auto lm) __attribute__((always_inline)) {
-            ka_sweep(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
-                const unsigned int key = f2key(v);
-                const int m = ka_match<decltype(lm)::value>(key & mask, pf);
-                if (m) atomicAdd(&hist[ka_word((m - 1) * NB + (int)((key >> shift) & (NB - 1)), half)], inc);
-            });
-        });
-    }
-    __syncthreads();
-
-    // narrow: walk the bins of my slot for my cell until the running count passes my rank
-    auto cnt = [&](int row) __attribute__((always_inline)) { return (hist[ka_word(row, half)] >> sh16) & 0xffffu; };
-    int bin0 = 0, bin1 = NB;
-    unsigned int cum = 0;
-    bool many = false;                     // more than KA_CAP elements share my (now longer) prefix
-    if (SLOTS == 1) {
-        // first sweep (one slot, NB bins): 16 groups of NB/16 bins are summed by all 1024 threads first
-        constexpr int GB = NB / KA_WAVES;
-        unsigned int gs = 0;
-#pragma unroll 8
-        for (int u = 0; u < GB; ++u) gs += cnt(wave * GB + u);
-        hist[KA_GROUPS_AT + wave * 64 + lane] = gs;
-        __syncthreads();
-        if (state) {
-            // group of my rank = number of groups whose inclusive running count is <= myr (branch-free: the 16
-            // LDS reads are independent and pipeline; a `break` loop serialised them behind their latency)
-            unsigned int run = 0;
-            int g = 0;
-#pragma unroll
-            for (int u = 0; u < KA_WAVES; ++u) {
-                run += hist[KA_GROUPS_AT + u * 64 + lane];
-                const bool le = run <= myr;
-                g += le;
-                cum = le ? run : cum;
-            }
-            g = min(g, KA_WAVES - 1);
-            bin0 = g * GB;
-            bin1 = bin0 + GB;
-        }
-    }
-    if (state) {
-        // digit = number of bins (from bin0) whose inclusive running count is <= myr; `cum` ends as the count
-        // before the chosen bin.  Branch-free for the same reason as above.
-        const int base = (SLOTS == 1 ? 0 : myslot) * NB;
-        unsigned int run = cum;
-        int d = 0;
-#pragma unroll 8
-        for (int bin = bin0; bin < bin1; ++bin) {
-            run += cnt(base + bin);
-            const bool le = run <= myr;
-            d += le;
-            cum = le ? run : cum;
-        }
-        const int digit = bin0 + min(d, bin1 - bin0 - 1);
-        many = cnt(base + digit) > (unsigned)KA_CAP;
-        myp |= (unsigned)digit << shift;
-        myr -= cum;
-    }
-    const bool wmany = __ballot(many) != 0;
-    __syncthreads();                       // everyone is done reading the histograms
-    if (shift > 0 && state) hist[wave * 64 + lane] = myp;     // publish for the next sweep's matching
-    if (lane == 0) hist[KA_FLAGS_AT + wave] = wmany;
-    __syncthreads();
-    return __ballot(hist[KA_FLAGS_AT + (lane & (KA_WAVES - 1))] != 0u) != 0;
-}
-
-// Finish without further histogram sweeps once every (cell, rank) of the tile has at most KA_CAP elements left
-// under its prefix: ONE more sweep appends each surviving key to the list of its slot - the idle histogram
-// memory, list[slot][i][cell] with the fill counter in row KA_CAP - and the owner thread picks its rank from
-// the <= KA_CAP candidates by counting (k-th smallest = the smallest key with more than k keys <= it).
-// Typical data needs 9 + 6 known bits for that (two histogram sweeps + this one instead of five); heavy
-// ties never get there and take all five histogram sweeps.
-__device__ __forceinline__ int ka_list(int slot, int i, int cell) { return (slot * 32 + i) * 64 + cell; }
-
-__device__ __forceinline__ void ka_collect(const float *__restrict__ col, bool cok, int n, long long M, int nk, int known,
-                                           unsigned int *hist, unsigned int &myp, unsigned int myr, int lane, int wave, int tid)
-{
-    const unsigned int mask = ~0u << known;
-    unsigned int pf[KA_MAXK];
-    int lmax = 1, myslot = 0;
-    ka_prefixes(hist, nk, lane, wave, pf, lmax, myslot);
-    for (int i = tid; i < KA_HIST_WORDS; i += 1024) hist[i] = ((i >> 6) & 31) == KA_CAP ? 0u : 0xffffffffu;   // counters / sentinels
-    __syncthreads();
-
-    ka_by_slots(lmax, [&](auto lm) __attribute__((always_inline)) {
-        ka_sweep(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
-            const unsigned int key = f2key(v);
-            const int m = ka_match<decltype(lm)::value>(key & mask, pf);
-            if (m) {
-                const unsigned int pos = atomicAdd(&hist[ka_list(m - 1, KA_CAP, lane)], 1u);
-                hist[ka_list(m - 1, (int)pos, lane)] = key;      // pos < KA_CAP: the histogram counted these elements
-            }
-        });
-    });
-    __syncthreads();
-
-    if (wave < nk) {
-        const int c = (int)hist[ka_list(myslot, KA_CAP, lane)];
-        int cmax = c;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
-        cmax = __builtin_amdgcn_readfirstlane(cmax);
-        unsigned int ans = 0xffffffffu;
-        for (int i = 0; i < cmax; ++i) {
-            const unsigned int ki = hist[ka_list(myslot, i, lane)];          // sentinel beyond my own count
-            unsigned int le = 0;
-            for (int j = 0; j < cmax; ++j) le += hist[ka_list(myslot, j, lane)] <= ki;
-            if (i < c && le > myr) ans = min(ans, ki);
-        }
-        myp = ans;
-    }
-}
-
-__global__ void __launch_bounds__(1024, 8) kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile0,
-                                                            const KAList kl, float *__restrict__ out)
-{
-    __shared__ unsigned int hist[KA_HIST_WORDS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nk = kl.nk;
-    const long long c0 = (tile0 + blockIdx.x) * KA_W, c = c0 + lane;
-    const bool cok = c < M;
-    const float *col = s + c;
-    const bool state = wave < nk;
-    unsigned int myp = 0u, myr = state ? (unsigned)kl.k[wave] : 0u;
-    // 8 + 6 + 6 + 6 + 6 bits; stop counting as soon as the survivors fit the lists
-    int known = 24;                        // lowest known bit so far
-    bool many = ka_pass<8, 1>(col, cok, n, M, nk, 24, hist, myp, myr, lane, wave, tid);
-#pragma unroll 1
-    for (int shift = 18; many && shift >= 0; shift -= 6) {
-        many = ka_pass<6, KA_MAXK>(col, cok, n, M, nk, shift, hist, myp, myr, lane, wave, tid);
-        known = shift;
-    }
-    if (known > 0) ka_collect(col, cok, n, M, nk, known, hist, myp, myr, lane, wave, tid);   // else all 32 bits are counted
-    if (state && cok) out[(long long)wave * M + c] = key2f(myp);
-}
-
 // ------------------------------------------------------------------ coverage
 __global__ void __launch_bounds__(256) cov_count_kernel(const float *__restrict__ y, const float *__restrict__ lo,
                                                         const float *__restrict__ hi, long long total, long long M,
@@ -655,30 +399,6 @@ int pre_kth_f32(const float *scores, int64_t N, const int64_t *ks, int nk, float
         for (int j = 0; j < kl.nk; ++j) kl.k[j] = ks[j0 + j];
         hipLaunchKernelGGL(kth_kernel, dim3(kl.nk), dim3(1024), 0, as_stream(stream), scores, (long long)N, kl, out + j0);
         PRE_LAUNCH_CHECK();
-    }
-    return PRE_OK;
-}
-
-int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks, int nk, float *out, void *stream)
-{
-    if (!scores || !ks || !out || n <= 0 || M <= 0 || nk <= 0) return PRE_E_NULL;
-    if (n >= 65536 || nk > 64) return PRE_E_SHAPE;
-    for (int j = 0; j < nk; ++j) {
-        if (ks[j] < 0 || ks[j] >= n) return PRE_E_RANGE;
-        if (j > 0 && ks[j] < ks[j - 1]) return PRE_E_RANGE;      // ascending (slots rely on it)
-    }
-    const long long tiles = (M + KA_W - 1) / KA_W;
-    const long long per_launch = 1LL << 21;                     // x 1024 threads: the dispatch packet counts work-items in 32 bits
-    for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
-        KAList kl;
-        kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
-        for (int j = 0; j < kl.nk; ++j) kl.k[j] = ks[j0 + j];
-        for (long long t0 = 0; t0 < tiles; t0 += per_launch) {
-            const long long nt = tiles - t0 < per_launch ? tiles - t0 : per_launch;
-            hipLaunchKernelGGL(kth_axis0_kernel, dim3((unsigned)nt), dim3(1024), 0, as_stream(stream), scores, (int)n,
-                               (long long)M, t0, kl, out + (long long)j0 * M);
-            PRE_LAUNCH_CHECK();
-        }
     }
     return PRE_OK;
 }

@@ -1,0 +1,631 @@
+// kth_axis0.hip - per-cell order statistics over the batch axis of [n, M] scores (marginal q-hat:
+// calibrate(scores, n, alpha) with 2-D+ scores, call sites Marginal/Wave_Residuals_CP.py:288,
+// Marginal/NS_Residuals_CP.py:310), all requested ranks of a cell at once, ONE launch, no workspace.
+//
+// Bound: HBM.  Algorithmic traffic 4 B per element per sweep; the point of the design is FEW sweeps.
+//
+// A 1024-thread workgroup owns 64 adjacent cells (256 B of every sample row - narrower column tiles lose DRAM
+// efficiency fast: 128 B -> 0.7x, 64 B -> 0.3x, tools/exp/colread.hip).  lane = cell everywhere, one wave = one
+// row, so the 64 LDS atomics of a wave-instruction never hit the same counter.
+//
+// MSD radix select on kk = key - klo[cell]  (key = order-preserving uint32 image of the fp32 score):
+//   0. SAMPLE (<= 1/16 sweep): ~256 evenly spaced rows give each cell the window [klo, khi] of its sample and
+//      its own shift s = the smallest with (khi - klo) >> s <= NB1 - 2 (per cell: one tile-wide shift would be set
+//      by the cell whose sample happens to hold the smallest value, 15 binades instead of 9 on |N(0,1)| scores).
+//   1. FIRST DIGIT (1 sweep, one slot): NB1 = 512 or 1024 buckets over the cell's own window, + an underflow
+//      counter (key < klo) and an overflow bucket.  A fixed top-byte digit wastes its bins on exponents the data
+//      never takes; the window puts all of them where the cell's scores are (|N(0,1)|-like scores: ~16 known
+//      bits instead of 8).
+//      FAST form (n up to ~6 NB1): bucket = floor(fma(v - vlo, sf, 1)) in fp32, sf = (NB1-1)/(vhi - vlo): buckets of
+//      equal width in the VALUE, all NB1 - 1 of them inside the window.  The key is log-like in the value: equal
+//      key-widths spend most buckets on the sparse small values and give a bell-shaped score distribution twice
+//      the peak occupancy (measured: 1023 key-linear buckets left ~half the tiles of n = 4096 |N(0,1)| scores with
+//      a pair above CAP; value-linear ones have a peak mean occupancy of 9).  Any map that is monotone in the
+//      key order keeps the select exact (an fp32 fma with a positive factor, a clamp and floor are; a NaN, whose key
+//      is the largest, would not be, so a NaN in the tile sends it to the general form); if every pair then has
+//      <= CAP elements in its bucket, step 3 follows directly: elements are matched to pairs by bucket number
+//      - a per-cell bitmap of target rows in LDS answers "is this element wanted?" with one conflict-free read,
+//      and only the ~1 % that are pay for the search of their slot: 9 VALU instructions per element instead of
+//      28 - and the rank is picked among their keys.  Otherwise (ties, heavy
+//      tails, non-finite window):
+//      GENERAL form: buckets of width 2^s (digit = kk >> s), so that later digits are bit fields of kk.
+//      If some rank falls outside its window (extreme ranks, unrepresentative sample) the tile repeats this step
+//      with klo = 0 and the plain top-9/10-bit digit: exactness never depends on the sample.
+//   2. while some (cell, rank) still has more than CAP = 31 (29) elements under its prefix: one more
+//      histogram sweep of 6 (5) bits per DISTINCT prefix of the cell ("slot"; ranks ascend, so equal
+//      prefixes are adjacent), counters for <= 10 slots.
+//   3. COLLECT (1 sweep): each surviving element is appended to the list of its slot (the idle histogram
+//      memory) and the owner thread picks its rank among the <= 31 candidates by counting.
+// Typical data: sample + 2 sweeps (8.25 B per element) up to n ~ 2000 with 512 buckets (80 KiB LDS, two
+// workgroups per CU) and up to n ~ 6000 with 1024 buckets (133 KiB, one workgroup per CU); beyond that the
+// general form, sample + 3 sweeps; round 1's fixed 8+6+6+6+6-bit digits needed 3 and 4 sweeps there.  Heavy ties never get under CAP and take every
+// histogram sweep (exact either way).
+//
+// Counters: 16 bit, cells c and c+32 sharing a word (the 32 lanes the LDS serves per cycle hit 32 different
+// banks whatever rows they address), valid for n < 65536; n >= 65536 (BASELINE C5: 65536 samples) runs the
+// WIDE instantiation with one 32-bit counter per cell (512 first-digit buckets, 5-bit later digits).
+//
+// narrow: thread (cell = tid & 63, rank j = tid >> 6) owns the state (prefix, residual rank) of its pair in
+// registers and walks the bins of its slot - 640 independent walks, no cross-lane traffic, written branch-free
+// (digit = number of bins whose running count is <= the rank) so the LDS reads pipeline.  New prefixes reach the
+// sweeping waves through the idle histogram memory.
+#include "common.h"
+
+namespace {
+
+#ifndef KA_U_A
+#define KA_U_A 8
+#endif
+#ifndef KA_U_B
+#define KA_U_B 16
+#endif
+constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16;
+constexpr int KA_LATE_WORDS = KA_MAXK * 64 * 32;          // later sweeps (and up to 31-entry collect lists): 80 KiB
+constexpr int KA_FLAGS_AT = 1008;                         // per-wave flags (words 640..1023 are never used otherwise)
+struct KAList { int nk; int k[KA_MAXK]; };
+
+template <bool WIDE> struct Ctr {
+    static constexpr int CW = WIDE ? 64 : 32;             // words per histogram row
+    static __device__ __forceinline__ int word(int row, int lane) { return WIDE ? row * 64 + lane : row * 32 + (lane & 31); }
+    static __device__ __forceinline__ unsigned int inc(int lane) { return WIDE ? 1u : 1u << (16 * (lane >> 5)); }
+    static __device__ __forceinline__ unsigned int get(const unsigned int *hist, int row, int lane)
+    {
+        return WIDE ? hist[row * 64 + lane] : (hist[row * 32 + (lane & 31)] >> (16 * (lane >> 5))) & 0xffffu;
+    }
+};
+
+template <int LOG_NB1, bool WIDE>
+struct KACfg {
+    static constexpr int NB1 = 1 << LOG_NB1, CW = WIDE ? 64 : 32;
+    static constexpr int FIRST_WORDS = (NB1 + 1) * CW + KA_WAVES * 64;       // first-digit histogram + group sums
+    static constexpr int WG_PER_CU = 2 * (FIRST_WORDS > KA_LATE_WORDS ? FIRST_WORDS : KA_LATE_WORDS) * 4 <= 160 * 1024 ? 2 : 1;
+    // collect lists list[slot][i][cell], i < CAP, fill counter in row CAP; behind them the fast form's table "which
+    // slot, if any, wants this row of this cell":
+    //   two workgroups per CU (both must fit 80 KiB; 27-entry lists): a bitmap, word [row >> 4][cell], bit (row & 15)
+    //     = "a target row", bits 16.. = the slot of the word's first target row;
+    //   one workgroup per CU (31-entry lists): room for a byte per (row, cell) holding slot + 1 - five instructions
+    //     less per element (measured at n = 4096: 3.60 vs 3.77 ms) at the price of 2-way bank conflicts inside a quad
+    //     of lanes, which nothing waits for.
+    static constexpr bool BYTEMAP = WG_PER_CU == 1;
+    static constexpr int BM_WORDS = BYTEMAP ? (NB1 + 1) * 16 : ((NB1 + 1 + 15) / 16) * 64;
+    static constexpr int LS = WG_PER_CU == 2 ? 28 : 32, CAP = LS - 1;
+    static constexpr int BM_AT = KA_MAXK * LS * 64;
+    static constexpr int COLLECT_WORDS = BM_AT + BM_WORDS;
+    static constexpr int W1 = FIRST_WORDS > COLLECT_WORDS ? FIRST_WORDS : COLLECT_WORDS;
+    static constexpr int WORDS = W1 > KA_LATE_WORDS ? W1 : KA_LATE_WORDS;
+    static constexpr int U = WG_PER_CU == 2 ? KA_U_A : KA_U_B;             // rows per batch of loads
+    static constexpr int BITS = WIDE ? 5 : 6;                               // 10 slots x 2^BITS bins x CW words = 80 KiB
+    static_assert(WORDS * 4 * WG_PER_CU <= 160 * 1024, "does not fit the 160 KiB LDS");
+};
+
+// elements below the cell's window get all ones: above every valid prefix, so they never match one
+__device__ __forceinline__ unsigned int ka_kk(float v, unsigned int klo)
+{
+    const unsigned int key = f2key(v);
+    return key >= klo ? key - klo : 0xffffffffu;
+}
+
+// My cell's DISTINCT prefixes (published in hist[j*64 + cell] by the previous narrowing), compacted to the
+// front: slot i = i-th distinct prefix; unused entries hold the sentinel 1.  lmax = most slots any cell of the tile
+// has (wave-uniform loop bound for the match); myslot = slot of this thread's own rank.  Ends with a barrier: hist
+// is free again.
+__device__ __forceinline__ void ka_prefixes(unsigned int *hist, int nk, int lane, int wave, unsigned int (&pf)[KA_MAXK],
+                                            int &lmax, int &myslot)
+{
+    unsigned int *scr = hist + 1024 + wave * (KA_MAXK * 64);
+    unsigned int prev = 0;
+    int L = 0;
+#pragma unroll
+    for (int j = 0; j < KA_MAXK; ++j) {
+        const unsigned int p = j < nk ? hist[j * 64 + lane] : 0u;
+        if (j < nk && (j == 0 || p != prev)) { scr[L * 64 + lane] = p; ++L; }
+        if (j == wave) myslot = L - 1;
+        prev = p;
+    }
+#pragma unroll
+    for (int j = 0; j < KA_MAXK; ++j) pf[j] = j < L ? scr[j * 64 + lane] : 1u;
+    int m = L;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    lmax = __builtin_amdgcn_readfirstlane(m);
+    __syncthreads();
+}
+
+template <int N> struct ka_ic { static constexpr int value = N; };
+
+// slot (1-based) whose prefix equals hi, 0 if none; LM = static bound on the number of slots in use.  The lowest
+// slot wins: the sentinel of the unused slots (1) can equal a legitimate value (a fully known kk, bucket row 1),
+// and the real slots come first; a match with an unused slot alone only touches that slot's idle counters.
+template <int LM>
+__device__ __forceinline__ int ka_match(unsigned int hi, const unsigned int (&pf)[KA_MAXK])
+{
+    int m = 0;
+#pragma unroll
+    for (int j = LM - 1; j >= 0; --j) m = (hi == pf[j]) ? j + 1 : m;
+    return m;
+}
+
+// one row of the tile: 64 consecutive floats at the wave-uniform address `p`, lane l reading p[l] (byte offset loff)
+__device__ __forceinline__ float ka_row(const float *p, int loff)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 256, 0x00020000);
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, loff, 0, 0));
+}
+
+// rows wave, wave+16, ... of my cell, U loads in flight per lane.  `col` = the tile's first cell and `wave` are
+// wave-uniform (readfirstlane'd by the kernel): each row is read through a buffer descriptor whose base is advanced
+// by scalar adds, and every load uses the SAME per-lane offset register (per-lane 64-bit addresses cost 2 registers
+// per load in flight and spilled).  (Issuing the next batch before processing the current one was tried: no gain,
+// the sweeps are bound by VALU issue, not by loads in flight.)
+template <int U, class F>
+__device__ __forceinline__ void ka_sweep(const float *__restrict__ col, bool cok, int n, long long M, int wave, F &&f)
+{
+    if (!cok) return;
+    constexpr int STEP = U * KA_WAVES, SPAN = (U - 1) * KA_WAVES;
+    const int loff = (int)(threadIdx.x & 63u) * 4;
+    const long long stride = (long long)KA_WAVES * M;
+    const float *p = col + (long long)wave * M;
+    int i = wave;
+    for (; i + SPAN < n; i += STEP) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { v[u] = ka_row(p, loff); p += stride; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) f(v[u]);
+    }
+    for (; i < n; i += KA_WAVES) { f(ka_row(p, loff)); p += stride; }
+}
+
+// the match against the cell's prefixes costs 2 VALU instructions per slot and element: instantiate the sweep for
+// a few static slot counts and branch (wave-uniformly) on the tile's actual maximum
+template <class G>
+__device__ __forceinline__ void ka_by_slots(int lmax, G &&g)
+{
+    if (lmax <= 2) g(ka_ic<2>{});
+    else if (lmax <= 4) g(ka_ic<4>{});
+    else if (lmax <= 7) g(ka_ic<7>{});
+    else g(ka_ic<KA_MAXK>{});
+}
+
+// block-uniform OR of per-wave flag words (through 16 spare LDS words); ends with a barrier passed by everyone
+__device__ __forceinline__ unsigned int ka_or(unsigned int *hist, unsigned int w, int lane, int wave)
+{
+    if (lane == 0) hist[KA_FLAGS_AT + wave] = w;
+    __syncthreads();
+    unsigned int x = hist[KA_FLAGS_AT + (lane & (KA_WAVES - 1))];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) x |= __shfl_xor(x, o);
+    return __builtin_amdgcn_readfirstlane(x);
+}
+
+// ---- step 0: the cell's window from ~256 evenly spaced rows: klo and the shift of the general form (per lane), and
+// the map t = fma(v - vlo, sf, 1) of the fast form (sf < 0: the window is not finite, the fast form must not be used)
+template <int LOG_NB1>
+__device__ __forceinline__ int ka_window(const float *__restrict__ col, bool cok, int n, long long M, unsigned int *hist,
+                                         unsigned int &klo, float &sf, float &vlo, int lane, int wave)
+{
+    const int m = n < 256 ? n : 256;                       // sample rows floor(j*n/m), j = wave, wave+16, ...
+    unsigned int kmin = 0xffffffffu, kmax = 0u;
+    if (cok) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = wave + u * KA_WAVES;
+            v[u] = j < m ? ka_row(col + (long long)(((long long)j * n) / m) * M, lane * 4) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (wave + u * KA_WAVES < m) {
+                const unsigned int k = f2key(v[u]);
+                kmin = min(kmin, k);
+                kmax = max(kmax, k);
+            }
+    }
+    hist[wave * 64 + lane] = kmin;
+    hist[1024 + wave * 64 + lane] = kmax;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < KA_WAVES; ++w) {
+        kmin = min(kmin, hist[w * 64 + lane]);
+        kmax = max(kmax, hist[1024 + w * 64 + lane]);
+    }
+    __syncthreads();
+    klo = cok ? kmin : 0u;
+    const unsigned int range = cok ? kmax - kmin : 0u;
+    // general form: smallest shift with (range >> shift) <= NB1 - 2 (bucket NB1 - 1 is the overflow bucket)
+    int s = range == 0u ? 0 : max(0, (32 - __clz((int)range)) - LOG_NB1);
+    if ((range >> s) > (unsigned)((1 << LOG_NB1) - 2)) ++s;
+    // fast form: rows 1 .. NB1-1 hold the window (t in [1, NB1)), row 0 = below it, row NB1 = above it:
+    // sf a hair under (NB1-1)/(vhi - vlo), so that the window's top value stays below NB1
+    vlo = key2f(kmin);
+    const float r = key2f(kmax) - vlo;
+    sf = r > 0.f ? ((float)((1 << LOG_NB1) - 1) / r) * 0.999999f : 0.f;       // r == 0: one value sampled, row 1 takes all
+    if (!(r >= 0.f) || !(r < __builtin_inff()) || !(fabsf(vlo) < __builtin_inff())) sf = -1.f;
+    if (!cok) { sf = 0.f; vlo = 0.f; }
+    return s;
+}
+
+// row of the fast form: 0 for t < 1 (below the window), NB1 at or beyond the window's end.  (v - vlo first: folding
+// vlo into the fma's addend would be one instruction less but rounds the window position by ulp(vlo * sf) rows.)
+template <int NB1>
+__device__ __forceinline__ int ka_frow(float v, float sf, float vlo)
+{
+    return (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(v - vlo, sf, 1.0f), 0.f, (float)NB1);
+}
+
+// ---- narrowing after a first-digit sweep.  Buckets d = 0..NB1-1 live in histogram rows row0 + d, the elements
+// below the window in row `urow`.  For the thread's (cell, rank): bucket, its count, the rank left inside it;
+// `outside`: the rank lies below the window or in the overflow bucket NB1-1 (`window`).
+template <int LOG_NB1, bool WIDE>
+__device__ __forceinline__ void ka_narrow_first(unsigned int *hist, int row0, int urow, bool window, bool state,
+                                                unsigned int &myr, int &digit, unsigned int &count, bool &outside,
+                                                int lane, int wave)
+{
+    using C = Ctr<WIDE>;
+    constexpr int NB1 = 1 << LOG_NB1, GB = NB1 / KA_WAVES, GROUPS_AT = (NB1 + 1) * C::CW;
+    // 16 groups of GB bins are summed by all 1024 threads first
+    unsigned int gs = 0;
+#pragma unroll 8
+    for (int u = 0; u < GB; ++u) gs += C::get(hist, row0 + wave * GB + u, lane);
+    hist[GROUPS_AT + wave * 64 + lane] = gs;
+    __syncthreads();
+    outside = false;
+    digit = 0;
+    count = 0;
+    if (state) {
+        const unsigned int under = C::get(hist, urow, lane);
+        outside = myr < under;
+        const unsigned int r = outside ? 0u : myr - under;
+        // group of my rank = number of groups whose inclusive running count is <= r (branch-free: the LDS reads
+        // are independent and pipeline)
+        unsigned int run = 0, cum = 0;
+        int g = 0;
+#pragma unroll
+        for (int u = 0; u < KA_WAVES; ++u) {
+            run += hist[GROUPS_AT + u * 64 + lane];
+            const bool le = run <= r;
+            g += le;
+            cum = le ? run : cum;
+        }
+        g = min(g, KA_WAVES - 1);
+        const int bin0 = g * GB;
+        run = cum;
+        int d = 0;
+#pragma unroll 8
+        for (int bin = bin0; bin < bin0 + GB; ++bin) {
+            run += C::get(hist, row0 + bin, lane);
+            const bool le = run <= r;
+            d += le;
+            cum = le ? run : cum;
+        }
+        digit = bin0 + min(d, GB - 1);
+        outside = outside || (window && digit == NB1 - 1);
+        count = C::get(hist, row0 + digit, lane);
+        myr = r - cum;
+    }
+}
+
+template <int LS> __device__ __forceinline__ int ka_list(int slot, int i, int cell) { return (slot * LS + i) * 64 + cell; }
+
+// counters 0, entries all ones (the sentinel the pick relies on)
+template <int LS> __device__ __forceinline__ void ka_list_init(unsigned int *hist, int tid)
+{
+    int rm = (tid >> 6) % LS;              // list row of word i: (i >> 6) % LS, advanced without a division per store
+    for (int i = tid; i < KA_MAXK * LS * 64; i += 1024) {
+        hist[i] = rm == LS - 1 ? 0u : 0xffffffffu;
+        rm += 16;
+        rm = rm >= LS ? rm - LS : rm;
+    }
+}
+
+// the owner thread picks its rank among the <= CAP candidates of its slot by counting (k-th smallest = the
+// smallest candidate with more than k candidates <= it)
+template <int LS>
+__device__ __forceinline__ unsigned int ka_pick(const unsigned int *hist, int myslot, bool open, unsigned int myr, int lane)
+{
+    const int c = open ? (int)hist[ka_list<LS>(myslot, LS - 1, lane)] : 0;
+    int cmax = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+    cmax = __builtin_amdgcn_readfirstlane(cmax);
+    unsigned int ans = 0xffffffffu;
+    for (int i = 0; i < cmax; ++i) {
+        const unsigned int ki = hist[ka_list<LS>(myslot, i, lane)];      // sentinel beyond my own count
+        unsigned int le = 0;
+        for (int j = 0; j < cmax; ++j) le += hist[ka_list<LS>(myslot, j, lane)] <= ki;
+        if (i < c && le > myr) ans = min(ans, ki);
+    }
+    return ans;
+}
+
+// ---- the fast form (steps 1 + 3).  Returns true (block-uniform) when the tile is finished: `ans` then holds the
+// KEY of the thread's (cell, rank).  Returns false when some pair has more than CAP elements in its bucket, a
+// rank lies outside its window, the window is not finite, or the tile holds a NaN: nothing is kept, the caller
+// runs the general form; *below reports whether a rank lay outside its window.
+template <int LOG_NB1, bool WIDE>
+__device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok, int n, long long M, int nk, float sf, float vlo,
+                                        unsigned int *hist, unsigned int k0, unsigned int &ans, bool &below, int lane,
+                                        int wave, int tid)
+{
+    using C = Ctr<WIDE>;
+    using Cfg = KACfg<LOG_NB1, WIDE>;
+    constexpr int NB1 = 1 << LOG_NB1, U = Cfg::U, LS = Cfg::LS, CAP = Cfg::CAP;
+    const bool state = wave < nk;
+    for (int i = tid; i < (NB1 + 1) * C::CW; i += 1024) hist[i] = 0u;
+    __syncthreads();
+    const unsigned int inc = C::inc(lane);
+    unsigned long long nan = 0ull;
+    ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+        nan |= __ballot(v != v);
+        atomicAdd(&hist[C::word(ka_frow<NB1>(v, sf, vlo), lane)], inc);
+    });
+    __syncthreads();
+    unsigned int myr = k0, count;
+    int digit;
+    bool outside;
+    ka_narrow_first<LOG_NB1, WIDE>(hist, 1, 0, true, state, myr, digit, count, outside, lane, wave);
+    const bool bad = state && (outside || sf < 0.f), many = state && count > (unsigned)CAP;
+    const unsigned int w = (__ballot(many) != 0 ? 1u : 0u) | (__ballot(bad) != 0 ? 2u : 0u) | (nan != 0ull ? 4u : 0u);
+    __syncthreads();                       // everyone is done reading the histograms
+    if (state) hist[wave * 64 + lane] = (unsigned)(digit + 1);         // publish my ROW for the collect's matching
+    const unsigned int fl = ka_or(hist, w, lane, wave);
+    below = (fl & 2u) != 0u;
+    if (fl) return false;
+
+    // collect: every pair has <= CAP elements in its row.  An element is tested against the bitmap of its cell's
+    // target rows (one conflict-free LDS read).  Slots are the cell's distinct target rows in ascending order, so
+    // the slot of a hit is the number of target rows below it: the word's base count + a popcount - four
+    // instructions, which matters because a wave takes the branch when ANY of its 64 cells hits (~60 % of the rows).
+    unsigned int pf[KA_MAXK];
+    int lmax = 1, myslot = 0;
+    ka_prefixes(hist, nk, lane, wave, pf, lmax, myslot);
+    ka_list_init<LS>(hist, tid);
+    for (int i = tid; i < Cfg::BM_WORDS; i += 1024) hist[Cfg::BM_AT + i] = 0u;
+    __syncthreads();
+    const int myrow = digit + 1;
+    if constexpr (Cfg::BYTEMAP) {
+        unsigned char *map = reinterpret_cast<unsigned char *>(hist + Cfg::BM_AT);
+        if (state) map[myrow * 64 + lane] = (unsigned char)(myslot + 1);
+        __syncthreads();
+        ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+            const int m = map[ka_frow<NB1>(v, sf, vlo) * 64 + lane];
+            if (m) {
+                const unsigned int pos = atomicAdd(&hist[ka_list<LS>(m - 1, CAP, lane)], 1u);
+                if (pos < (unsigned)CAP) hist[ka_list<LS>(m - 1, (int)pos, lane)] = f2key(v);  // (always: the histogram counted them)
+            }
+        });
+    } else {
+        unsigned int *myword = &hist[Cfg::BM_AT + (myrow >> 4) * 64 + lane];
+        if (state) atomicOr(myword, 1u << (myrow & 15));
+        __syncthreads();
+        if (state) atomicOr(myword, (unsigned)(myslot - __popc(*myword & ((1u << (myrow & 15)) - 1u))) << 16);
+        __syncthreads();
+        ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+            const int row = ka_frow<NB1>(v, sf, vlo);
+            const unsigned int w = hist[Cfg::BM_AT + (row >> 4) * 64 + lane], bit = (unsigned)row & 15u;
+            if ((w >> bit) & 1u) {
+                const int slot = (int)(w >> 16) + __popc(w & ((1u << bit) - 1u));
+                const unsigned int pos = atomicAdd(&hist[ka_list<LS>(slot, CAP, lane)], 1u);
+                if (pos < (unsigned)CAP) hist[ka_list<LS>(slot, (int)pos, lane)] = f2key(v);   // (always: the histogram counted them)
+            }
+        });
+    }
+    __syncthreads();
+    if (state) ans = ka_pick<LS>(hist, myslot, true, myr, lane);
+    return true;
+}
+
+// ---- step 1, general form: buckets (key - klo) >> shift (clamped to the overflow bucket NB1-1) in rows
+// 0..NB1-1, row NB1 = key < klo.  `window`: a rank that lands in the overflow bucket or below the window is
+// reported through `outside`.  Returns (block-uniform) whether some pair has more than CAP elements left.
+template <int LOG_NB1, bool WIDE>
+__device__ __forceinline__ bool ka_first(const float *__restrict__ col, bool cok, int n, long long M, int nk, int shift,
+                                         unsigned int klo, bool window, unsigned int *hist, unsigned int &myp,
+                                         unsigned int &myr, bool &outside, int lane, int wave, int tid)
+{
+    using C = Ctr<WIDE>;
+    constexpr int NB1 = 1 << LOG_NB1, U = KACfg<LOG_NB1, WIDE>::U, CAP = KACfg<LOG_NB1, WIDE>::CAP;
+    const bool state = wave < nk;
+    for (int i = tid; i < (NB1 + 1) * C::CW; i += 1024) hist[i] = 0u;
+    __syncthreads();
+    const unsigned int inc = C::inc(lane);
+    ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+        const unsigned int key = f2key(v);
+        const unsigned int d = min((key - klo) >> shift, (unsigned)(NB1 - 1));
+        atomicAdd(&hist[C::word(key >= klo ? (int)d : NB1, lane)], inc);
+    });
+    __syncthreads();
+    int digit;
+    unsigned int count;
+    ka_narrow_first<LOG_NB1, WIDE>(hist, 0, NB1, window, state, myr, digit, count, outside, lane, wave);
+    const bool many = state && shift > 0 && count > (unsigned)CAP;          // shift == 0: every bit is known
+    if (state) myp = (unsigned)digit << shift;
+    const unsigned int w = (__ballot(many) != 0 ? 1u : 0u) | (__ballot(outside) != 0 ? 2u : 0u);
+    __syncthreads();                       // everyone is done reading the histograms
+    if (state) hist[wave * 64 + lane] = myp;                  // publish for the next sweep's matching
+    const unsigned int fl = ka_or(hist, w, lane, wave);
+    outside = (fl & 2u) != 0u;                                // block-uniform from here on
+    return (fl & 1u) != 0u;
+}
+
+// ---- step 2: one more digit of BITS bits at `shift` under the prefixes known down to bit `pshift` (both per
+// cell; shift + BITS may exceed pshift for the last digit: the overlapping bits are fixed by the prefix match, so
+// only consistent bins fill; a cell that is already fully known, pshift == 0, just recounts its ties).  Returns
+// whether some pair still has more than CAP elements under its prefix.
+template <int BITS, bool WIDE, int U, int CAP>
+__device__ __forceinline__ bool ka_pass(const float *__restrict__ col, bool cok, int n, long long M, int nk, int pshift,
+                                        int shift, unsigned int klo, unsigned int *hist, unsigned int &myp,
+                                        unsigned int &myr, int lane, int wave, int tid)
+{
+    using C = Ctr<WIDE>;
+    constexpr int NB = 1 << BITS;
+    const unsigned int mask = ~0u << pshift;
+    const bool state = wave < nk;
+    unsigned int pf[KA_MAXK];
+    int lmax = 1, myslot = 0;
+    ka_prefixes(hist, nk, lane, wave, pf, lmax, myslot);
+    for (int i = tid; i < KA_MAXK * NB * C::CW; i += 1024) hist[i] = 0u;
+    __syncthreads();
+
+    const unsigned int inc = C::inc(lane);
+    ka_by_slots(lmax, [&](auto lm) __attribute__((always_inline)) {
+        ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+            const unsigned int kk = ka_kk(v, klo);
+            const int m = ka_match<decltype(lm)::value>(kk & mask, pf);
+            if (m) atomicAdd(&hist[C::word((m - 1) * NB + (int)((kk >> shift) & (NB - 1)), lane)], inc);
+        });
+    });
+    __syncthreads();
+
+    bool many = false;
+    if (state) {
+        // digit = number of bins whose inclusive running count is <= myr; `cum` ends as the count before it
+        const int base = myslot * NB;
+        unsigned int run = 0, cum = 0;
+        int d = 0;
+#pragma unroll 8
+        for (int bin = 0; bin < NB; ++bin) {
+            run += C::get(hist, base + bin, lane);
+            const bool le = run <= myr;
+            d += le;
+            cum = le ? run : cum;
+        }
+        const int digit = min(d, NB - 1);
+        many = shift > 0 && C::get(hist, base + digit, lane) > (unsigned)CAP;
+        if (pshift > 0) {
+            myp |= (unsigned)digit << shift;
+            myr -= cum;
+        }
+    }
+    const unsigned int w = __ballot(many) != 0 ? 1u : 0u;
+    __syncthreads();                       // everyone is done reading the histograms
+    if (state) hist[wave * 64 + lane] = myp;
+    return ka_or(hist, w, lane, wave) != 0u;
+}
+
+// ---- step 3, general form: every (cell, rank) of the tile has at most CAP elements left under its prefix
+// (known down to bit `known`, per cell): ONE sweep appends each surviving kk to the list of its slot -
+// list[slot][i][cell], fill counter in row CAP - and the owner thread picks its rank.
+template <int U, int LS>
+__device__ __forceinline__ void ka_collect(const float *__restrict__ col, bool cok, int n, long long M, int nk, int known,
+                                           unsigned int klo, unsigned int *hist, unsigned int &myp, unsigned int myr,
+                                           int lane, int wave, int tid)
+{
+    const unsigned int mask = ~0u << known;
+    unsigned int pf[KA_MAXK];
+    int lmax = 1, myslot = 0;
+    ka_prefixes(hist, nk, lane, wave, pf, lmax, myslot);
+    ka_list_init<LS>(hist, tid);
+    __syncthreads();
+
+    ka_by_slots(lmax, [&](auto lm) __attribute__((always_inline)) {
+        ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+            const unsigned int kk = ka_kk(v, klo);
+            const int m = ka_match<decltype(lm)::value>(kk & mask, pf);
+            if (m) {
+                const unsigned int pos = atomicAdd(&hist[ka_list<LS>(m - 1, LS - 1, lane)], 1u);
+                // pos < CAP for every pair still open (the histogram counted its elements); a fully known cell
+                // (known == 0) matches all its ties, which are not needed
+                if (pos < (unsigned)(LS - 1)) hist[ka_list<LS>(m - 1, (int)pos, lane)] = kk;
+            }
+        });
+    });
+    __syncthreads();
+    if (wave < nk) {                       // (whole waves: the pick shuffles across the lanes)
+        const unsigned int ans = ka_pick<LS>(hist, myslot, known > 0, myr, lane);
+        if (known > 0) myp = ans;
+    }
+}
+
+template <int LOG_NB1, bool WIDE>
+__global__ void __launch_bounds__(1024, (4 * KACfg<LOG_NB1, WIDE>::WG_PER_CU))
+kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile0, const KAList kl, int fast,
+                 float *__restrict__ out)
+{
+    using Cfg = KACfg<LOG_NB1, WIDE>;
+    constexpr int U = Cfg::U, BITS = Cfg::BITS;
+    __shared__ unsigned int hist[Cfg::WORDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = kl.nk;
+    const long long c0 = (tile0 + blockIdx.x) * KA_W, c = c0 + lane;
+    const bool cok = c < M;
+    const float *col = s + c0;             // the tile's first cell: wave-uniform (lane offsets are added at the loads)
+    const bool state = wave < nk;
+    const unsigned int k0 = state ? (unsigned)kl.k[wave] : 0u;
+
+    unsigned int klo = 0u;
+    float sf = 0.f, vlo = 0.f;
+    int shift = ka_window<LOG_NB1>(col, cok, n, M, hist, klo, sf, vlo, lane, wave);
+    bool outside = false;
+    if (fast) {
+        unsigned int key = 0u;
+        if (ka_fast<LOG_NB1, WIDE>(col, cok, n, M, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid)) {
+            if (state && cok) out[(long long)wave * M + c] = key2f(key);
+            return;
+        }
+        __syncthreads();                   // (every wave has read the flags before the histogram memory is cleared again)
+    }
+    unsigned int myp = 0u, myr = k0;
+    bool many = true;
+    if (!outside) {
+        many = ka_first<LOG_NB1, WIDE>(col, cok, n, M, nk, shift, klo, true, hist, myp, myr, outside, lane, wave, tid);
+        if (outside) __syncthreads();
+    }
+    if (outside) {                         // some rank lies outside its cell's sampled window: plain top digit
+        klo = 0u;
+        shift = 32 - LOG_NB1;
+        myp = 0u;
+        myr = k0;
+        many = ka_first<LOG_NB1, WIDE>(col, cok, n, M, nk, shift, klo, false, hist, myp, myr, outside, lane, wave, tid);
+    }
+    int known = shift;                     // lowest known bit of my cell's kk so far (per lane)
+#pragma unroll 1
+    while (many) {
+        const int sh = known > BITS ? known - BITS : 0;
+        many = ka_pass<BITS, WIDE, U, Cfg::CAP>(col, cok, n, M, nk, known, sh, klo, hist, myp, myr, lane, wave, tid);
+        known = sh;
+    }
+    __syncthreads();
+    if (ka_or(hist, __ballot(state && known > 0) != 0 ? 1u : 0u, lane, wave))      // else every bit of every cell is counted
+        ka_collect<U, Cfg::LS>(col, cok, n, M, nk, known, klo, hist, myp, myr, lane, wave, tid);
+    if (state && cok) out[(long long)wave * M + c] = key2f(myp + klo);
+}
+
+template <int LOG_NB1, bool WIDE>
+int launch_kth(const float *scores, int n, long long M, const int32_t *ks, int nk, float *out, hipStream_t st)
+{
+    const long long tiles = (M + KA_W - 1) / KA_W;
+    const long long per_launch = 1LL << 21;                     // x 1024 threads: the dispatch packet counts work-items in 32 bits
+    for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
+        KAList kl;
+        kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
+        for (int j = 0; j < kl.nk; ++j) kl.k[j] = ks[j0 + j];
+        for (long long t0 = 0; t0 < tiles; t0 += per_launch) {
+            const long long nt = tiles - t0 < per_launch ? tiles - t0 : per_launch;
+            // the fast first digit pays while a full bucket holds well under CAP elements (n <= ~6 NB1 on
+            // bell-shaped scores); beyond that it would be a wasted sweep
+            hipLaunchKernelGGL((kth_axis0_kernel<LOG_NB1, WIDE>), dim3((unsigned)nt), dim3(1024), 0, st, scores, n, M, t0, kl,
+                               n <= 6 * (1 << LOG_NB1) ? 1 : 0, out + (long long)j0 * M);
+            PRE_LAUNCH_CHECK();
+        }
+    }
+    return PRE_OK;
+}
+
+}  // namespace
+
+extern "C" int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks, int nk, float *out, void *stream)
+{
+    if (!scores || !ks || !out || n <= 0 || M <= 0 || nk <= 0) return PRE_E_NULL;
+    if (n > 0x7fffffff || nk > 64) return PRE_E_SHAPE;
+    for (int j = 0; j < nk; ++j) {
+        if (ks[j] < 0 || ks[j] >= n) return PRE_E_RANGE;
+        if (j > 0 && ks[j] < ks[j - 1]) return PRE_E_RANGE;      // ascending (slots rely on it)
+    }
+    hipStream_t st = as_stream(stream);
+    // 16-bit counters hold n < 65536; 1024 first-digit buckets (one workgroup per CU) pay off once 512 buckets
+    // would leave more than CAP elements per bucket (n above ~2000)
+    if (n >= 65536) return launch_kth<9, true>(scores, (int)n, (long long)M, ks, nk, out, st);
+    if (n > 2048) return launch_kth<10, false>(scores, (int)n, (long long)M, ks, nk, out, st);
+    return launch_kth<9, false>(scores, (int)n, (long long)M, ks, nk, out, st);
+}

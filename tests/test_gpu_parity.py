@@ -353,6 +353,54 @@ def test_marginal_qhat_bit_exact_vs_numpy(gpu, n, cells):
     assert np.array_equal(q, oc.calibrate(a_, n, 0.1))
 
 
+@pytest.mark.parametrize("n,M", [(65536, 4096), (70001, 130), (100000, 64)])
+def test_marginal_qhat_large_n_wide_counters(gpu, n, M):
+    """n >= 65536 (BASELINE C5 has 65536 samples; Marginal/Burgers_Residuals_CP.py:272 would select per cell over
+    all of them): the 32-bit-counter instantiation, against torch.sort on the device, the 10 reference ranks
+    plus the extremes."""
+    from cp_pre_amd import inductive_cp as icp
+    g = torch.Generator(device=gpu).manual_seed(n)
+    s = torch.randn(n, M, device=gpu, generator=g).abs_() * (0.5 + torch.rand(M, device=gpu, generator=g) * 8)
+    s[: n // 3, 0] = 2.0                                                # a third of one column tied
+    s[:, 1] = 7.25                                                      # a constant column
+    s[17, 2] = float("inf")
+    ks = sorted({icp.kth_index(n, n, float(a)) for a in icp.ALPHA_LEVELS} | {0, 1, n - 2, n - 1})
+    got = icp.kth_axis0(s, ks)
+    ref = torch.sort(s, dim=0).values[ks]
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("n", [40, 256, 1500, 2049, 5000, 12000])
+def test_marginal_qhat_window_and_fallback_paths(gpu, n):
+    """The sample-guided first digit must never decide the RESULT: columns whose sampled rows are unrepresentative
+    (sorted data, outliers only between the sampled rows, mixed signs, huge dynamic range, heavy ties, denormals)
+    and ranks at both extremes, against torch.sort.  Bit-exact."""
+    from cp_pre_amd import inductive_cp as icp
+    g = torch.Generator(device=gpu).manual_seed(1000 + n)
+    M = 200
+    s = torch.randn(n, M, device=gpu, generator=g)
+    s[:, :20] = s[:, :20].abs()
+    s[:, 20:40] = torch.sort(s[:, 20:40], dim=0).values                 # ordered calibration sets
+    s[:, 40:50] = torch.sort(s[:, 40:50], dim=0, descending=True).values
+    stride = max(1, n // 256)
+    off = torch.arange(n, device=gpu) % stride != 0                     # rows the sampler never reads (if any)
+    if off.any():
+        s[:, 50:60] = torch.where(off[:, None], s[:, 50:60] * 1e6, s[:, 50:60] * 1e-6)
+    s[:, 60:70] = torch.exp(s[:, 60:70] * 20)                           # ~170 binades
+    s[:, 70:80] = torch.round(s[:, 70:80] * 2) / 2                      # heavy ties (a handful of distinct values)
+    s[:, 80:90] = s[:, 80:90] * 1e-42                                   # denormals
+    s[: n // 2, 90:95] = 3.0
+    s[n // 2:, 90:95] = -3.0                                            # two values only
+    s[::3, 95:100] = 0.0
+    s[1::3, 95:100] = -0.0
+    ks = sorted({icp.kth_index(n, n, float(a)) for a in icp.ALPHA_LEVELS if icp.quantile_level(n, float(a)) <= 1}
+                | {0, 1, n // 2, n - 2, n - 1})
+    for group in (ks[:10], ks[-10:]):
+        got = icp.kth_axis0(s, group)
+        ref = torch.sort(s, dim=0).values[group]
+        assert torch.equal(got.view(torch.int32), ref.view(torch.int32)) or torch.equal(got, ref), (n, group)
+
+
 def test_joint_recipe_vs_numpy(gpu):
     """modulation -> per-sample score -> scalar q-hat -> bounds -> joint coverage; q-hat within 1e-6."""
     from cp_pre_amd import inductive_cp as icp
