@@ -139,39 +139,69 @@ class JointCalibration:
         return self.ops.kth(scores, _ranks(self.n_total, alphas))
 
 
-def marginal_qhat(scores, alphas, group=None, ops=None, stage_bytes=8 << 30):
+def marginal_qhat(scores, alphas, group=None, ops=None, stage_bytes=4 << 30, overlap=True):
     """Per-cell q-hat [len(alphas), *cells] of |residual| scores [n_local, *cells].
 
-    Single rank: one multi-rank radix select.  Sharded: all-to-all (batch-sharded ->
-    cell-sharded), local select over all ``n_local * world`` samples, all-gather of the result.
-    The exchange runs over runs of cells sized so that the send and the receive staging buffers
-    hold at most ``stage_bytes`` each (a C3 slab of scores is 43 GB; staging it whole twice next to
-    the fields would not fit in HBM)."""
+    Single rank: one multi-rank radix select.  Sharded: all-to-all (batch-sharded -> cell-sharded), local select
+    over all ``n_local * world`` samples, ONE all-gather of the result at the end.
+
+    The exchange runs over runs of cells sized so that one send and one receive staging buffer hold at most
+    ``stage_bytes`` each (a C3 slab of scores is 56 GB; staging it whole next to the fields would not fit in HBM).
+    ``overlap``: the staging buffers are double-buffered and the all-to-all of run k is issued asynchronously
+    (RCCL runs it on its own stream) before the select of run k-1 is enqueued, so the xGMI transfer of one run hides
+    behind the select of the previous one; nothing else is ordered differently, the result is identical."""
     ops = ops or HipOps
     n_local, cells = scores.shape[0], tuple(scores.shape[1:])
     if group is None:
         return ops.kth(scores, _ranks(n_local, alphas))
     world = torch.distributed.get_world_size(group)
+    if n_local * world > 0x7fffffff:
+        raise ValueError(f"{n_local} x {world} calibration samples exceed the select's 32-bit sample count")
     flat = scores.reshape(n_local, -1)
     M = flat.shape[1]
-    ks = _ranks(n_local * world, alphas)
+    ks = _ranks(n_local * world, alphas)          # raises before any collective if a level exceeds 1
+    nk = len(alphas)
     per = max(1, min((M + world - 1) // world, int(stage_bytes) // (4 * n_local * world)))   # cells per rank per run
     run = per * world
-    q = flat.new_empty(len(alphas), M)
-    send = flat.new_empty(world, n_local, per)
-    recv = torch.empty_like(send)
-    parts = [flat.new_empty(len(alphas), per) for _ in range(world)]
-    for c0 in range(0, M, run):
+    runs = (M + run - 1) // run
+    nbuf = 2 if (overlap and runs > 1) else 1
+    send = [flat.new_empty(world, n_local, per) for _ in range(nbuf)]
+    recv = [torch.empty_like(send[0]) for _ in range(nbuf)]
+    q_own = flat.new_empty(runs, nk, per)         # the q-hats of the cells this rank owns, run by run
+    work = [None] * nbuf
+
+    def pack(k, buf):
+        c0 = k * run
         w = min(run, M - c0)
         if w == run:                                           # rank r will own cells [c0 + r*per, c0 + (r+1)*per)
-            send.copy_(flat[:, c0:c0 + run].reshape(n_local, world, per).permute(1, 0, 2))
-        else:                                                  # ragged last run: pad with zeros, dropped below
-            send.zero_()
+            buf.copy_(flat[:, c0:c0 + run].reshape(n_local, world, per).permute(1, 0, 2))
+        else:                                                  # ragged last run: pad with zeros, dropped at the end
+            buf.zero_()
             for r in range(world):
                 wr = max(0, min(per, w - r * per))
-                send[r, :, :wr] = flat[:, c0 + r * per:c0 + r * per + wr]
-        torch.distributed.all_to_all_single(recv, send, group=group)      # RCCL: (world-1)/world of the run leaves
-        q_local = ops.kth(recv.reshape(world * n_local, per), ks)         # every sample of my cells: [nk, per]
-        torch.distributed.all_gather(parts, q_local.contiguous(), group=group)
-        q[:, c0:c0 + w] = torch.cat(parts, dim=1)[:, :w]
-    return q.reshape((len(alphas),) + cells)
+                buf[r, :, :wr] = flat[:, c0 + r * per:c0 + r * per + wr]
+
+    def select(k):
+        b = k % nbuf
+        if work[b] is not None:
+            work[b].wait()                                     # the compute stream waits for run k's exchange
+            work[b] = None
+        q_own[k] = ops.kth(recv[b].reshape(world * n_local, per), ks)        # every sample of my cells: [nk, per]
+
+    for k in range(runs):
+        b = k % nbuf
+        pack(k, send[b])
+        # RCCL: (world-1)/world of the run leaves over xGMI; issued after the pack (stream order), completes on
+        # RCCL's stream while the select below runs
+        work[b] = torch.distributed.all_to_all_single(recv[b], send[b], group=group, async_op=nbuf > 1)
+        if nbuf > 1 and k > 0:
+            select(k - 1)
+        elif nbuf == 1:
+            select(k)
+    if nbuf > 1:
+        select(runs - 1)
+    parts = [torch.empty_like(q_own) for _ in range(world)]
+    torch.distributed.all_gather(parts, q_own, group=group)                  # RCCL: nk * M / world floats per rank
+    # parts[r][k, j, i] is the q-hat j of cell k*run + r*per + i
+    q = torch.stack(parts, dim=2).permute(1, 0, 2, 3).reshape(nk, runs * run)[:, :M]
+    return q.reshape((nk,) + cells)

@@ -76,6 +76,14 @@ def _worker(rank, world, port, n_local, shape, slabs, out_dir):
         qm_runs = pipeline.marginal_qhat(mine.abs().contiguous(), ALPHAS, group=dist.group.WORLD, ops=CpuOps,
                                          stage_bytes=4 * n_local * world * 100)
         assert torch.equal(qm_runs, qm)
+        # the double-buffered asynchronous exchange (default) against the blocking one, 1 / 4 / 8 runs
+        for cells_per_rank in (400, 100, 50):
+            kw = dict(group=dist.group.WORLD, ops=CpuOps, stage_bytes=4 * n_local * world * cells_per_rank)
+            a = pipeline.marginal_qhat(mine.abs().contiguous(), ALPHAS, overlap=True, **kw)
+            b = pipeline.marginal_qhat(mine.abs().contiguous(), ALPHAS, overlap=False, **kw)
+            assert torch.equal(a, b) and torch.equal(a, qm)
+        with pytest.raises(ValueError):                       # a level above 1 is refused before any collective
+            pipeline.marginal_qhat(mine.abs().contiguous(), [1e-6], group=dist.group.WORLD, ops=CpuOps)
         np.save(os.path.join(out_dir, f"q_{rank}.npy"), q.numpy())
         np.save(os.path.join(out_dir, f"scores_{rank}.npy"), jc.all_scores.numpy())
         np.save(os.path.join(out_dir, f"mod_{rank}.npy"), torch.cat([m[1:-1] for m in jc.modulation]).numpy())
