@@ -4,9 +4,11 @@
 // pre_stencil3d_f32 first offers the tap list to the streaming star kernel
 // (star_march.hip); tap sets that are not on the 7-point star, views without a unit-stride
 // axis, and the last (extent % 4) columns of an odd-width grid run here:
-// Two forms:
-//   generic_tile_kernel  views with a unit-stride axis (relabelled to be the last one): 16 x 256 output
-//                        tiles, each needed input plane staged once in LDS, taps grouped by row;
+// Three forms:
+//   generic_tile_kernel  views with a unit-stride axis of >= 64 cells (relabelled to be the last one): 16 x 256
+//                        output tiles, each needed input plane staged once in LDS, taps grouped by row;
+//   flat_taps_kernel     views whose unit-stride axis is short but contiguous with the next one (the surrogate's
+//                        Nt-fastest layout): the two axes merged into one row, chunks of 1024 cells staged in LDS;
 //   generic_kernel       anything else (and sub-box tails): one thread per cell, neighbours via L2.
 // It is the correctness floor of the library (5^3 / 7^3 Taylor kernels, padded additive kernels,
 // fully strided views, odd sizes); it is not on the benchmarked path.
@@ -145,6 +147,116 @@ __global__ void __launch_bounds__(256) generic_tile_kernel(const float *__restri
             if (y + 3 < Y) *reinterpret_cast<G4u *>(o) = G4u{a[k][0], a[k][1], a[k][2], a[k][3]};
             else for (int j = 0; j < Y - y; ++j) o[j] = a[k][j];
         }
+    }
+}
+
+// ---- flat form: SHORT unit-stride axis whose rows follow each other in memory ---------------------------
+// The surrogate's native layout [BS,F,Nx,Ny,Nt] seen through permute(0,1,4,2,3) has Nt = 10..40 as its unit-stride
+// axis (Marginal/NS_Residuals_CP.py:282): a 256-column tile would keep a handful of lanes busy, and such views used
+// to fall to the one-thread-per-cell kernel (~0.7 TB/s).  Memory axes (A0, A1, A2) = (slowest, stride E2, unit):
+// A1 and A2 are merged into one row of L = E1*E2 cells.  A workgroup owns a chunk of 2048 (1024) merged cells of one A0
+// row (two quads per thread); for every A0 offset of the tap set it stages chunk + 128 cells of halo per side in LDS once, and a tap
+// (d0, d1, d2) reads the cell d1*E2 + d2 further along the merged row, masked where a1 + d1 or a2 + d2 leaves the
+// domain (= the zero padding of F.conv3d).  Needs L % 4 == 0 and max|d1|*E2 + max|d2| <= 128.
+constexpr int FT_H = 32;                       // halo quads per side
+constexpr int FT_P = 2;                        // quads per thread: the (scalar) tap decoding is paid once for both
+
+// FT_Q threads; a chunk is FT_P * FT_Q quads, thread t owns quads t, t + FT_Q, ...
+template <int FT_Q>
+__global__ void __launch_bounds__(FT_Q) flat_taps_kernel(const float *__restrict__ in, long long sB, long long s0,
+                                                        float *__restrict__ out, long long oB, long long o0, int B, int E0,
+                                                        int E1, int E2, int nchunks, int flags, const TapList taps)
+{
+    constexpr int CQ = FT_P * FT_Q;                               // quads per chunk
+    __shared__ float4 lds4[CQ + 2 * FT_H];
+    const float *lds = reinterpret_cast<const float *>(lds4);
+    // neighbouring A0 rows are nchunks blocks apart: keep them in one XCD's L2
+    const unsigned int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = blk % nchunks, r = blk / nchunks;
+    const int L = E1 * E2, m0 = chunk * (4 * CQ);
+    int m[FT_P];
+    // validity of my cells' neighbours, per offset: bit 4*(d+3) + j of v1 (v2) says that cell j of the quad stays
+    // inside the A1 (A2) extent when moved by d = -3..3
+    unsigned int v1[FT_P], v2[FT_P];
+#pragma unroll
+    for (int p = 0; p < FT_P; ++p) {
+        m[p] = m0 + 4 * ((int)threadIdx.x + p * FT_Q);
+        v1[p] = v2[p] = 0u;
+        int c1 = m[p] / E2, c2 = m[p] % E2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int d = -3; d <= 3; ++d) {
+                v1[p] |= ((unsigned)(c1 + d) < (unsigned)E1 ? 1u : 0u) << (4 * (d + 3) + j);
+                v2[p] |= ((unsigned)(c2 + d) < (unsigned)E2 ? 1u : 0u) << (4 * (d + 3) + j);
+            }
+            const bool wrap = c2 + 1 == E2;
+            c2 = wrap ? 0 : c2 + 1;
+            c1 += wrap ? 1 : 0;
+        }
+    }
+    for (int b = blockIdx.z; b < B; b += gridDim.z) {
+        float acc[FT_P][4] = {};
+        int staged = 99;                                          // d0 of the row now in LDS
+        for (int i = 0; i < taps.n; ++i) {                        // sorted by d0
+            const int of = taps.off[i];
+            const int d0 = (of & 15) - 8, d1 = ((of >> 4) & 15) - 8, d2 = ((of >> 8) & 15) - 8;
+            const int rr = r + d0;
+            if (rr < 0 || rr >= E0) continue;                     // the whole row is padding (block-uniform)
+            const float *row = in + b * sB + rr * s0;
+            const int dc = d1 * E2 + d2;
+            float e[FT_P][4];
+            if (of & (1 << 12)) {
+                // a row that carries one or two taps only (the x arms of a Taylor Laplacian): read the shifted quads
+                // straight from global memory (L2: it is the centre row of a neighbouring workgroup) instead of staging
+#pragma unroll
+                for (int p = 0; p < FT_P; ++p) {
+                    const int g = m[p] + dc;
+                    if (g >= 0 && g + 3 < L) {
+                        const G4u u = *reinterpret_cast<const G4u *>(row + g);
+                        e[p][0] = u.x; e[p][1] = u.y; e[p][2] = u.z; e[p][3] = u.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) e[p][j] = (g + j >= 0 && g + j < L) ? row[g + j] : 0.f;
+                    }
+                }
+            } else {
+                if (d0 != staged) {
+                    staged = d0;
+                    __syncthreads();                              // readers of the previous row are done
+                    for (int q = threadIdx.x; q < CQ + 2 * FT_H; q += FT_Q) {
+                        const int g = m0 - 4 * FT_H + 4 * q;      // L % 4 == 0: a quad is all inside or all outside
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (g >= 0 && g < L) {
+                            const G4u u = *reinterpret_cast<const G4u *>(row + g);
+                            v = make_float4(u.x, u.y, u.z, u.w);
+                        }
+                        lds4[q] = v;
+                    }
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int p = 0; p < FT_P; ++p) {
+                    const float *src = lds + 4 * FT_H + (m[p] - m0) + dc;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[p][j] = src[j];
+                }
+            }
+            const float w = taps.w[i];
+#pragma unroll
+            for (int p = 0; p < FT_P; ++p) {
+                const unsigned int ok = (v1[p] >> (4 * (d1 + 3))) & (v2[p] >> (4 * (d2 + 3)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[p][j] += (ok >> j) & 1u ? w * e[p][j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < FT_P; ++p)
+            if (m[p] < L) {
+                if (flags & PRE_FLAG_ABS)
+                    for (int j = 0; j < 4; ++j) acc[p][j] = fabsf(acc[p][j]);
+                *reinterpret_cast<G4u *>(out + b * oB + r * o0 + m[p]) = G4u{acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
+            }
     }
 }
 
@@ -308,6 +420,59 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *
                                (int)B, (int)D[p[0]], (int)D[p[1]], (int)D[p[2]], (int)nstrips, flags, rows);
             PRE_LAUNCH_CHECK();
             return PRE_OK;
+        }
+    }
+    // short unit-stride axis A2 (< 64 cells: the tile kernel above would idle) whose rows follow each other along
+    // another axis A1 (stride == extent of A2) in the input and in the output: flat form
+    if (!box[0] && !box[1] && !box[2] && ntaps > 0) {
+        for (int a2 = 2; a2 >= 0; --a2) {
+            if (si[a2] != 1 || so[a2] != 1 || D[a2] >= 64 || D[a2] < 2) continue;
+            for (int a1 = 2; a1 >= 0; --a1) {
+                if (a1 == a2 || si[a1] != D[a2] || so[a1] != D[a2] || D[a1] < 2) continue;
+                const int a0 = 3 - a1 - a2;
+                const long long L = D[a1] * D[a2];
+                int reach = 0, r1 = 0, r2 = 0;
+                for (int i = 0; i < ntaps; ++i) {
+                    const int d1 = tap_off[3 * i + a1], d2 = tap_off[3 * i + a2];
+                    r1 = (d1 < 0 ? -d1 : d1) > r1 ? (d1 < 0 ? -d1 : d1) : r1;
+                    r2 = (d2 < 0 ? -d2 : d2) > r2 ? (d2 < 0 ? -d2 : d2) : r2;
+                }
+                reach = r1 * (int)D[a2] + r2;
+                // chunks of 2048 cells (256 threads) unless 1024-cell ones (128 threads) waste fewer lanes on the last
+                // chunk of a row (Nt = 10, Ny = 256: 2560 cells = 1.25 big chunks or 2.5 small ones)
+                const long long q = L / 4;
+                const bool small = ((q + 128 * FT_P - 1) / (128 * FT_P)) * 128 < ((q + 256 * FT_P - 1) / (256 * FT_P)) * 256;
+                const int ftq = (small ? 128 : 256) * FT_P;
+                const long long nchunks = (q + ftq - 1) / ftq;
+                if (L % 4 != 0 || L > 0x7fffffffLL || reach > 4 * FT_H || nchunks * D[a0] > 0x7fffffffLL) continue;
+                TapList ft;                                        // taps on the memory axes, sorted by d0 (stable)
+                ft.n = 0;
+                for (int d0 = -3; d0 <= 3; ++d0) {
+                    int cnt = 0;
+                    for (int i = 0; i < ntaps; ++i) cnt += tap_off[3 * i + a0] == d0;
+                    const int direct = cnt <= 2 ? 1 << 12 : 0;    // rows with one or two taps are read without staging
+                    for (int i = 0; i < ntaps; ++i)
+                        if (tap_off[3 * i + a0] == d0) {
+                            ft.w[ft.n] = tap_w[i];
+                            ft.off[ft.n++] = (d0 + 8) | ((tap_off[3 * i + a1] + 8) << 4) | ((tap_off[3 * i + a2] + 8) << 8) | direct;
+                        }
+                }
+                // a block walks the batch axis with stride gridDim.z: enough blocks to fill the chip (~16 k), few enough
+                // that the per-thread set-up (validity masks) is paid once for many samples
+                long long gz = (16384 + nchunks * D[a0] - 1) / (nchunks * D[a0]);
+                gz = gz < 1 ? 1 : (gz > B ? B : gz);
+                const dim3 grid((unsigned)(nchunks * D[a0]), 1u, (unsigned)(gz < 65535 ? gz : 65535));
+                if (small)
+                    hipLaunchKernelGGL(flat_taps_kernel<128>, grid, dim3(128), 0, st, in->ptr, (long long)in->sB, (long long)si[a0],
+                                       out->ptr, (long long)out->sB, (long long)so[a0], (int)B, (int)D[a0], (int)D[a1],
+                                       (int)D[a2], (int)nchunks, flags, ft);
+                else
+                    hipLaunchKernelGGL(flat_taps_kernel<256>, grid, dim3(256), 0, st, in->ptr, (long long)in->sB, (long long)si[a0],
+                                       out->ptr, (long long)out->sB, (long long)so[a0], (int)B, (int)D[a0], (int)D[a1],
+                                       (int)D[a2], (int)nchunks, flags, ft);
+                PRE_LAUNCH_CHECK();
+                return PRE_OK;
+            }
         }
     }
     TapList taps;

@@ -162,6 +162,55 @@ def test_tiled_tap_list_kernel_vs_oracle(gpu):
     assert rel_err(xg.grad.cpu().numpy(), xc.grad.numpy()) <= 1e-4
 
 
+@pytest.mark.parametrize("nt", [10, 12, 20, 30, 40, 63])
+def test_flat_tap_list_kernel_short_nt_vs_oracle(gpu, nt):
+    """Tap sets off the 7-point star on the surrogate's native layout [BS,Nx,Ny,Nt] with a SHORT Nt (the reference's
+    T_out = 10..40) - the flat tap-list kernel: Taylor-4/6 Laplacians (Utils/ConvOps_2d.py:36-62), dense 3^3 / 5^3
+    kernels, the additive wave kernel with a Taylor-4 Laplacian (pad_kernel idiom), |.| epilogue, adjoint, and the
+    1-D operator on [BS,Nx,Nt] data; every boundary cell included (zero padding), against the C oracle."""
+    from cp_pre_amd import _dispatch
+    from cp_pre_amd.convops_1d import ConvOperator as C1
+    from cp_pre_amd.convops_2d import ConvOperator
+    from oracle.cstencil import xcorr_c
+    g = torch.Generator().manual_seed(100 + nt)
+    lap4 = ConvOperator(("x", "y"), 2, taylor_order=4).kernel
+    k5 = torch.zeros(5, 5, 5)
+    k5[1:4, 1:4, 1:4] = ConvOperator("t", 2).kernel
+    cases = [("t4", lap4), ("t6", ConvOperator(("x", "y"), 2, taylor_order=6).kernel), ("wave4", k5 - 0.25 * lap4),
+             ("d3", torch.randn(3, 3, 3, generator=g)), ("d5", torch.randn(5, 5, 5, generator=g))]
+    for (B, X, Y) in [(2, 9, 14), (1, 33, 6), (3, 4, 70)]:
+        if (Y * nt) % 4:
+            Y += 1 if ((Y + 1) * nt) % 4 == 0 else 2 if ((Y + 2) * nt) % 4 == 0 else 3
+        sur = torch.randn(B, X, Y, nt, generator=g)                       # [BS,Nx,Ny,Nt]
+        v = sur.permute(0, 3, 1, 2)                                       # the reference's [BS,Nt,Nx,Ny] view
+        for name, k in cases:
+            D = ConvOperator()
+            D.kernel = k
+            got = D(v.to(gpu))
+            assert got.stride() == v.stride(), name
+            want = xcorr_c(v.contiguous().numpy(), k.numpy())
+            assert rel_err(got.cpu().numpy(), want) <= RES_TOL, (name, nt, (B, X, Y))
+        got = _dispatch.xcorr(v.to(gpu), lap4, 3, flags=1)
+        assert rel_err(got.cpu().numpy(), np.abs(xcorr_c(v.contiguous().numpy(), lap4.numpy()))) <= RES_TOL
+    # adjoint (autograd through the flat kernel: flipped taps)
+    sur = torch.randn(2, 8, 10, nt, generator=g)
+    xg = sur.to(gpu).permute(0, 3, 1, 2).requires_grad_(True)
+    D = ConvOperator()
+    D.kernel = cases[4][1]
+    D(xg).square().sum().backward()
+    xc = sur.permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    torch.nn.functional.conv3d(xc[:, None], cases[4][1][None, None], padding=2).square().sum().backward()
+    assert rel_err(xg.grad.cpu().numpy(), xc.grad.numpy()) <= 1e-4
+    # 1-D: surrogate [BS,Nx,Nt] -> permute(0,2,1) (Joint/Burgers_Residuals_CP.py:217), dense and 5x5 kernels
+    s1 = torch.randn(5, 36, nt, generator=g)
+    u1 = s1.permute(0, 2, 1)
+    for k in (torch.randn(3, 3, generator=g), torch.randn(5, 5, generator=g)):
+        D1 = C1()
+        D1.kernel = k
+        got = D1(u1.to(gpu))
+        assert rel_err(got.cpu().numpy(), xcorr_c(u1.contiguous().numpy(), k.numpy())) <= RES_TOL
+
+
 def test_vector_ops_vs_oracle(gpu):
     from cp_pre_amd import vector_convops as V
     from oracle import convops as ocv

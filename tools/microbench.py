@@ -76,7 +76,13 @@ def bench_generic():
     dense.kernel = torch.randn(3, 3, 3)
     report("dense 3^3 kernel (27 taps) 8B/cell", timeit(lambda: dense(x)), 8 * x.numel())
     xt = torch.randn(256, 512, 512, 10, device=dev).permute(0, 3, 1, 2)
-    report("taylor-4 laplacian on an Nt-fastest view 8B/cell", timeit(lambda: D4(xt)), 8 * xt.numel())
+    report("taylor-4 laplacian on an Nt-fastest view [256,10,512,512] 8B/cell", timeit(lambda: D4(xt)), 8 * xt.numel())
+    for nt in (10, 20, 40):
+        xs = torch.randn(256 * 40 // nt, 256, 256, nt, device=dev).permute(0, 3, 1, 2)
+        report(f"taylor-4 laplacian, Nt-fastest [{xs.shape[0]},{nt},256,256] 8B/cell", timeit(lambda: D4(xs)), 8 * xs.numel())
+        report(f"taylor-6 laplacian, Nt-fastest [{xs.shape[0]},{nt},256,256] 8B/cell", timeit(lambda: D6(xs)), 8 * xs.numel())
+        report(f"wave + taylor-4 (12 taps), Nt-fastest 8B/cell", timeit(lambda: W(xs)), 8 * xs.numel())
+        del xs
     xo = torch.randn(256, 10, 201, 201, device=dev)
     report("taylor-4 laplacian, odd width [256,10,201,201] 8B/cell", timeit(lambda: D4(xo)), 8 * xo.numel())
 
