@@ -163,19 +163,21 @@ int pre_std_from_moments_f32(const double *sum, const double *sumsq, int64_t n_t
  * UNCROPPED, mod: [T,X,Y]; only cells with crop <= index < extent-crop on each of the last
  * three axes take part (crop_t/x/y = 1 reproduces the reference's [...,1:-1,1:-1,1:-1]).
  * scores[n] must be zero-filled by the caller; the kernel max-accumulates into it, so
- * per-slab calls over a split T axis compose. */
+ * per-slab calls over a split T axis compose.  NaN propagates like np.max: a NaN residual or modulation,
+ * or 0/0, makes the sample's score NaN (sticky across calls); x/0 with x != 0 gives inf. */
 int pre_joint_score_f32(const float *a, const float *b, const float *mod,
                         int64_t n, int64_t T, int64_t X, int64_t Y,
                         int crop_t, int crop_x, int crop_y, float *scores, void *stream);
 
 /* ---- a11: calibrate(scores, n, alpha) ---------------------------------------------------
  * (Neural_PDE.UQ.inductive_cp, absent; call sites Marginal/Wave_Residuals_CP.py:288,
- * Joint/Burgers_Residuals_CP.py:283).  Exact order statistics by MSD radix select on the
+ * Joint/Burgers_Residuals_CP.py:283).  Exact order statistics by bucket / MSD radix select on the
  * order-preserving uint32 image of fp32; result is bit-for-bit an input value.
  * ks: host array of 0-based sorted ranks (the caller derives them from alpha).
- * pre_kth_f32:       scores[N]            -> out[nk]
+ * pre_kth_f32:       scores[N]            -> out[nk]; any NaN score makes every result NaN (np.quantile)
  * pre_kth_axis0_f32: scores[n, M] contiguous -> out[nk, M]   (per-cell over the batch axis),
- *                    n < 65536, ks ascending, nk <= 64. */
+ *                    n < 2^31 (32-bit counters from n = 65536 on), ks ascending, nk <= 64; a NaN score
+ *                    orders by its key (positive NaN above +inf, negative NaN below -inf). */
 int pre_kth_f32(const float *scores, int64_t N, const int64_t *ks /*host*/, int nk, float *out, void *stream);
 int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks /*host*/, int nk,
                       float *out, void *stream);
