@@ -124,7 +124,7 @@ for tag, srcs, mode in (("pmc_sq_c3.txt", ("sq1", "sq2"), "joint"), ("pmc_sq_c3_
     with open(f"{out}/{tag}", "w") as o:
         o.write(f"rocprofv3 --pmc <counters, one group per pass> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --batch 1024"
                 f"{' --mode marginal' if mode == 'marginal' else ''}\n"
-                f"(C3 {mode}, quarter batch: [1024,10,512,512] per launch; per-dispatch sums over all SEs/XCDs, averaged over dispatches;\n"
+                f"(C3 {mode}, quarter batch: [1024,S+2,512,512] per launch, S = 13/12; per-dispatch sums over all SEs/XCDs, averaged over dispatches;\n"
                 f" FETCH_SIZE in KiB, x2 for bytes on gfx950)\n\n")
         kernels = sorted({k for (_, k) in sq if k.startswith(OURS)})
         for k in kernels:
