@@ -128,10 +128,15 @@ __device__ __forceinline__ void js_update(float av, float sv, float &m, float &t
 
 __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                           const float *__restrict__ mod, int T, int X, int Y,
-                                                          int ct, int cx, int cy, int groups, float *__restrict__ scores)
+                                                          int ct, int cx, int cy, int groups, int smp_fastest,
+                                                          float *__restrict__ scores)
 {
     const long long plane = (long long)X * Y, vol = plane * T;
-    const int smp = blockIdx.y;
+    // smp_fastest: consecutive workgroups take the SAME rows of consecutive samples, so the modulation rows they
+    // share stay in L2 (chunk-fastest order swept the whole modulation, 14 MB for a C3 slab, once per sample).
+    // (Tried on top and dropped: four load pairs in flight per thread - 74 VGPRs, 15 % slower.)
+    const int smp = smp_fastest ? blockIdx.x : blockIdx.y;
+    const unsigned int cblk = smp_fastest ? blockIdx.y : blockIdx.x;
     const float *pa = a + smp * vol, *pb = b ? b + smp * vol : nullptr;
     const long long nrows = (long long)T * X;
     const bool vec = (Y % 4 == 0) && !(((uintptr_t)a | (uintptr_t)mod | (uintptr_t)(b ? b : a)) & 15);
@@ -142,7 +147,7 @@ __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restric
     // `groups` spans of JS_RB rows per block (short rows - e.g. the surrogate's Nt = 10 cells - would otherwise
     // leave a block with a few hundred cells and one atomic each)
     for (int gi = 0; gi < groups; ++gi) {
-    const long long r0 = ((long long)blockIdx.x * groups + gi) * JS_RB;
+    const long long r0 = ((long long)cblk * groups + gi) * JS_RB;
     if (r0 >= nrows) break;
     __syncthreads();             // the previous span's rowmask has been read by everyone
     if (threadIdx.x < 64) {      // which of this span's rows survive the (t, x) crop
@@ -380,9 +385,10 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod, int64_
     for (int64_t s0 = 0; s0 < n; s0 += 65535) {
         const int64_t ns = (n - s0) < 65535 ? (n - s0) : 65535;
         const long long vol = (long long)T * X * Y;
-        hipLaunchKernelGGL(joint_score_kernel, dim3((unsigned)chunks, (unsigned)ns), dim3(256), 0, as_stream(stream),
-                           a + s0 * vol, b ? b + s0 * vol : nullptr, mod, (int)T, (int)X, (int)Y, crop_t, crop_x, crop_y,
-                           (int)groups, scores + s0);
+        const int swap = chunks <= 65535;
+        hipLaunchKernelGGL(joint_score_kernel, swap ? dim3((unsigned)ns, (unsigned)chunks) : dim3((unsigned)chunks, (unsigned)ns),
+                           dim3(256), 0, as_stream(stream), a + s0 * vol, b ? b + s0 * vol : nullptr, mod, (int)T, (int)X, (int)Y,
+                           crop_t, crop_x, crop_y, (int)groups, swap, scores + s0);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
