@@ -451,7 +451,10 @@ def main():
             "config": {"workload": f"C3 2D Navier-Stokes momentum residual [{B},{args.nt},{X},{Y}] x3 fields per rank, "
                                    f"{args.mode} CP, 10 alpha levels; streamed as {n_slabs} t-slabs of {slabs} interior "
                                    f"planes (+2 halo planes each)",
-                       "mode": args.mode, "batch_per_rank": B, **par},
+                       "mode": args.mode, "batch_per_rank": B, **par,
+                       # `value` is measured with the fields resident in HBM (contract); if the 3 fields came from host
+                       # memory instead, PCIe Gen5 x16 (63 GB/s spec) would bound the job at 63e9 / 12 B per cell
+                       "inputs": "resident in HBM", "host_fed_bound_cells_per_s": 63e9 / 12.0},
             "roofline": {"bound": "hbm", "kernel": "march_kernel<NSMomentum<0>,8,64>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,

@@ -239,8 +239,10 @@ __device__ __forceinline__ int ka_window(const float *__restrict__ col, bool cok
     // sf a hair under (NB1-1)/(vhi - vlo), so that the window's top value stays below NB1
     vlo = key2f(kmin);
     const float r = key2f(kmax) - vlo;
-    sf = r > 0.f ? ((float)((1 << LOG_NB1) - 1) / r) * 0.999999f : 0.f;       // r == 0: one value sampled, row 1 takes all
-    if (!(r >= 0.f) || !(r < __builtin_inff()) || !(fabsf(vlo) < __builtin_inff())) sf = -1.f;
+    sf = ((float)((1 << LOG_NB1) - 1) / r) * 0.999999f;
+    // no fast form for this cell when the window is empty (one value sampled: sf = inf, and with sf = 0 an infinite
+    // score would turn into 0 * inf = NaN and be filed BELOW the window), not finite, or so narrow that sf overflows
+    if (!(r > 0.f) || !(r < __builtin_inff()) || !(fabsf(vlo) < __builtin_inff()) || !(sf < __builtin_inff())) sf = -1.f;
     if (!cok) { sf = 0.f; vlo = 0.f; }
     return s;
 }

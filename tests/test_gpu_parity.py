@@ -442,6 +442,14 @@ def test_marginal_qhat_window_and_fallback_paths(gpu, n):
     s[n // 2:, 90:95] = -3.0                                            # two values only
     s[::3, 95:100] = 0.0
     s[1::3, 95:100] = -0.0
+    # a constant sample (every sampled row equal) hiding infinities / a tiny spread between the sampled rows
+    s[:, 100:104] = 2.0
+    s[:, 104:108] = 2.0
+    if off.any():
+        idx = torch.nonzero(off)[:, 0]
+        s[idx[: max(1, len(idx) // 3)], 100:102] = float("inf")
+        s[idx[-max(1, len(idx) // 3):], 102:104] = float("-inf")
+        s[idx, 104:108] = 2.0 + 1e-6 * torch.randn(len(idx), 4, device=gpu, generator=g)
     ks = sorted({icp.kth_index(n, n, float(a)) for a in icp.ALPHA_LEVELS if icp.quantile_level(n, float(a)) <= 1}
                 | {0, 1, n // 2, n - 2, n - 1})
     for group in (ks[:10], ks[-10:]):
