@@ -276,6 +276,46 @@ __global__ void __launch_bounds__(256) cov_count_kernel(const float *__restrict_
     if (threadIdx.x == 0) atomicAdd(count, (unsigned long long)(red[0] + red[1] + red[2] + red[3]));
 }
 
+// Vector form for M % 4 == 0 and 16-byte aligned rows: grid (quad-column chunks, sample groups).  A thread owns ONE
+// column of 4 cells: its bounds are loaded once (per-cell bounds) and its samples stream by as float4, eight loads in
+// flight - against one scalar load and a 64-bit `i % M` per element above (2.0-2.2 TB/s at the reference's sizes).
+__global__ void __launch_bounds__(256) cov_count4_kernel(const float4 *__restrict__ y, const float4 *__restrict__ lo,
+                                                         const float4 *__restrict__ hi, int n, long long M4, int per_sample,
+                                                         int rows_per, unsigned long long *count)
+{
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int local = 0;
+    if (q < M4) {
+        const int s0 = blockIdx.y * rows_per, s1 = min(n, s0 + rows_per);
+        float4 l = lo[q], h = hi[q];
+        auto inside = [&](const float4 &v, const float4 &a, const float4 &b) __attribute__((always_inline)) {
+            return (unsigned)((v.x >= a.x) && (v.x <= b.x)) + (unsigned)((v.y >= a.y) && (v.y <= b.y)) +
+                   (unsigned)((v.z >= a.z) && (v.z <= b.z)) + (unsigned)((v.w >= a.w) && (v.w <= b.w));
+        };
+        int s = s0;
+        if (!per_sample) {
+            for (; s + 7 < s1; s += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = y[(long long)(s + u) * M4 + q];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) local += inside(v[u], l, h);
+            }
+        }
+        for (; s < s1; ++s) {
+            const long long o = (long long)s * M4 + q;
+            if (per_sample) { l = lo[o]; h = hi[o]; }
+            local += inside(y[o], l, h);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    __shared__ unsigned int red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0 && (red[0] | red[1] | red[2] | red[3])) atomicAdd(count, (unsigned long long)(red[0] + red[1] + red[2] + red[3]));
+}
+
 // grid (chunks, n): clear inside[i] if any cell of sample i leaves [lo, hi]
 __global__ void __launch_bounds__(256) cov_joint_kernel(const float *__restrict__ y, const float *__restrict__ lo,
                                                         const float *__restrict__ hi, long long M, int per_sample,
@@ -285,9 +325,19 @@ __global__ void __launch_bounds__(256) cov_joint_kernel(const float *__restrict_
     const float *py = y + smp * M;
     const float *plo = lo + (per_sample ? smp * M : 0), *phi = hi + (per_sample ? smp * M : 0);
     bool bad = false;
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < M; c += (long long)gridDim.x * blockDim.x) {
-        const float v = py[c];
-        bad |= !((v >= plo[c]) && (v <= phi[c]));
+    if (M % 4 == 0 && !(((uintptr_t)y | (uintptr_t)lo | (uintptr_t)hi) & 15)) {      // rows of whole, aligned quads
+        const float4 *y4 = reinterpret_cast<const float4 *>(py), *l4 = reinterpret_cast<const float4 *>(plo),
+                     *h4 = reinterpret_cast<const float4 *>(phi);
+        for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < M / 4; q += (long long)gridDim.x * blockDim.x) {
+            const float4 v = y4[q], a = l4[q], b = h4[q];
+            bad |= !((v.x >= a.x) && (v.x <= b.x) && (v.y >= a.y) && (v.y <= b.y) && (v.z >= a.z) && (v.z <= b.z) &&
+                     (v.w >= a.w) && (v.w <= b.w));
+        }
+    } else {
+        for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < M; c += (long long)gridDim.x * blockDim.x) {
+            const float v = py[c];
+            bad |= !((v >= plo[c]) && (v <= phi[c]));
+        }
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) inside[smp] = 0;
 }
@@ -302,9 +352,19 @@ __global__ void __launch_bounds__(256) cov_rowcount_kernel(const float *__restri
     const float *py = y + smp * M;
     const float *plo = lo + (per_sample ? smp * M : 0), *phi = hi + (per_sample ? smp * M : 0);
     unsigned int local = 0;
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < M; c += (long long)gridDim.x * blockDim.x) {
-        const float v = py[c];
-        local += outside ? ((v <= plo[c]) || (v >= phi[c])) : ((v >= plo[c]) && (v <= phi[c]));
+    auto hit = [&](float v, float a, float b) __attribute__((always_inline)) {
+        return (unsigned)(outside ? ((v <= a) || (v >= b)) : ((v >= a) && (v <= b)));
+    };
+    if (M % 4 == 0 && !(((uintptr_t)y | (uintptr_t)lo | (uintptr_t)hi) & 15)) {      // rows of whole, aligned quads
+        const float4 *y4 = reinterpret_cast<const float4 *>(py), *l4 = reinterpret_cast<const float4 *>(plo),
+                     *h4 = reinterpret_cast<const float4 *>(phi);
+        for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < M / 4; q += (long long)gridDim.x * blockDim.x) {
+            const float4 v = y4[q], a = l4[q], b = h4[q];
+            local += hit(v.x, a.x, b.x) + hit(v.y, a.y, b.y) + hit(v.z, a.z, b.z) + hit(v.w, a.w, b.w);
+        }
+    } else {
+        for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < M; c += (long long)gridDim.x * blockDim.x)
+            local += hit(py[c], plo[c], phi[c]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
@@ -413,6 +473,21 @@ int pre_cov_count_f32(const float *y, const float *lo, const float *hi, int64_t 
                       unsigned long long *count, void *stream)
 {
     if (!y || !lo || !hi || !count || n <= 0 || M <= 0) return PRE_E_NULL;
+    if (M % 4 == 0 && !(((uintptr_t)y | (uintptr_t)lo | (uintptr_t)hi) & 15) && n <= 0x7fffffff) {
+        const long long M4 = M / 4, bx = (M4 + 255) / 256;
+        // sample groups: enough workgroups to fill the chip (~4 k), rows in multiples of 8 (the unrolled trip)
+        long long groups = (4096 + bx - 1) / bx;
+        long long rows_per = (n + groups - 1) / groups;
+        rows_per = (rows_per + 7) / 8 * 8;
+        groups = (n + rows_per - 1) / rows_per;
+        if (bx <= 0x7fffffffLL && groups <= 65535) {
+            hipLaunchKernelGGL(cov_count4_kernel, dim3((unsigned)bx, (unsigned)groups), dim3(256), 0, as_stream(stream),
+                               reinterpret_cast<const float4 *>(y), reinterpret_cast<const float4 *>(lo),
+                               reinterpret_cast<const float4 *>(hi), (int)n, M4, per_sample_bounds, (int)rows_per, count);
+            PRE_LAUNCH_CHECK();
+            return PRE_OK;
+        }
+    }
     hipLaunchKernelGGL(cov_count_kernel, dim3(grid_for(n * M, 256)), dim3(256), 0, as_stream(stream), y, lo, hi,
                        (long long)(n * M), (long long)M, per_sample_bounds, count);
     PRE_LAUNCH_CHECK();

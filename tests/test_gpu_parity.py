@@ -675,6 +675,14 @@ def test_calibration_edge_cases(gpu):
     assert icp.emp_cov([y - 0.5, y + q], y * 1.2) == pytest.approx(oc.emp_cov([y - 0.5, y + q], y * 1.2), abs=1e-12)
     assert icp.emp_cov_joint([-3 * q, 3 * q], y) == pytest.approx(oc.emp_cov_joint([-3 * q, 3 * q], y), abs=1e-12)
     assert icp.emp_cov([np.float32(-1.0), np.float32(1.0)], y) == pytest.approx(oc.emp_cov([-1.0, 1.0], y), abs=1e-12)
+    # cell counts that are multiples of 4 take the float4 kernel: ragged sample counts, both kinds of bounds, a big case
+    for n_, cells in ((1, (4,)), (53, (8, 12)), (200, (3, 20, 52)), (1000, (30, 64, 64))):
+        yv = rng.standard_normal((n_,) + cells).astype(np.float32)
+        qv = np.abs(rng.standard_normal(cells)).astype(np.float32)
+        yv[0].flat[0] = qv.flat[0]                                    # exactly on the bound: inside
+        assert icp.emp_cov([-qv, qv], yv) == pytest.approx(oc.emp_cov([-qv, qv], yv), abs=1e-12)
+        if n_ <= 200:
+            assert icp.emp_cov([yv - 0.5, yv + qv], yv * 1.2) == pytest.approx(oc.emp_cov([yv - 0.5, yv + qv], yv * 1.2), abs=1e-12)
 
 
 # ---------------------------------------------------------------- autograd
