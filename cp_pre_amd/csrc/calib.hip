@@ -214,6 +214,61 @@ __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restric
     }
 }
 
+// Flat form for a SHORT innermost axis (the surrogate's memory order [n, Nx, Ny, Nt], Nt = 10..40: rows of 10 cells
+// kept 10 of a wave's 64 lanes busy on the row walk above, 1.5 TB/s).  A block takes JSF_CELLS consecutive cells of one
+// sample as quads, whatever the row length; the (t, x, y) position of a quad's first cell is one division per quad
+// and the crop test walks the four cells from there.  vol % 4 == 0 and 16-byte aligned pointers.
+constexpr int JSF_CELLS = 8192;
+__global__ void __launch_bounds__(256) joint_score_flat_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                               const float *__restrict__ mod, int T, int X, int Y, int ct,
+                                                               int cx, int cy, float *__restrict__ scores)
+{
+    const long long vol = (long long)T * X * Y;
+    const int smp = blockIdx.x;
+    const float4 *pa = reinterpret_cast<const float4 *>(a + smp * vol);
+    const float4 *pb = b ? reinterpret_cast<const float4 *>(b + smp * vol) : nullptr;
+    const float4 *pm = reinterpret_cast<const float4 *>(mod);
+    const unsigned int c0 = blockIdx.y * (unsigned)JSF_CELLS;     // vol < 2^31 (host check): 32-bit cell indices
+    __shared__ float red[4];
+    float m = 0.f, thr = 0.f;
+    bool nan = false;
+    // position of my first quad (one 32-bit division pair per thread), then 1024 cells further per trip
+    unsigned int f = c0 + 4u * threadIdx.x;
+    const unsigned int row0 = f / (unsigned)Y;
+    int y0 = (int)(f - row0 * (unsigned)Y), x0 = (int)(row0 % (unsigned)X), t0 = (int)(row0 / (unsigned)X);
+    const int dy = 1024 % Y, drow = 1024 / Y, dx = drow % X, dt = drow / X;
+    for (int k = 0; k < JSF_CELLS / 1024 && f < (unsigned)vol; ++k, f += 1024u) {
+        float4 v = pa[f >> 2];
+        if (pb) { const float4 w = pb[f >> 2]; v = make_float4(v.x - w.x, v.y - w.y, v.z - w.z, v.w - w.w); }
+        const float4 sg = pm[f >> 2];
+        const float av[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+        const float sv[4] = {sg.x, sg.y, sg.z, sg.w};
+        int y = y0, x = x0, t = t0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = t >= ct && t < T - ct && x >= cx && x < X - cx && y >= cy && y < Y - cy;
+            if (in) js_update(av[j], sv[j], m, thr, nan);
+            if (++y == Y) { y = 0; if (++x == X) { x = 0; ++t; } }
+        }
+        y0 += dy;
+        const int carry = y0 >= Y;
+        y0 -= carry ? Y : 0;
+        x0 += dx + carry;                                         // < 2X
+        const int cx2 = x0 >= X;
+        x0 -= cx2 ? X : 0;
+        t0 += dt + cx2;
+    }
+    m = wave_max(m);
+    if (__ballot(nan)) m = __uint_as_float(0x7fc00000u);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int u = max(max(__float_as_uint(red[0]), __float_as_uint(red[1])),
+                                   max(__float_as_uint(red[2]), __float_as_uint(red[3])));
+        if (u) atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, u);
+    }
+}
+
 // ------------------------------------------------------------------ scalar k-th (radix select)
 struct KList { int nk; long long k[16]; };
 
@@ -435,6 +490,17 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod, int64_
     if (!a || !mod || !scores || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
     if (crop_t < 0 || crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
     if (n > 65535 * 1024LL || T * X > 0x7fffffffLL * JS_RB || Y > 0x7fffffff) return PRE_E_SHAPE;
+    {
+        // short rows: flat form (sample-fastest block order, like the row form)
+        const long long vol = (long long)T * X * Y, nblk = (vol + JSF_CELLS - 1) / JSF_CELLS;
+        if (Y < 64 && vol % 4 == 0 && vol < 0x7fffffffLL && nblk <= 65535 && n <= 0x7fffffff &&
+            !(((uintptr_t)a | (uintptr_t)mod | (uintptr_t)(b ? b : a)) & 15)) {
+            hipLaunchKernelGGL(joint_score_flat_kernel, dim3((unsigned)n, (unsigned)nblk), dim3(256), 0, as_stream(stream), a, b, mod,
+                               (int)T, (int)X, (int)Y, crop_t, crop_x, crop_y, scores);
+            PRE_LAUNCH_CHECK();
+            return PRE_OK;
+        }
+    }
     // spans of JS_RB rows; a block takes as many as give it >= ~8 k cells (but leaves >= ~2 k blocks when possible)
     const long long spans = (T * X + JS_RB - 1) / JS_RB;
     long long groups = 8192 / (JS_RB * Y);
