@@ -229,3 +229,76 @@ def test_fuzz_spatial_family_mixed_boundaries(gpu):
         want = ref(a, b) if kind != "laplace" else ref(a)
         assert tuple(got.shape) == tuple(want.shape), (case, kind)
         assert rel_err(got.cpu().numpy(), want.numpy()) <= RES_TOL, (case, kind, sides, (B, X, Y))
+
+
+def test_fuzz_round2_select_paths(gpu):
+    """The per-cell select of round 2 (register sort for n <= 128, sampled value-linear first digit, general
+    radix form, 32-bit counters): random n, cell counts, distributions and ranks against torch.sort."""
+    from cp_pre_amd import inductive_cp as icp
+    rng = np.random.default_rng(2024)
+    g = torch.Generator(device=gpu).manual_seed(2024)
+    for case in range(max(16, CASES // 2)):
+        n = int(rng.choice([1, 2, 5, 63, 64, 65, 100, 127, 128, 129, 300, 777, 2047, 2048, 2049, 3000, 6144, 6145, 9001]))
+        M = int(rng.choice([1, 3, 63, 64, 65, 200, 1000]))
+        kind = str(rng.choice(["abs", "signed", "log", "ties", "sorted", "spike", "tiny", "const"]))
+        s = torch.randn(n, M, device=gpu, generator=g)
+        if kind == "abs":
+            s = s.abs() * (0.1 + 10 * torch.rand(M, device=gpu, generator=g))
+        elif kind == "log":
+            s = torch.exp(s * float(rng.choice([1.0, 8.0, 30.0])))
+        elif kind == "ties":
+            s = torch.round(s * float(rng.choice([1.0, 4.0]))) / 4
+        elif kind == "sorted":
+            s = torch.sort(s, dim=0, descending=bool(rng.integers(0, 2))).values
+        elif kind == "spike":
+            s = s.abs()
+            s[torch.rand(n, M, device=gpu, generator=g) < 0.02] *= 1e8
+        elif kind == "tiny":
+            s = 1.0 + 1e-6 * s                                            # spread far below the magnitude
+        elif kind == "const":
+            s = torch.full_like(s, -7.5)
+        nk = int(rng.integers(1, 11))
+        ks = sorted(int(k) for k in rng.integers(0, n, size=nk))
+        if rng.random() < 0.3:
+            ks = sorted(set(ks) | {0, n - 1})
+        got = icp.kth_axis0(s, ks)
+        ref = torch.sort(s, dim=0).values[ks]
+        assert torch.equal(got, ref), (case, n, M, kind, ks)
+
+
+def test_fuzz_round2_flat_tap_list_and_joint_score(gpu):
+    """Random tap sets on random SHORT-Nt surrogate layouts (flat tap-list kernel; 3-D and 1-D operators), and the
+    cropped joint score on the same memory order (flat quad walk), against the C / numpy oracles."""
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd.convops_1d import ConvOperator as C1
+    from cp_pre_amd.convops_2d import ConvOperator as C2
+    rng = np.random.default_rng(77)
+    gen = torch.Generator().manual_seed(77)
+    for case in range(max(12, CASES // 3)):
+        nt = int(rng.choice([2, 3, 5, 10, 12, 20, 31, 40, 63]))
+        B, X = int(rng.integers(1, 4)), int(rng.integers(1, 20))
+        Y = int(rng.choice([1, 2, 4, 7, 16, 30, 64]))
+        sur = torch.randn(B, X, Y, nt, generator=gen)                     # [BS,Nx,Ny,Nt]
+        v = sur.permute(0, 3, 1, 2)
+        k = _random_kernel(rng, gen, 3)
+        if all(s % 2 == 1 for s in k.shape):
+            D = C2()
+            D.kernel = k
+            got = D(v.to(gpu))
+            assert rel_err(got.cpu().numpy(), xcorr_c(v.contiguous().numpy(), k.numpy())) <= RES_TOL, (case, "3d", v.shape, k.shape)
+        s1 = torch.randn(B + 2, X + 3, nt, generator=gen)                 # [BS,Nx,Nt] -> [BS,Nt,Nx]
+        u1 = s1.permute(0, 2, 1)
+        k2 = _random_kernel(rng, gen, 2)
+        D1 = C1()
+        D1.kernel = k2
+        got = D1(u1.to(gpu))
+        assert rel_err(got.cpu().numpy(), xcorr_c(u1.contiguous().numpy(), k2.numpy())) <= RES_TOL, (case, "1d", u1.shape, k2.shape)
+        # joint score with a crop on the surrogate memory order
+        n = int(rng.integers(2, 30))
+        res = torch.randn(n, X + 2, Y + 2, nt + 2, generator=gen).permute(0, 3, 1, 2)          # logical [n,T,X,Y], T fastest
+        rn = res.contiguous().numpy()
+        inner = rn[:, 1:-1, 1:-1, 1:-1]
+        mod_full = np.abs(np.random.default_rng(case).standard_normal(rn.shape[1:])).astype(np.float32) + 0.1
+        want = oc.ncf_metric_joint(inner, np.zeros_like(inner), mod_full[1:-1, 1:-1, 1:-1])
+        got = icp.ncf_metric_joint(res.to(gpu), None, torch.from_numpy(mod_full).to(gpu), crop=1)
+        assert np.array_equal(got.cpu().numpy(), want), (case, "joint score", rn.shape)
