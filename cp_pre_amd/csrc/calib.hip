@@ -48,14 +48,14 @@ __global__ void __launch_bounds__(256) std_axis0_kernel(const float *__restrict_
     if (c >= M) return;
     const float *pa = a + c, *pb = b ? b + c : nullptr;
     float s = 0.f;
-#pragma unroll 8
+#pragma unroll 16
     for (int i = 0; i < n; ++i) {
         const float v = pb ? pa[(long long)i * M] - pb[(long long)i * M] : pa[(long long)i * M];
         s = s + v;
     }
     const float mean = s / (float)n;
     float acc = 0.f;
-#pragma unroll 8
+#pragma unroll 16
     for (int i = 0; i < n; ++i) {
         const float v = pb ? pa[(long long)i * M] - pb[(long long)i * M] : pa[(long long)i * M];
         const float d = v - mean;
@@ -450,7 +450,10 @@ int pre_std_axis0_f32(const float *a, const float *b, int64_t n, int64_t M, floa
 {
     if (!a || !mod || n <= 0 || M <= 0) return PRE_E_NULL;
     if (n > 0x7fffffff || M > 0xffffff00LL) return PRE_E_SHAPE;        // one thread per cell, 32-bit work-item count
-    hipLaunchKernelGGL(std_axis0_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), a, b, (int)n,
+    // one thread per cell (the sums are sequential, numpy's order): few cells -> one wave per workgroup, so that the
+    // waves spread over all CUs (C5's 102 400 cells are 400 workgroups of 256 threads: 1.6 per CU)
+    const int bs = M >= (1 << 19) ? 256 : 64;
+    hipLaunchKernelGGL(std_axis0_kernel, dim3((unsigned)((M + bs - 1) / bs)), dim3(bs), 0, as_stream(stream), a, b, (int)n,
                        (long long)M, eps, mod);
     PRE_LAUNCH_CHECK();
     return PRE_OK;

@@ -547,6 +547,11 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
             if ((Ty & 3) == 0) {                     // wave-uniform: the x neighbours are whole quads
                 n[i].xm = lds[bi][i][FLAT_H + q - (Ty >> 2)];
                 n[i].xp = lds[bi][i][FLAT_H + q + (Ty >> 2)];
+            } else if ((Ty & 1) == 0) {              // Ty = 10, 30, 50 (T_out of the reference scripts): 8-byte aligned pairs
+                const float2 a = *reinterpret_cast<const float2 *>(row - Ty), b = *reinterpret_cast<const float2 *>(row + 2 - Ty);
+                const float2 c = *reinterpret_cast<const float2 *>(row + Ty), d = *reinterpret_cast<const float2 *>(row + 2 + Ty);
+                n[i].xm = make_float4(a.x, a.y, b.x, b.y);
+                n[i].xp = make_float4(c.x, c.y, d.x, d.y);
             } else {
                 n[i].xm = make_float4(row[-Ty], row[1 - Ty], row[2 - Ty], row[3 - Ty]);
                 n[i].xp = make_float4(row[Ty], row[Ty + 1], row[Ty + 2], row[Ty + 3]);
