@@ -477,7 +477,10 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
     const int ts = Lb % g.nTSeg;
     const int b = Lb / g.nTSeg;
     const int Ty = g.Y, L = g.X * g.Y;
-    const int m0 = ch * FLAT_NT * 4, m = m0 + 4 * q;
+    // threads per chunk: 512, or fewer when that wastes fewer lanes on the last chunk of a row (chosen by the host;
+    // the LDS image is sized for 512 either way)
+    const int NT = blockDim.x;
+    const int m0 = ch * NT * 4, m = m0 + 4 * q;
     const bool inb = m < L;
     int t0 = ts * g.tSeg, t1 = min(t0 + g.tSeg, g.T);
     if (g.flags & PRE_FLAG_INTERIOR_T) {       // the caller crops the t rim: neither compute nor store it
@@ -487,10 +490,10 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
 
     // halo duty: the first / last FLAT_H threads fetch one quad left / right of the chunk (L % 4 == 0: a quad is
     // entirely inside the row or entirely padding)
-    const bool hl = q < FLAT_H, hr = q >= FLAT_NT - FLAT_H;
-    const int hm = hl ? m0 - 4 * FLAT_H + 4 * q : m0 + 4 * FLAT_NT + 4 * (q - (FLAT_NT - FLAT_H));
+    const bool hl = q < FLAT_H, hr = q >= NT - FLAT_H;
+    const int hm = hl ? m0 - 4 * FLAT_H + 4 * q : m0 + 4 * NT + 4 * (q - (NT - FLAT_H));
     const bool hok = (hl || hr) && hm >= 0 && hm < L;
-    const int hslot = hl ? q : q + 2 * FLAT_H;      // right halo quad k sits at FLAT_H + FLAT_NT + k, k = q - (FLAT_NT - FLAT_H)
+    const int hslot = hl ? q : q + 2 * FLAT_H;      // right halo quad k sits at FLAT_H + NT + k, k = q - (NT - FLAT_H)
 
     // which of my four cells have a y- / y+ neighbour inside their own x row
     bool lok[4], rok[4];
@@ -586,15 +589,22 @@ int launch_flat(Geom &g, const typename Fn::Params &prm, hipStream_t st)
 {
     static_assert(2 * Fn::F * (FLAT_NT + 2 * FLAT_H) * 16 <= 160 * 1024, "chunk does not fit the 160 KiB LDS");
     g.nXT = 1;
-    g.nYT = (int)(((long long)g.X * g.Y / 4 + FLAT_NT - 1) / FLAT_NT);
+    // chunk = 512 quads, or 448 / 384 / 320 / 256 when that leaves fewer idle lanes in the row's last chunk (the
+    // surrogate's Nt = 10 on a 256-wide grid is a row of 640 quads: two chunks of 320 instead of 512 + 128)
+    const long long quads = (long long)g.X * g.Y / 4;
+    // cost of a row = chunks x (quads + 64 halo quads staged per chunk); ties go to the wider chunk
+    int nt = FLAT_NT;
+    for (int c = FLAT_NT - 64; c >= 256; c -= 64)
+        if ((quads + c - 1) / c * (c + 2 * FLAT_H) < (quads + nt - 1) / nt * (nt + 2 * FLAT_H)) nt = c;
+    g.nYT = (int)((quads + nt - 1) / nt);
     long long tiles = (long long)g.B * g.nYT;
     int tSeg = g.T;
     while (tiles * ((g.T + tSeg - 1) / tSeg) < 2048 && tSeg > 16) tSeg = (tSeg + 1) / 2;
     g.tSeg = tSeg;
     g.nTSeg = (g.T + tSeg - 1) / tSeg;
     tiles *= g.nTSeg;
-    if (tiles <= 0 || tiles * FLAT_NT > 0xffffffffLL) return PRE_E_SHAPE;
-    hipLaunchKernelGGL((flat_march_kernel<Fn>), dim3((unsigned)tiles), dim3(FLAT_NT), 0, st, g, prm);
+    if (tiles <= 0 || tiles * nt > 0xffffffffLL) return PRE_E_SHAPE;
+    hipLaunchKernelGGL((flat_march_kernel<Fn>), dim3((unsigned)tiles), dim3(nt), 0, st, g, prm);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }
