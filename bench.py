@@ -6,9 +6,9 @@ Navier-Stokes momentum residual of (u, v, p) on [4096, 64, 512, 512] fp32 per ra
 by conformal calibration over the 4096 samples at the reference's 10 alpha levels.
 
 One field of that shape is 275 GB, so the tensor is streamed as t-slabs: --slab S interior planes
-(default 13 -> 5 slabs of 13,13,13,13,12 planes) + the 2 halo planes their stencils read; the three
-input slabs [B,S+2,512,512] (194 GB) and the residual buffer [B,S,512,512] (56 GB: interior planes only,
-PRE_FLAG_OUT_INTERIOR_T) are resident in HBM before the timed region.  Synthetic data: one resident
+(default: 16 -> 4 slabs if the 301 GB resident set fits the free HBM, else 13 -> 13,13,13,13,12) + the 2 halo
+planes their stencils read; the three input slabs [B,S+2,512,512] (232 GB at S = 16) and the residual buffer
+[B,S,512,512] (69 GB: interior planes only, PRE_FLAG_OUT_INTERIOR_T) are resident in HBM before the timed region.  Synthetic data: one resident
 slab of B + n_slabs - 1 samples stands in for the slab positions, slab position s reading the batch
 window [s, s + B) of it (825 GB of distinct input cannot be resident; the arithmetic and traffic per
 slab do not depend on the values).  One STEP = the whole [4096,64,512,512] job = n_slabs passes of
@@ -78,7 +78,8 @@ def parse():
     ap.add_argument("--nt", type=int, default=None)
     ap.add_argument("--nx", type=int, default=None)
     ap.add_argument("--ny", type=int, default=None)
-    ap.add_argument("--slab", type=int, default=13, help="interior planes per t-slab (c3)")
+    ap.add_argument("--slab", type=int, default=0,
+                    help="interior planes per t-slab (c3); 0 = the largest of 16 / 13 / 8 whose resident set fits the free HBM")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch samples per rank; strong: --batch samples in total, split over the ranks")
     ap.add_argument("--plumbing-check", action="store_true",
@@ -110,6 +111,14 @@ def launch_plan(gpus, environ, argv, script=None):
     if int(ws) != gpus:
         return "error", f"bench.py: WORLD_SIZE={ws} but --gpus {gpus}: launch with --nproc-per-node {gpus} (or pass --gpus {ws})"
     return "run", int(ws)
+
+
+def resident_bytes(B, nt, slab, X, Y):
+    """HBM held by the c3 driver: three input slabs of B + n_slabs - 1 samples with their halo planes + the residual
+    buffer of the slab's interior planes."""
+    slabs = split_slabs(nt, slab)
+    S = max(slabs)
+    return ((B + len(slabs) - 1) * 3 * (S + 2) + B * S) * X * Y * 4
 
 
 def split_slabs(nt, slab):
@@ -367,6 +376,12 @@ def main():
     from cp_pre_amd.residuals import NavierStokes
 
     B, X, Y = args.batch, args.nx, args.ny
+    free = torch.cuda.mem_get_info(dev)[0]
+    if not args.slab:
+        # fewer, thicker slabs re-read fewer halo planes (64 planes: 16 -> 4 slabs, 13 -> 5, 8 -> 8); the resident
+        # set of S = 16 at the full batch is 301 GB of the 309 GB the device reports, so it is taken only if it fits
+        extra = 4 * (4 << 30) if (args.mode == "marginal" and world > 1) else 0       # the exchange's staging buffers
+        args.slab = next((c for c in (16, 13, 8) if resident_bytes(B, args.nt, c, X, Y) + extra <= free - (4 << 30)), 8)
     slabs = split_slabs(args.nt, args.slab)                   # interior planes per slab position
     n_slabs, S = len(slabs), max(slabs)
     alphas = [float(a) for a in icp.ALPHA_LEVELS]
@@ -377,8 +392,7 @@ def main():
     torch.manual_seed(1234 + rank)
     # n_slabs - 1 extra samples: slab position s reads the batch window [s, s + B), so no two slab passes of a
     # step see the same input (and no layer of the memory system could serve one from another)
-    need = ((B + n_slabs - 1) * 3 * (S + 2) + B * S) * X * Y * 4
-    free = torch.cuda.mem_get_info(dev)[0]
+    need = resident_bytes(B, args.nt, args.slab, X, Y)
     if need > free - (2 << 30):
         print(f"bench.py: --slab {args.slab} needs {need / 1e9:.0f} GB resident, {free / 1e9:.0f} GB free", file=sys.stderr, flush=True)
         return 2
@@ -451,7 +465,7 @@ def main():
             "config": {"workload": f"C3 2D Navier-Stokes momentum residual [{B},{args.nt},{X},{Y}] x3 fields per rank, "
                                    f"{args.mode} CP, 10 alpha levels; streamed as {n_slabs} t-slabs of {slabs} interior "
                                    f"planes (+2 halo planes each)",
-                       "mode": args.mode, "batch_per_rank": B, **par,
+                       "mode": args.mode, "batch_per_rank": B, "slab": args.slab, **par,
                        # `value` is measured with the fields resident in HBM (contract); if the 3 fields came from host
                        # memory instead, PCIe Gen5 x16 (63 GB/s spec) would bound the job at 63e9 / 12 B per cell
                        "inputs": "resident in HBM", "host_fed_bound_cells_per_s": 63e9 / 12.0},

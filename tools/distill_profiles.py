@@ -97,6 +97,10 @@ def hbm_report(tag, fetch_src, write_src, kernel, cmd, workload, alg_bytes, halo
 
 c3 = bench.CONFIGS["c3"]["shape"]
 slab = 13
+try:                                                     # the slab size the profiled run chose (bench line of the trace pass)
+    slab = int(json.loads(bench_line("gpurun_out/prof/bench_fetch.log"))["config"]["slab"])
+except Exception:
+    pass
 slabs = bench.split_slabs(c3[1], slab)
 cells_xy = c3[0] * c3[2] * c3[3]
 hbm_report("c3", "fetch", "write", MK, "--steps 1 --warmup 0 --no-cpu-baseline",
@@ -124,7 +128,7 @@ for tag, srcs, mode in (("pmc_sq_c3.txt", ("sq1", "sq2"), "joint"), ("pmc_sq_c3_
     with open(f"{out}/{tag}", "w") as o:
         o.write(f"rocprofv3 --pmc <counters, one group per pass> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --batch 1024"
                 f"{' --mode marginal' if mode == 'marginal' else ''}\n"
-                f"(C3 {mode}, quarter batch: [1024,S+2,512,512] per launch, S = 13/12; per-dispatch sums over all SEs/XCDs, averaged over dispatches;\n"
+                f"(C3 {mode}, quarter batch: [1024,S+2,512,512] per launch, S = the slab size of the run; per-dispatch sums over all SEs/XCDs, averaged over dispatches;\n"
                 f" FETCH_SIZE in KiB, x2 for bytes on gfx950)\n\n")
         kernels = sorted({k for (_, k) in sq if k.startswith(OURS)})
         for k in kernels:
