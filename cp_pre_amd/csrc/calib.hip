@@ -280,28 +280,61 @@ __global__ void __launch_bounds__(1024) kth_kernel(const float *__restrict__ s, 
     __shared__ long long sh_rank;
     __shared__ int sh_nan;
     const int j = blockIdx.x;
+    const int lane = threadIdx.x & 63;
     unsigned int prefix = 0, mask = 0;
     long long rank = kl.k[j];
     if (threadIdx.x == 0) sh_nan = 0;
+    const bool vec = !((uintptr_t)s & 15);
+    const long long N8 = vec ? N / 8 : 0;                       // items of two float4 per thread and trip
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
-        for (long long i = threadIdx.x; i < N; i += blockDim.x) {
-            const float v = s[i];
-            if (shift == 24 && v != v) sh_nan = 1;          // np.quantile: any NaN score makes every quantile NaN
+        auto count = [&](float v) __attribute__((always_inline)) {
+            if (shift == 24 && v != v) sh_nan = 1;              // np.quantile: any NaN score makes every quantile NaN
             const unsigned int key = f2key(v);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            long long cum = 0;
-            unsigned int d = 0;
-            for (; d < 255; ++d) {
-                if (cum + hist[d] > rank) break;
-                cum += hist[d];
+            const bool hit = (key & mask) == prefix;
+            const unsigned int d = (key >> shift) & 255u;
+            // scores of one calibration set share their top byte (sign + exponent): 1024 threads adding to ONE LDS
+            // counter serialise lane by lane.  When every matching lane of the wave has the same digit, one lane adds
+            // the count (the later digits are spread and take the plain path).
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {
+                const int first = __builtin_ctzll(hm);
+                const unsigned int d0 = __builtin_amdgcn_readlane((int)d, first);
+                if (__ballot(hit && d == d0) == hm) {
+                    if (lane == first) atomicAdd(&hist[d0], (unsigned)__popcll(hm));
+                } else if (hit) {
+                    atomicAdd(&hist[d], 1u);
+                }
             }
-            sh_prefix = prefix | (d << shift);
-            sh_rank = rank - cum;
+        };
+        // eight scores per thread and trip, both loads issued before the first is used (one dependent scalar load per
+        // trip made the single workgroup latency-bound: 0.43 ms for N = 524288)
+        const float4 *s4 = reinterpret_cast<const float4 *>(s);
+        for (long long i = threadIdx.x; i < N8; i += blockDim.x) {
+            const float4 a = s4[2 * i], b = s4[2 * i + 1];
+            count(a.x); count(a.y); count(a.z); count(a.w);
+            count(b.x); count(b.y); count(b.z); count(b.w);
+        }
+        for (long long i = 8 * N8 + threadIdx.x; i < N; i += blockDim.x) count(s[i]);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            // digit of the rank: wave-parallel scan of the 256 bins (4 per lane)
+            const unsigned int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+            long long incl = (long long)c0 + c1 + c2 + c3;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const long long up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            long long excl = incl - ((long long)c0 + c1 + c2 + c3);
+            const bool mine = (excl <= rank && rank < incl) || (lane == 63 && rank >= incl);      // (rank < N: the last lane is a guard)
+            if (mine) {
+                unsigned int d = 4 * lane;
+                if (rank >= excl + c0) { excl += c0; ++d; if (rank >= excl + c1) { excl += c1; ++d; if (rank >= excl + c2) { excl += c2; ++d; } } }
+                sh_prefix = prefix | (d << shift);
+                sh_rank = rank - excl;
+            }
         }
         __syncthreads();
         prefix = sh_prefix;
