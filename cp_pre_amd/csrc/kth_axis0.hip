@@ -9,7 +9,8 @@
 // row, so the 64 LDS atomics of a wave-instruction never hit the same counter.
 //
 // MSD radix select on kk = key - klo[cell]  (key = order-preserving uint32 image of the fp32 score):
-//   0. SAMPLE (<= 1/16 sweep): ~256 evenly spaced rows give each cell the window [klo, khi] of its sample and
+//   0. SAMPLE (<= 1/16 sweep): 256 evenly spaced rows (64, with the range widened by half on each side, for
+//      n <= 1024) give each cell the window [klo, khi] of its sample and
 //      its own shift s = the smallest with (khi - klo) >> s <= NB1 - 2 (per cell: one tile-wide shift would be set
 //      by the cell whose sample happens to hold the smallest value, 15 binades instead of 9 on |N(0,1)| scores).
 //   1. FIRST DIGIT (1 sweep, one slot): NB1 = 512 or 1024 buckets over the cell's own window, + an underflow
@@ -204,7 +205,9 @@ template <int LOG_NB1>
 __device__ __forceinline__ int ka_window(const float *__restrict__ col, bool cok, int n, long long M, unsigned int *hist,
                                          unsigned int &klo, float &sf, float &vlo, int lane, int wave)
 {
-    const int m = n < 256 ? n : 256;                       // sample rows floor(j*n/m), j = wave, wave+16, ...
+    // sample rows floor(j*n/m), j = wave, wave+16, ...: 256 of them, or 64 for n <= 1024, where 256 rows would be a
+    // quarter to all of a sweep; the small sample's range is then widened by half on each side (below)
+    const int m = n <= 1024 ? (n < 64 ? n : 64) : 256;
     unsigned int kmin = 0xffffffffu, kmax = 0u;
     if (cok) {
         float v[16];
@@ -238,7 +241,11 @@ __device__ __forceinline__ int ka_window(const float *__restrict__ col, bool cok
     // fast form: rows 1 .. NB1-1 hold the window (t in [1, NB1)), row 0 = below it, row NB1 = above it:
     // sf a hair under (NB1-1)/(vhi - vlo), so that the window's top value stays below NB1
     vlo = key2f(kmin);
-    const float r = key2f(kmax) - vlo;
+    float r = key2f(kmax) - vlo;
+    if (m < n && m < 256) {                                // 64 of n rows: the 5 % / 95 % ranks may lie outside their range
+        vlo -= 0.5f * r;
+        r *= 2.0f;
+    }
     sf = ((float)((1 << LOG_NB1) - 1) / r) * 0.999999f;
     // no fast form for this cell when the window is empty (one value sampled: sf = inf, and with sf = 0 an infinite
     // score would turn into 0 * inf = NaN and be filed BELOW the window), not finite, or so narrow that sf overflows
