@@ -430,7 +430,7 @@ __device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok,
 template <int LOG_NB1, bool WIDE>
 __device__ __forceinline__ bool ka_first(const float *__restrict__ col, bool cok, int n, long long M, int nk, int shift,
                                          unsigned int klo, bool window, unsigned int *hist, unsigned int &myp,
-                                         unsigned int &myr, bool &outside, int lane, int wave, int tid)
+                                         unsigned int &myr, bool &outside, bool &nanl, int lane, int wave, int tid)
 {
     using C = Ctr<WIDE>;
     constexpr int NB1 = 1 << LOG_NB1, U = KACfg<LOG_NB1, WIDE>::U, CAP = KACfg<LOG_NB1, WIDE>::CAP;
@@ -439,6 +439,7 @@ __device__ __forceinline__ bool ka_first(const float *__restrict__ col, bool cok
     __syncthreads();
     const unsigned int inc = C::inc(lane);
     ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+        nanl |= v != v;                    // (this sweep sees every element of my cell in my wave's rows)
         const unsigned int key = f2key(v);
         const unsigned int d = min((key - klo) >> shift, (unsigned)(NB1 - 1));
         atomicAdd(&hist[C::word(key >= klo ? (int)d : NB1, lane)], inc);
@@ -575,9 +576,9 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
         __syncthreads();                   // (every wave has read the flags before the histogram memory is cleared again)
     }
     unsigned int myp = 0u, myr = k0;
-    bool many = true;
+    bool many = true, nanl = false;
     if (!outside) {
-        many = ka_first<LOG_NB1, WIDE>(col, cok, n, M, nk, shift, klo, true, hist, myp, myr, outside, lane, wave, tid);
+        many = ka_first<LOG_NB1, WIDE>(col, cok, n, M, nk, shift, klo, true, hist, myp, myr, outside, nanl, lane, wave, tid);
         if (outside) __syncthreads();
     }
     if (outside) {                         // some rank lies outside its cell's sampled window: plain top digit
@@ -585,7 +586,7 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
         shift = 32 - LOG_NB1;
         myp = 0u;
         myr = k0;
-        many = ka_first<LOG_NB1, WIDE>(col, cok, n, M, nk, shift, klo, false, hist, myp, myr, outside, lane, wave, tid);
+        many = ka_first<LOG_NB1, WIDE>(col, cok, n, M, nk, shift, klo, false, hist, myp, myr, outside, nanl, lane, wave, tid);
     }
     int known = shift;                     // lowest known bit of my cell's kk so far (per lane)
 #pragma unroll 1
@@ -597,7 +598,14 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
     __syncthreads();
     if (ka_or(hist, __ballot(state && known > 0) != 0 ? 1u : 0u, lane, wave))      // else every bit of every cell is counted
         ka_collect<U, Cfg::LS>(col, cok, n, M, nk, known, klo, hist, myp, myr, lane, wave, tid);
-    if (state && cok) out[(long long)wave * M + c] = key2f(myp + klo);
+    // np.quantile: a NaN anywhere in a cell's column makes every quantile of that cell NaN (the fast form never
+    // finishes a tile that holds one).  Cell flags are OR-ed across the waves through 64 LDS words.
+    __syncthreads();
+    if (tid < 64) hist[tid] = 0u;
+    __syncthreads();
+    if (nanl) hist[lane] = 1u;
+    __syncthreads();
+    if (state && cok) out[(long long)wave * M + c] = hist[lane] ? __uint_as_float(0x7fc00000u) : key2f(myp + klo);
 }
 
 // ---- small calibration sets (n <= 128; the reference scripts use n_cal = 100 and 1000): the whole column of a
@@ -682,11 +690,14 @@ __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict_
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = i < n ? f2key(raw[i]) : 0xffffffffu;
     ks_sort<N, 2>(v);
+    // np.quantile: a NaN in the column makes every quantile of the cell NaN.  Sorted by key, positive NaNs sit above
+    // +inf at the top of the n real entries and negative ones below -inf at the bottom
+    const bool nan = ks_take<N>(v, n - 1) > 0xff800000u || v[0] < 0x007fffffu;
 #pragma unroll
     for (int j = 0; j < KA_MAXK; ++j) {
         if (j >= kl.nk) break;                                    // wave-uniform
         const unsigned int r = ks_take<N>(v, kl.k[j]);
-        if (cok) out[(long long)j * M + c] = key2f(r);
+        if (cok) out[(long long)j * M + c] = nan ? __uint_as_float(0x7fc00000u) : key2f(r);
     }
 }
 

@@ -450,17 +450,22 @@ def test_marginal_qhat_window_and_fallback_paths(gpu, n):
         s[idx[: max(1, len(idx) // 3)], 100:102] = float("inf")
         s[idx[-max(1, len(idx) // 3):], 102:104] = float("-inf")
         s[idx, 104:108] = 2.0 + 1e-6 * torch.randn(len(idx), 4, device=gpu, generator=g)
-    # NaN scores order by their key, above +inf (torch.sort's convention too); the tile takes the general form
+    # np.quantile: a NaN anywhere in a cell's column makes every quantile of that cell NaN (the other cells of the
+    # tile are unaffected; the tile takes the general form)
     s[3, 108:112] = float("nan")
     s[n // 2, 110:112] = float("nan")
     s[n - 1, 111] = float("inf")
+    has_nan = torch.isnan(s).any(dim=0)
     ks = sorted({icp.kth_index(n, n, float(a)) for a in icp.ALPHA_LEVELS if icp.quantile_level(n, float(a)) <= 1}
                 | {0, 1, n // 2, n - 2, n - 1})
     for group in (ks[:10], ks[-10:]):
         got = icp.kth_axis0(s, group)
         ref = torch.sort(s, dim=0).values[group]
-        same = (got == ref) | (torch.isnan(got) & torch.isnan(ref))
+        same = torch.where(has_nan[None, :], torch.isnan(got), got == ref)
         assert bool(same.all()), (n, group)
+    with np.errstate(all="ignore"):
+        col = s[:, 109].cpu().numpy()
+        assert np.isnan(np.quantile(col, 0.5, method="higher")) and np.isnan(icp.kth_axis0(s, [n // 2])[0, 109].item())
 
 
 def test_joint_recipe_vs_numpy(gpu):
