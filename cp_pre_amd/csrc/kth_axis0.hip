@@ -613,7 +613,8 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
 // each, all issued before the first is used), keys padded with all ones to N = 64 / 128, a fully unrolled bitonic
 // network of v_min_u32 / v_max_u32 on the register array (N/4 log2(N) (log2(N)+1) compare-exchanges: 672 / 1792),
 // and the requested ranks - wave-uniform - are read with register-relative addressing.  (N = 256 was measured too:
-// 256 registers per lane leave one wave per SIMD, 3.3 ms against 2.1 ms for the radix form on [256, 2.6M].)  No LDS, no barrier, no atomics, one read
+// 256 registers per lane leave one wave per SIMD: 1.73 ms against 1.93 ms for the radix form on [256, 2.6M], for
+// 40 s more compile time - not instantiated.)  No LDS, no barrier, no atomics, one read
 // of the scores; the radix machinery above spends ~1500 instructions per thread on per-tile set-up alone, which at
 // n = 100 is 6 elements per thread.
 // one compare-exchange stage (partner distance J inside sorted runs of length K), fully unrolled; the stages are
