@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--plumbing-check", action="store_true",
                     help="initialise the process group, run one all-reduce, print the rank count and exit (no compute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prune", action="store_true",
+                    help="c3 joint: read the whole residual in the score pass instead of the branch-and-bound form")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -404,12 +406,13 @@ def main():
     res_buf = torch.empty(B * S * X * Y, dtype=torch.float32, device=dev)
     res_of = {sl: res_buf[:B * sl * X * Y].view(B, sl, X, Y) for sl in set(slabs)}
 
+
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(n_slabs * (args.steps + args.warmup))]
     ev_used = []
 
     def step(k):
-        jc = pipeline.JointCalibration(B, dev, group=group) if args.mode == "joint" else None
+        jc = pipeline.JointCalibration(B, dev, group=group, prune=not args.no_prune) if args.mode == "joint" else None
         q = None
         for s, sl in enumerate(slabs):
             res = res_of[sl]

@@ -87,6 +87,50 @@ __global__ void __launch_bounds__(256) moments_kernel(const float *__restrict__ 
     else { atomicAdd(&sum[c], s); atomicAdd(&sumsq[c], q); }
 }
 
+// Moments of a residual slab [n, T, X, Y] (T <= 16 planes, Y % 64 == 0) AND, from the same read, the bounds of the
+// pruned joint score: segmax[i][x][y / 64] = bit pattern of max |a| of sample i over the T planes and the 64 columns
+// of the segment (cells within cx / cy of the x / y rim excluded, 0 for rim rows).  A thread owns one (x, y) column of
+// the slab and keeps its 2 T fp64 sums in registers; a wave is one segment, so the per-sample maximum is a wave
+// reduction and one store.  Per cell the samples are added in the same order as moments_kernel does: same sums.
+constexpr int MS_TMAX = 16;
+__global__ void __launch_bounds__(256) moments_segmax_kernel(const float *__restrict__ a, int n, int T, int X, int Y, int cx, int cy,
+                                                             int rows_per_split, double *__restrict__ sum,
+                                                             double *__restrict__ sumsq, unsigned int *__restrict__ segmax)
+{
+    const long long plane = (long long)X * Y, c = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // c < plane (X*Y % 256 == 0)
+    const int x = (int)(c / Y), y = (int)(c - (long long)x * Y), nseg = Y / 64;
+    const bool scored = x >= cx && x < X - cx && y >= cy && y < Y - cy;
+    const int i0 = blockIdx.y * rows_per_split, i1 = min(n, i0 + rows_per_split);
+    double s[MS_TMAX], q[MS_TMAX];
+#pragma unroll
+    for (int t = 0; t < MS_TMAX; ++t) s[t] = q[t] = 0.0;
+    for (int i = i0; i < i1; ++i) {
+        const float *p = a + (long long)i * T * plane + c;
+        float v[MS_TMAX];
+#pragma unroll
+        for (int t = 0; t < MS_TMAX; ++t) v[t] = t < T ? p[t * plane] : 0.f;
+        unsigned int m = 0u;
+#pragma unroll
+        for (int t = 0; t < MS_TMAX; ++t)
+            if (t < T) {
+                const double d = (double)v[t];
+                s[t] += d;
+                q[t] += d * d;
+                m = max(m, __float_as_uint(v[t]) & 0x7fffffffu);     // non-negative floats order like their patterns, NaN on top
+            }
+        m = scored ? m : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o));
+        if ((threadIdx.x & 63) == 0) segmax[((long long)i * X + x) * nseg + (y >> 6)] = m;
+    }
+#pragma unroll
+    for (int t = 0; t < MS_TMAX; ++t)
+        if (t < T) {
+            if (gridDim.y == 1) { sum[t * plane + c] += s[t]; sumsq[t * plane + c] += q[t]; }
+            else { atomicAdd(&sum[t * plane + c], s[t]); atomicAdd(&sumsq[t * plane + c], q[t]); }
+        }
+}
+
 __global__ void __launch_bounds__(256) std_from_moments_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
                                                                double n_total, long long M, float eps, float *__restrict__ mod)
 {
@@ -267,6 +311,113 @@ __global__ void __launch_bounds__(256) joint_score_flat_kernel(const float *__re
                                    max(__float_as_uint(red[2]), __float_as_uint(red[3])));
         if (u) atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, u);
     }
+}
+
+// ------------------------------------------------------------------ pruned joint score (branch and bound)
+// The score of a sample is a MAXIMUM over cells, and for a segment S (one row x, 64 columns, the slab's planes)
+//     max_{c in S} fl(|r_c| / mod_c)  <=  fl( max_S |r_c| / min_S mod_c )
+// because correctly rounded division is monotone in both arguments.  The residual kernel delivers max_S |r| per
+// sample (segmax), segmin_kernel min_S mod once per slab; a block per sample then (1) evaluates the segment with the
+// largest bound exactly, (2) lists the segments whose bound still exceeds the best so far (earlier slabs' score
+// included) and evaluates only those.  On noise-like residuals that is a handful of the 4096 segments of a C3 slab:
+// the pass reads the 16 KB of bounds per sample instead of 13.6 MB of residual.
+constexpr int JP_SEG = 64;
+
+__global__ void __launch_bounds__(64) segmin_kernel(const float *__restrict__ mod, int T, int X, int Y, int ct, int cx, int cy,
+                                                    int nseg, float *__restrict__ segmin)
+{
+    const int x = blockIdx.x, seg = blockIdx.y, y = seg * JP_SEG + (int)threadIdx.x;
+    float m = __builtin_inff();
+    bool bad = false;
+    if (x >= cx && x < X - cx && y >= cy && y < Y - cy)
+        for (int t = ct; t < T - ct; ++t) {
+            const float v = mod[((long long)t * X + x) * Y + y];
+            bad |= !(v > 0.f);                                    // NaN or <= 0: no usable bound
+            m = fminf(m, v);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+    bad = __ballot(bad) != 0;
+    if (threadIdx.x == 0) segmin[(long long)x * nseg + seg] = bad ? 0.f : m;
+}
+
+__global__ void __launch_bounds__(256) joint_score_pruned_kernel(const float *__restrict__ res, const float *__restrict__ mod,
+                                                                 const unsigned int *__restrict__ segmax,
+                                                                 const float *__restrict__ segmin, int T, int X, int Y, int ct,
+                                                                 int cx, int cy, int nseg, float *__restrict__ scores)
+{
+    extern __shared__ unsigned int work[];                        // X * nseg segment ids
+    __shared__ unsigned int red[4], redi[4], nwork;
+    const int smp = blockIdx.x, tid = threadIdx.x;
+    const long long vol = (long long)T * X * Y;
+    const float *pr = res + smp * vol;
+    const unsigned int *pm = segmax + (long long)smp * X * nseg;
+    const int total = X * nseg;
+    const unsigned int NANBITS = 0x7fc00000u;
+
+    // upper bound of a segment's scores as a bit pattern (NaN above everything: "must be read")
+    auto bound = [&](int j) __attribute__((always_inline)) {
+        const unsigned int mx = pm[j];
+        if (mx == 0u) return 0u;                                  // rim row / nothing in it
+        const float q = __uint_as_float(mx) / segmin[j];          // mx NaN, segmin 0 -> inf or NaN
+        return q != q ? NANBITS : __float_as_uint(q);
+    };
+    // exact maximum of |r| / mod over one segment, by the whole block
+    auto evaluate = [&](int j) __attribute__((always_inline)) {
+        const int x = j / nseg, y0 = (j - x * nseg) * JP_SEG;
+        const int planes = T - 2 * ct;
+        unsigned int m = 0u;
+        for (int k = tid; k < planes * JP_SEG; k += 256) {
+            const int t = ct + k / JP_SEG, y = y0 + (k & (JP_SEG - 1));
+            if (y >= cy && y < Y - cy) {
+                const long long o = ((long long)t * X + x) * Y + y;
+                const float q = fabsf(pr[o]) / mod[o];
+                m = max(m, q != q ? NANBITS : __float_as_uint(q));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o));
+        __syncthreads();                                          // red is free again
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        return max(max(red[0], red[1]), max(red[2], red[3]));
+    };
+
+    // (1) the segment with the largest bound
+    unsigned int bb = 0u, bj = 0u;
+    for (int j = tid; j < total; j += 256) {
+        const unsigned int b = bound(j);
+        if (b > bb) { bb = b; bj = (unsigned)j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int ob = (unsigned int)__shfl_xor((int)bb, o), oj = (unsigned int)__shfl_xor((int)bj, o);
+        if (ob > bb || (ob == bb && oj < bj)) { bb = ob; bj = oj; }
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = bb; redi[tid >> 6] = bj; }
+    if (tid == 0) nwork = 0u;
+    __syncthreads();
+    for (int w = 1; w < 4; ++w)
+        if (red[w] > red[0] || (red[w] == red[0] && redi[w] < redi[0])) { bb = red[w]; bj = redi[w]; }   // (every thread the same)
+    {
+        unsigned int gb = red[0], gj = redi[0];
+        for (int w = 1; w < 4; ++w)
+            if (red[w] > gb || (red[w] == gb && redi[w] < gj)) { gb = red[w]; gj = redi[w]; }
+        bb = gb; bj = gj;
+    }
+    unsigned int best = __float_as_uint(scores[smp]);            // earlier slabs (non-negative or NaN: orders as uint)
+    if (bb == 0u) return;                                         // nothing scored in this slab (block-uniform)
+    if (bb > best) best = max(best, evaluate((int)bj));
+    // (2) every other segment that can still beat it
+    for (int j = tid; j < total; j += 256)
+        if ((unsigned)j != bj && bound(j) > best) work[atomicAdd(&nwork, 1u)] = (unsigned)j;
+    __syncthreads();
+    const unsigned int nw = nwork;
+    for (unsigned int i = 0; i < nw; ++i) {
+        const int j = (int)work[i];
+        if (bound(j) > best) best = max(best, evaluate(j));      // (block-uniform: best and the bound are)
+    }
+    if (tid == 0) atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, best);
 }
 
 // ------------------------------------------------------------------ scalar k-th (radix select)
@@ -509,6 +660,24 @@ int pre_moments_axis0_f64(const float *a, const float *b, int64_t n, int64_t M, 
     return PRE_OK;
 }
 
+int pre_moments_segmax_f64(const float *a, int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y, double *sum,
+                           double *sumsq, uint32_t *segmax, void *stream)
+{
+    if (!a || !sum || !sumsq || !segmax || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
+    if (crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
+    if (T > MS_TMAX || Y % 64 != 0 || (X * Y) % 256 != 0) return PRE_E_UNSUPPORTED;      // caller: plain moments + plain score
+    if (n > 0x7fffffff || X * Y > 0x7fffffffLL * 256) return PRE_E_SHAPE;
+    const long long bx = X * Y / 256;
+    long long splits = 1;
+    while (bx * splits < 1024 && splits * 32 < n) splits *= 2;
+    const int rows = (int)((n + splits - 1) / splits);
+    splits = (n + rows - 1) / rows;
+    hipLaunchKernelGGL(moments_segmax_kernel, dim3((unsigned)bx, (unsigned)splits), dim3(256), 0, as_stream(stream), a, (int)n, (int)T,
+                       (int)X, (int)Y, crop_x, crop_y, rows, sum, sumsq, segmax);
+    PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
+
 int pre_std_from_moments_f32(const double *sum, const double *sumsq, int64_t n_total, int64_t M, float eps, float *mod,
                              void *stream)
 {
@@ -553,6 +722,32 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod, int64_
                            crop_t, crop_x, crop_y, (int)groups, swap, scores + s0);
         PRE_LAUNCH_CHECK();
     }
+    return PRE_OK;
+}
+
+int pre_segmin_mod_f32(const float *mod, int64_t T, int64_t X, int64_t Y, int crop_t, int crop_x, int crop_y, float *segmin,
+                       void *stream)
+{
+    if (!mod || !segmin || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
+    if (crop_t < 0 || crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
+    const long long nseg = (Y + JP_SEG - 1) / JP_SEG;
+    if (X > 0x7fffffff || nseg > 65535 || T > 0x7fffffff) return PRE_E_SHAPE;
+    hipLaunchKernelGGL(segmin_kernel, dim3((unsigned)X, (unsigned)nseg), dim3(64), 0, as_stream(stream), mod, (int)T, (int)X, (int)Y,
+                       crop_t, crop_x, crop_y, (int)nseg, segmin);
+    PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
+
+int pre_joint_score_pruned_f32(const float *res, const float *mod, const uint32_t *segmax, const float *segmin, int64_t n,
+                               int64_t T, int64_t X, int64_t Y, int crop_t, int crop_x, int crop_y, float *scores, void *stream)
+{
+    if (!res || !mod || !segmax || !segmin || !scores || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
+    if (crop_t < 0 || crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
+    const long long nseg = (Y + JP_SEG - 1) / JP_SEG, total = X * nseg;
+    if (n > 0x7fffffff || total * 4 > 150 * 1024 || T > 0x7fffffff) return PRE_E_SHAPE;      // the work list lives in LDS
+    hipLaunchKernelGGL(joint_score_pruned_kernel, dim3((unsigned)n), dim3(256), (size_t)total * 4, as_stream(stream), res, mod,
+                       segmax, segmin, (int)T, (int)X, (int)Y, crop_t, crop_x, crop_y, (int)nseg, scores);
+    PRE_LAUNCH_CHECK();
     return PRE_OK;
 }
 

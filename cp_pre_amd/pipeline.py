@@ -85,6 +85,40 @@ class HipOps:
                                                        _lib.ptr(scores), _lib.stream()), "pre_joint_score_f32")
 
     @staticmethod
+    def can_prune(res, crop):
+        """The branch-and-bound score needs a contiguous [n,T,X,Y] slab whose planes all count (no t crop), at most 16
+        of them, and whole 64-column segments."""
+        return (res.dim() == 4 and res.is_contiguous() and crop[0] == 0 and res.shape[1] <= 16 and res.shape[3] % 64 == 0
+                and (res.shape[2] * res.shape[3]) % 256 == 0)
+
+    @staticmethod
+    def add_moments_segmax(res, mom, crop):
+        """``add_moments`` + from the same read the per-(sample, row, 64-column segment) maxima of |res|, cells within
+        ``crop`` of the x / y rim excluded: int32 [n, X, Y/64] (bit patterns) for ``max_scores_pruned``."""
+        n, (T, X, Y) = res.shape[0], res.shape[1:]
+        segmax = torch.empty(n, X, Y // 64, dtype=torch.int32, device=res.device)
+        with torch.cuda.device(res.device):
+            _lib.check(_lib.load().pre_moments_segmax_f64(_lib.ptr(res), n, T, X, Y, crop[1], crop[2], _lib.ptr(mom[0]),
+                                                          _lib.ptr(mom[1]), _lib.ptr(segmax), _lib.stream()),
+                       "pre_moments_segmax_f64")
+        return segmax
+
+    @staticmethod
+    def max_scores_pruned(res, mod, segmax, crop, scores):
+        """Branch-and-bound form of ``max_scores`` for the slab ``add_moments_segmax`` just read: same scores, bit for
+        bit, but only the segments whose bound (max |res| / min mod) exceeds a sample's best score so far are read."""
+        n, (T, X, Y) = res.shape[0], res.shape[1:]
+        nseg = (Y + 63) // 64
+        segmin = torch.empty(X, nseg, dtype=torch.float32, device=res.device)
+        lib = _lib.load()
+        with torch.cuda.device(res.device):
+            _lib.check(lib.pre_segmin_mod_f32(_lib.ptr(mod), T, X, Y, crop[0], crop[1], crop[2], _lib.ptr(segmin), _lib.stream()),
+                       "pre_segmin_mod_f32")
+            _lib.check(lib.pre_joint_score_pruned_f32(_lib.ptr(res), _lib.ptr(mod), _lib.ptr(segmax), _lib.ptr(segmin), n, T, X, Y,
+                                                      crop[0], crop[1], crop[2], _lib.ptr(scores), _lib.stream()),
+                       "pre_joint_score_pruned_f32")
+
+    @staticmethod
     def kth(scores, ks):
         return icp.kth_axis0(scores, ks)
 
@@ -103,8 +137,9 @@ class JointCalibration:
     per-sample max composes across slabs, so one sweep over the data suffices.
     """
 
-    def __init__(self, n_local, device, eps=0.0, group=None, ops=None):
+    def __init__(self, n_local, device, eps=0.0, group=None, ops=None, prune=True):
         self.ops = ops or HipOps
+        self.prune = prune
         self.group, self.eps, self.n_local, self.device = group, eps, n_local, device
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
         self.n_total = n_local * self.world
@@ -114,18 +149,28 @@ class JointCalibration:
     def add_slab(self, res, crop=(1, 1, 1)):
         """``res``: UNCROPPED residual slab [n_local, T_slab, X, Y]; ``crop`` cells per side are excluded
         from the score (the reference's ``[...,1:-1,1:-1,1:-1]``).  The t-rim planes may hold garbage
-        (``PRE_FLAG_INTERIOR_T``): they are neither reduced nor scored."""
+        (``PRE_FLAG_INTERIOR_T``): they are neither reduced nor scored.
+        When the slab allows it (``HipOps.can_prune``: contiguous, no t crop, <= 16 planes, Ny % 64 == 0) the moments
+        pass also delivers per-segment maxima of |res| and the score pass reads only the segments that can still raise
+        a sample's score - the same scores bit for bit (``prune=False`` forces the full pass)."""
         ops = self.ops
         M = res[0].numel() if hasattr(res[0], "numel") else res[0].size
         skip = crop[0] if (getattr(ops, "interior_t", False) and crop[0] > 0 and res.is_contiguous()
                            and res.shape[1] > 2 * crop[0]) else 0
         kw = {"skip_t": skip} if skip else {}
         mom = ops.zeros_moments(M - 2 * skip * (M // res.shape[1]), self.device)
-        ops.add_moments(res, mom, **kw)
+        segmax = None
+        if self.prune and getattr(ops, "can_prune", None) and ops.can_prune(res, crop):
+            segmax = ops.add_moments_segmax(res, mom, crop)
+        else:
+            ops.add_moments(res, mom, **kw)
         if self.group is not None:
             torch.distributed.all_reduce(mom, group=self.group)          # RCCL: sum of (sum, sumsq) per cell
         mod = ops.std_from_moments(mom, self.n_total, tuple(res.shape[1:]), self.eps, like=res, **kw)
-        ops.max_scores(res, mod, crop, self.scores)
+        if segmax is not None:
+            ops.max_scores_pruned(res, mod, segmax, crop, self.scores)
+        else:
+            ops.max_scores(res, mod, crop, self.scores)
         self.modulation.append(mod)
         return mod
 

@@ -57,7 +57,7 @@ typedef struct {
     int64_t sB, sT, sX, sY;
 } pre_out_t;
 
-int pre_abi_version(void);     /* 4 */
+int pre_abi_version(void);     /* 5 */
 
 /* ---- a4/a5/a6: ConvOperator.convolution ---------------------------------------------
  * Utils/ConvOps_2d.py:135-150  F.conv3d(field[:,None], K[None,None], padding=k//2)
@@ -168,6 +168,26 @@ int pre_std_from_moments_f32(const double *sum, const double *sumsq, int64_t n_t
 int pre_joint_score_f32(const float *a, const float *b, const float *mod,
                         int64_t n, int64_t T, int64_t X, int64_t Y,
                         int crop_t, int crop_x, int crop_y, float *scores, void *stream);
+
+/* Branch-and-bound form of the streaming joint score.  The score of a sample is a maximum, and for a segment (one row
+ * x, 64 columns, the slab's planes)  max |r_c| / min mod_c  bounds every |r_c| / mod_c in it (correctly rounded division
+ * is monotone), so a segment whose bound does not exceed the sample's best score so far - scores[i] from earlier slabs,
+ * then the segment with the largest bound - is never read.  Bit-identical to pre_joint_score_f32; on noise-like
+ * residuals it reads well under 1 % of them.
+ *   pre_moments_segmax_f64: pre_moments_axis0_f64 for a contiguous slab a[n,T,X,Y] (T <= 16, Y % 64 == 0, X*Y % 256 == 0;
+ *     else PRE_E_UNSUPPORTED) that ALSO writes, from the same read, segmax[i][x][y/64] (uint32 [n][X][Y/64]) = the bit
+ *     pattern of max |a| of sample i over the T planes and the segment's columns, cells within crop_x / crop_y of the
+ *     x / y rim excluded (0 for rim rows).  Same sums as pre_moments_axis0_f64 (same order of additions per cell).
+ *   pre_segmin_mod_f32: segmin[x][y/64] = min of mod[t][x][y] over crop_t <= t < T - crop_t and the segment's
+ *     uncropped columns; +inf for rim rows, 0 if the segment holds a NaN or a non-positive modulation (-> always read).
+ *   res: the same contiguous [n,T,X,Y] slab; crop_t must be 0 (segmax covers every plane); crops as pre_joint_score_f32. */
+int pre_moments_segmax_f64(const float *a, int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y,
+                           double *sum, double *sumsq, uint32_t *segmax, void *stream);
+int pre_segmin_mod_f32(const float *mod, int64_t T, int64_t X, int64_t Y, int crop_t, int crop_x, int crop_y,
+                       float *segmin, void *stream);
+int pre_joint_score_pruned_f32(const float *res, const float *mod, const uint32_t *segmax, const float *segmin,
+                               int64_t n, int64_t T, int64_t X, int64_t Y, int crop_t, int crop_x, int crop_y,
+                               float *scores, void *stream);
 
 /* ---- a11: calibrate(scores, n, alpha) ---------------------------------------------------
  * (Neural_PDE.UQ.inductive_cp, absent; call sites Marginal/Wave_Residuals_CP.py:288,

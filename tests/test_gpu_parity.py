@@ -557,6 +557,64 @@ def test_joint_score_propagates_nan_like_numpy(gpu):
         assert np.isnan(icp.calibrate(ref2, n, 0.1)) and np.isnan(np.quantile(ref2, 0.5, method="higher"))
 
 
+@pytest.mark.parametrize("shape", [(37, 5, 24, 256), (16, 3, 8, 192), (64, 8, 40, 512), (9, 16, 12, 320)])
+def test_pruned_joint_score_equals_full_pass(gpu, shape):
+    """Branch-and-bound joint score (segment maxima from the fused moments pass + pre_joint_score_pruned_f32) against the
+    full pass: identical moments, identical scores for the same modulation, identical q-hat, slab after slab; the
+    segment maxima themselves against torch; a NaN residual, a zero-modulation cell, an outlier sample and a sample
+    that is zero everywhere."""
+    from cp_pre_amd import pipeline
+    from cp_pre_amd.residuals import NavierStokes
+    B, T, X, Y = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    ns = NavierStokes(0.01, 1.0 / X, 1.0 / Y)
+    alphas = [0.1, 0.5, 0.9]
+    ops = pipeline.HipOps
+    crop = (0, 1, 1)
+    full_jc, pruned_jc = pipeline.JointCalibration(B, gpu, prune=False), pipeline.JointCalibration(B, gpu)
+    for slab in range(3):
+        v = (torch.rand(B, 3, T + 2, X, Y, generator=g) + 0.5).to(gpu)
+        if slab == 1:
+            v[3, :, :, 5:9, 70:140] += 40.0                               # an outlier sample
+            v[5] = 1.0                                                    # residual exactly zero everywhere
+        if slab == 2 and B > 10:
+            v[7, 0, 2, 4, 100] = float("nan")
+        inner = torch.empty(B, T, X, Y, device=gpu)
+        ns.residual_momentum(v, boundary=True, out=inner, skip_t_rim=True)
+        if slab == 0:
+            inner[:, :, 3, 77] = 0.0                                      # a constant cell: modulation 0 there
+        assert ops.can_prune(inner, crop)
+        # fused moments + segment maxima == plain moments, and the maxima against torch
+        m_ref, m_new = ops.zeros_moments(T * X * Y, gpu), ops.zeros_moments(T * X * Y, gpu)
+        ops.add_moments(inner, m_ref)
+        segmax = ops.add_moments_segmax(inner, m_new, crop)
+        assert torch.equal(torch.nan_to_num(m_ref, nan=7.0), torch.nan_to_num(m_new, nan=7.0))
+        a = inner.abs()
+        a[..., 0] = 0.0
+        a[..., -1] = 0.0
+        ref = a.view(B, T, X, Y // 64, 64)
+        ref = torch.where(torch.isnan(ref).any(-1).any(1), torch.full((), float("nan"), device=gpu), ref.amax(-1).amax(1))
+        ref[:, 0] = 0.0
+        ref[:, -1] = 0.0
+        assert torch.equal(torch.nan_to_num(segmax.view(torch.float32), nan=-5.0), torch.nan_to_num(ref, nan=-5.0)), (slab, shape)
+        # same modulation -> same scores, accumulated over the slabs
+        mod = ops.std_from_moments(m_ref, B, (T, X, Y), 0.0, like=inner)
+        s_full, s_pr = full_jc.scores.clone(), full_jc.scores.clone()
+        ops.max_scores(inner, mod, crop, s_full)
+        ops.max_scores_pruned(inner, mod, segmax, crop, s_pr)
+        assert torch.equal(torch.nan_to_num(s_full, nan=-1.0), torch.nan_to_num(s_pr, nan=-1.0)), (slab, shape, s_full, s_pr)
+        # and through the drivers
+        m1 = full_jc.add_slab(inner, crop=crop)
+        m2 = pruned_jc.add_slab(inner, crop=crop)
+        assert torch.equal(torch.nan_to_num(m1, nan=1.0), torch.nan_to_num(m2, nan=1.0))
+        assert torch.equal(torch.nan_to_num(full_jc.scores, nan=-1.0), torch.nan_to_num(pruned_jc.scores, nan=-1.0))
+    q1, q2 = full_jc.finish(alphas), pruned_jc.finish(alphas)
+    assert torch.equal(torch.nan_to_num(q1, nan=-1.0), torch.nan_to_num(q2, nan=-1.0))
+    # slabs the pruned form does not take fall back silently: 17 planes, a t crop, Ny not a multiple of 64
+    assert not ops.can_prune(torch.empty(2, 17, 8, 64, device=gpu), crop) and not ops.can_prune(inner, (1, 1, 1))
+    assert not ops.can_prune(torch.empty(2, 4, 8, 96, device=gpu), crop)
+
+
 def test_scalar_kth_large_and_absdiff(gpu):
     from cp_pre_amd import _lib, inductive_cp as icp
     rng = np.random.default_rng(9)

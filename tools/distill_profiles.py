@@ -14,6 +14,8 @@ def short(k):
     'march_kernel<NSMomentum<0>,8,64>'; torch/rccl kernels keep a trimmed name."""
     k = k.replace("(anonymous namespace)::", "").replace("void ", "")
     k = re.sub(r"\(.*$", "", k).strip()
+    k = re.sub(r",\s*false,\s*true>$", ",SEG>", k)             # march_kernel<Fn,NR,TYQ,BC=false,SEG=true>
+    k = re.sub(r",\s*false,\s*false>$", ">", k)
     k = re.sub(r",\s*(false|true)>$", lambda m: ">" if m.group(1) == "false" else ",BC>", k)
     return k.replace(", ", ",")[:70]
 
