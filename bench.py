@@ -86,7 +86,7 @@ def parse():
                     help="initialise the process group, run one all-reduce, print the rank count and exit (no compute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prune", action="store_true",
-                    help="c3 joint: read the whole residual in the score pass instead of the branch-and-bound form")
+                    help="joint mode: read the whole residual in the score pass instead of the branch-and-bound form")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -187,7 +187,7 @@ def run_secondary(args, cfg, dev, group, rank, world, par):
         e1.record()
         ev.append((e0, e1))
         if args.mode == "joint":
-            jc = pipeline.JointCalibration(B, dev, group=group)
+            jc = pipeline.JointCalibration(B, dev, group=group, prune=not args.no_prune)
             jc.add_slab(res, crop=crop)
             return jc.finish(alphas)
         return pipeline.marginal_qhat(res, alphas, group=group)

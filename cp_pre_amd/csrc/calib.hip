@@ -87,47 +87,93 @@ __global__ void __launch_bounds__(256) moments_kernel(const float *__restrict__ 
     else { atomicAdd(&sum[c], s); atomicAdd(&sumsq[c], q); }
 }
 
-// Moments of a residual slab [n, T, X, Y] (T <= 16 planes, Y % 64 == 0) AND, from the same read, the bounds of the
-// pruned joint score: segmax[i][x][y / 64] = bit pattern of max |a| of sample i over the T planes and the 64 columns
-// of the segment (cells within cx / cy of the x / y rim excluded, 0 for rim rows).  A thread owns one (x, y) column of
-// the slab and keeps its 2 T fp64 sums in registers; a wave is one segment, so the per-sample maximum is a wave
-// reduction and one store.  Per cell the samples are added in the same order as moments_kernel does: same sums.
+// Moments of a residual tensor [n, T, X, Y] (Y % 64 == 0) AND, from the same read, the bounds of the pruned joint
+// score: segmax[i][tc][x][y / 64] = bit pattern of max |a| of sample i over the (up to) 16 planes of chunk tc and the
+// 64 columns of the segment (cells within cx / cy of the x / y rim excluded, 0 for rim rows).  A thread owns one
+// (x, y) column of a chunk and keeps its 2 x 16 fp64 sums in registers; a wave is one segment, so the per-sample
+// maximum is a wave reduction and one store.  Per cell and split the samples are added in ascending order, as
+// moments_kernel does (the split counts differ, so the fp64 sums agree up to the order of the additions).
 constexpr int MS_TMAX = 16;
-__global__ void __launch_bounds__(256) moments_segmax_kernel(const float *__restrict__ a, int n, int T, int X, int Y, int cx, int cy,
-                                                             int rows_per_split, double *__restrict__ sum,
+// TCH planes x US samples in flight per thread (16 loads either way): <16,1> for slabs of many planes, <4,4> and
+// <1,16> when the tensor has only a few (C5 arrives as [n,1,Nt,Nx]).  A segment always spans MS_TMAX planes:
+// chunk tc = blockIdx.z covers planes [tc*MS_TMAX, ...) and for TCH < MS_TMAX there is one chunk.
+template <int US, int H>
+__device__ __forceinline__ void ms_butterfly(unsigned int (&m)[US], int lane)
+{
+    if constexpr (H >= 1) {
+        constexpr int width = 64 * H / US;                        // 32 for the first step
+        const bool up = lane & width;
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const unsigned int mine = up ? m[H + k] : m[k], send = up ? m[k] : m[H + k];
+            m[k] = max(mine, (unsigned int)__shfl_xor((int)send, width));
+        }
+        ms_butterfly<US, H / 2>(m, lane);
+    }
+}
+
+// US samples starting at sample i of one thread's column: loads first, then sums and the per-sample wave maxima.
+template <int TCH, int US>
+__device__ __forceinline__ void ms_step(const float *__restrict__ a, long long row_stride, long long plane, int i, int nt, bool scored,
+                                        double (&s)[TCH], double (&q)[TCH], unsigned int *__restrict__ seg, long long seg_stride)
+{
+    float v[US][TCH];
+#pragma unroll
+    for (int u = 0; u < US; ++u)
+#pragma unroll
+        for (int t = 0; t < TCH; ++t) v[u][t] = (TCH == 1 || t < nt) ? a[(i + u) * row_stride + t * plane] : 0.f;
+    unsigned int m[US];
+#pragma unroll
+    for (int u = 0; u < US; ++u) {
+        m[u] = 0u;
+#pragma unroll
+        for (int t = 0; t < TCH; ++t)
+            if (TCH == 1 || t < nt) {
+                const double d = (double)v[u][t];
+                s[t] += d;
+                q[t] += d * d;
+                m[u] = max(m[u], __float_as_uint(v[u][t]) & 0x7fffffffu);   // non-negative floats order like their patterns, NaN on top
+            }
+        m[u] = scored ? m[u] : 0u;
+    }
+    // wave maxima of US samples at once: each butterfly step halves the samples a lane is responsible for (US-1
+    // exchanges instead of 6 US), after which lane L holds sample L / (64/US) and the remaining lane bits are
+    // reduced as usual
+    const int lane = threadIdx.x & 63;
+    ms_butterfly<US, US / 2>(m, lane);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        if (o < 64 / US) m[0] = max(m[0], (unsigned int)__shfl_xor((int)m[0], o));
+    if ((lane & (64 / US - 1)) == 0) seg[(i + lane / (64 / US)) * seg_stride] = m[0];
+}
+
+template <int TCH, int US>
+__global__ void __launch_bounds__(256) moments_segmax_kernel(const float *__restrict__ a, long long row_stride, int n, int T, int X,
+                                                             int Y, int cx, int cy, int rows_per_split, double *__restrict__ sum,
                                                              double *__restrict__ sumsq, unsigned int *__restrict__ segmax)
 {
     const long long plane = (long long)X * Y, c = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // c < plane (X*Y % 256 == 0)
     const int x = (int)(c / Y), y = (int)(c - (long long)x * Y), nseg = Y / 64;
     const bool scored = x >= cx && x < X - cx && y >= cy && y < Y - cy;
     const int i0 = blockIdx.y * rows_per_split, i1 = min(n, i0 + rows_per_split);
-    double s[MS_TMAX], q[MS_TMAX];
+    const int tc = blockIdx.z, TC = gridDim.z, t0 = tc * MS_TMAX, nt = min(TCH, T - t0);
+    a += (long long)t0 * plane + c;
+    const long long seg_stride = (long long)TC * X * nseg;                                 // segmax [n][TC][X][nseg]
+    unsigned int *seg = segmax + ((long long)tc * X + x) * nseg + (y >> 6);
+    double s[TCH], q[TCH];
 #pragma unroll
-    for (int t = 0; t < MS_TMAX; ++t) s[t] = q[t] = 0.0;
-    for (int i = i0; i < i1; ++i) {
-        const float *p = a + (long long)i * T * plane + c;
-        float v[MS_TMAX];
+    for (int t = 0; t < TCH; ++t) s[t] = q[t] = 0.0;
+    int i = i0;
+    for (; i + US <= i1; i += US) ms_step<TCH, US>(a, row_stride, plane, i, nt, scored, s, q, seg, seg_stride);
+    if (US > 1)
+        for (; i < i1; ++i) ms_step<TCH, 1>(a, row_stride, plane, i, nt, scored, s, q, seg, seg_stride);
+    sum += (long long)t0 * plane + c;
+    sumsq += (long long)t0 * plane + c;
 #pragma unroll
-        for (int t = 0; t < MS_TMAX; ++t) v[t] = t < T ? p[t * plane] : 0.f;
-        unsigned int m = 0u;
-#pragma unroll
-        for (int t = 0; t < MS_TMAX; ++t)
-            if (t < T) {
-                const double d = (double)v[t];
-                s[t] += d;
-                q[t] += d * d;
-                m = max(m, __float_as_uint(v[t]) & 0x7fffffffu);     // non-negative floats order like their patterns, NaN on top
-            }
-        m = scored ? m : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o));
-        if ((threadIdx.x & 63) == 0) segmax[((long long)i * X + x) * nseg + (y >> 6)] = m;
-    }
-#pragma unroll
-    for (int t = 0; t < MS_TMAX; ++t)
-        if (t < T) {
-            if (gridDim.y == 1) { sum[t * plane + c] += s[t]; sumsq[t * plane + c] += q[t]; }
-            else { atomicAdd(&sum[t * plane + c], s[t]); atomicAdd(&sumsq[t * plane + c], q[t]); }
+    for (int t = 0; t < TCH; ++t)
+        if (t < nt) {
+            if (gridDim.y == 1) { sum[t * plane] += s[t]; sumsq[t * plane] += q[t]; }
+            else { atomicAdd(&sum[t * plane], s[t]); atomicAdd(&sumsq[t * plane], q[t]); }
         }
 }
 
@@ -316,21 +362,21 @@ __global__ void __launch_bounds__(256) joint_score_flat_kernel(const float *__re
 // ------------------------------------------------------------------ pruned joint score (branch and bound)
 // The score of a sample is a MAXIMUM over cells, and for a segment S (one row x, 64 columns, the slab's planes)
 //     max_{c in S} fl(|r_c| / mod_c)  <=  fl( max_S |r_c| / min_S mod_c )
-// because correctly rounded division is monotone in both arguments.  The residual kernel delivers max_S |r| per
-// sample (segmax), segmin_kernel min_S mod once per slab; a block per sample then (1) evaluates the segment with the
+// because correctly rounded division is monotone in both arguments.  moments_segmax_kernel delivers max_S |r| per
+// sample (segmax) from the read the moments need anyway, segmin_kernel min_S mod once per slab; a block per sample then (1) evaluates the segment with the
 // largest bound exactly, (2) lists the segments whose bound still exceeds the best so far (earlier slabs' score
 // included) and evaluates only those.  On noise-like residuals that is a handful of the 4096 segments of a C3 slab:
 // the pass reads the 16 KB of bounds per sample instead of 13.6 MB of residual.
 constexpr int JP_SEG = 64;
 
-__global__ void __launch_bounds__(64) segmin_kernel(const float *__restrict__ mod, int T, int X, int Y, int ct, int cx, int cy,
-                                                    int nseg, float *__restrict__ segmin)
+__global__ void __launch_bounds__(64) segmin_kernel(const float *__restrict__ mod, int T, int X, int Y, int cx, int cy, int nseg,
+                                                    float *__restrict__ segmin)
 {
-    const int x = blockIdx.x, seg = blockIdx.y, y = seg * JP_SEG + (int)threadIdx.x;
+    const int x = blockIdx.x, seg = blockIdx.y, tc = blockIdx.z, y = seg * JP_SEG + (int)threadIdx.x;
     float m = __builtin_inff();
     bool bad = false;
     if (x >= cx && x < X - cx && y >= cy && y < Y - cy)
-        for (int t = ct; t < T - ct; ++t) {
+        for (int t = tc * MS_TMAX; t < min(T, (tc + 1) * MS_TMAX); ++t) {
             const float v = mod[((long long)t * X + x) * Y + y];
             bad |= !(v > 0.f);                                    // NaN or <= 0: no usable bound
             m = fminf(m, v);
@@ -338,37 +384,39 @@ __global__ void __launch_bounds__(64) segmin_kernel(const float *__restrict__ mo
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
     bad = __ballot(bad) != 0;
-    if (threadIdx.x == 0) segmin[(long long)x * nseg + seg] = bad ? 0.f : m;
+    if (threadIdx.x == 0) segmin[((long long)tc * X + x) * nseg + seg] = bad ? 0.f : m;
 }
 
-__global__ void __launch_bounds__(256) joint_score_pruned_kernel(const float *__restrict__ res, const float *__restrict__ mod,
+__global__ void __launch_bounds__(256) joint_score_pruned_kernel(const float *__restrict__ res, long long row_stride,
+                                                                 const float *__restrict__ mod,
                                                                  const unsigned int *__restrict__ segmax,
-                                                                 const float *__restrict__ segmin, int T, int X, int Y, int ct,
-                                                                 int cx, int cy, int nseg, float *__restrict__ scores)
+                                                                 const float *__restrict__ segmin, int T, int X, int Y, int cx,
+                                                                 int cy, int nseg, int total, float *__restrict__ scores)
 {
-    extern __shared__ unsigned int work[];                        // X * nseg segment ids
+    extern __shared__ unsigned int work[];                        // `total` = TC * X * nseg segment ids
     __shared__ unsigned int red[4], redi[4], nwork;
     const int smp = blockIdx.x, tid = threadIdx.x;
-    const long long vol = (long long)T * X * Y;
-    const float *pr = res + smp * vol;
-    const unsigned int *pm = segmax + (long long)smp * X * nseg;
-    const int total = X * nseg;
+    const float *pr = res + smp * row_stride;
+    const unsigned int *pm = segmax + (long long)smp * total;
+    const int per_chunk = X * nseg;
     const unsigned int NANBITS = 0x7fc00000u;
 
     // upper bound of a segment's scores as a bit pattern (NaN above everything: "must be read")
     auto bound = [&](int j) __attribute__((always_inline)) {
+        const float sm = segmin[j];
+        if (sm == 0.f) return NANBITS;                            // a NaN or zero modulation inside: 0/0 and x/NaN are NaN
         const unsigned int mx = pm[j];
-        if (mx == 0u) return 0u;                                  // rim row / nothing in it
-        const float q = __uint_as_float(mx) / segmin[j];          // mx NaN, segmin 0 -> inf or NaN
+        if (mx == 0u) return 0u;                                  // rim row / all residuals zero over positive modulations
+        const float q = __uint_as_float(mx) / sm;                 // mx NaN -> NaN
         return q != q ? NANBITS : __float_as_uint(q);
     };
     // exact maximum of |r| / mod over one segment, by the whole block
     auto evaluate = [&](int j) __attribute__((always_inline)) {
-        const int x = j / nseg, y0 = (j - x * nseg) * JP_SEG;
-        const int planes = T - 2 * ct;
+        const int tc = j / per_chunk, r = j - tc * per_chunk, x = r / nseg, y0 = (r - x * nseg) * JP_SEG;
+        const int t0 = tc * MS_TMAX, planes = min(MS_TMAX, T - t0);
         unsigned int m = 0u;
         for (int k = tid; k < planes * JP_SEG; k += 256) {
-            const int t = ct + k / JP_SEG, y = y0 + (k & (JP_SEG - 1));
+            const int t = t0 + k / JP_SEG, y = y0 + (k & (JP_SEG - 1));
             if (y >= cy && y < Y - cy) {
                 const long long o = ((long long)t * X + x) * Y + y;
                 const float q = fabsf(pr[o]) / mod[o];
@@ -397,14 +445,9 @@ __global__ void __launch_bounds__(256) joint_score_pruned_kernel(const float *__
     if ((tid & 63) == 0) { red[tid >> 6] = bb; redi[tid >> 6] = bj; }
     if (tid == 0) nwork = 0u;
     __syncthreads();
+    bb = red[0], bj = redi[0];                                    // (every thread the same)
     for (int w = 1; w < 4; ++w)
-        if (red[w] > red[0] || (red[w] == red[0] && redi[w] < redi[0])) { bb = red[w]; bj = redi[w]; }   // (every thread the same)
-    {
-        unsigned int gb = red[0], gj = redi[0];
-        for (int w = 1; w < 4; ++w)
-            if (red[w] > gb || (red[w] == gb && redi[w] < gj)) { gb = red[w]; gj = redi[w]; }
-        bb = gb; bj = gj;
-    }
+        if (red[w] > bb || (red[w] == bb && redi[w] < bj)) { bb = red[w]; bj = redi[w]; }
     unsigned int best = __float_as_uint(scores[smp]);            // earlier slabs (non-negative or NaN: orders as uint)
     if (bb == 0u) return;                                         // nothing scored in this slab (block-uniform)
     if (bb > best) best = max(best, evaluate((int)bj));
@@ -660,20 +703,28 @@ int pre_moments_axis0_f64(const float *a, const float *b, int64_t n, int64_t M, 
     return PRE_OK;
 }
 
-int pre_moments_segmax_f64(const float *a, int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y, double *sum,
-                           double *sumsq, uint32_t *segmax, void *stream)
+int pre_moments_segmax_f64(const float *a, int64_t row_stride, int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y,
+                           double *sum, double *sumsq, uint32_t *segmax, void *stream)
 {
     if (!a || !sum || !sumsq || !segmax || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
-    if (crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
-    if (T > MS_TMAX || Y % 64 != 0 || (X * Y) % 256 != 0) return PRE_E_UNSUPPORTED;      // caller: plain moments + plain score
-    if (n > 0x7fffffff || X * Y > 0x7fffffffLL * 256) return PRE_E_SHAPE;
-    const long long bx = X * Y / 256;
+    if (crop_x < 0 || crop_y < 0 || row_stride < T * X * Y) return PRE_E_RANGE;
+    if (Y % 64 != 0 || (X * Y) % 256 != 0) return PRE_E_UNSUPPORTED;                      // caller: plain moments + plain score
+    const long long bx = X * Y / 256, TC = (T + MS_TMAX - 1) / MS_TMAX;
+    if (n > 0x7fffffff || bx > 0x7fffffffLL || TC > 65535 || T > 0x7fffffff) return PRE_E_SHAPE;
+    const int us = T == 1 ? 16 : T <= 4 ? 4 : 1;
     long long splits = 1;
-    while (bx * splits < 1024 && splits * 32 < n) splits *= 2;
+    const long long want = us > 1 ? 2048 : 1024;          // (the few-plane forms run 8 waves per SIMD)
+    while (bx * TC * splits < want && splits * 32 * us < n) splits *= 2;
     const int rows = (int)((n + splits - 1) / splits);
     splits = (n + rows - 1) / rows;
-    hipLaunchKernelGGL(moments_segmax_kernel, dim3((unsigned)bx, (unsigned)splits), dim3(256), 0, as_stream(stream), a, (int)n, (int)T,
-                       (int)X, (int)Y, crop_x, crop_y, rows, sum, sumsq, segmax);
+    const dim3 grid((unsigned)bx, (unsigned)splits, (unsigned)TC);
+#define PRE_MS_LAUNCH(TCH, US)                                                                                                \
+    hipLaunchKernelGGL((moments_segmax_kernel<TCH, US>), grid, dim3(256), 0, as_stream(stream), a, (long long)row_stride, (int)n,    \
+                       (int)T, (int)X, (int)Y, crop_x, crop_y, rows, sum, sumsq, segmax)
+    if (us == 16) PRE_MS_LAUNCH(1, 16);
+    else if (us == 4) PRE_MS_LAUNCH(4, 4);
+    else PRE_MS_LAUNCH(MS_TMAX, 1);
+#undef PRE_MS_LAUNCH
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }
@@ -725,28 +776,29 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod, int64_
     return PRE_OK;
 }
 
-int pre_segmin_mod_f32(const float *mod, int64_t T, int64_t X, int64_t Y, int crop_t, int crop_x, int crop_y, float *segmin,
-                       void *stream)
+int pre_segmin_mod_f32(const float *mod, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y, float *segmin, void *stream)
 {
     if (!mod || !segmin || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
-    if (crop_t < 0 || crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
-    const long long nseg = (Y + JP_SEG - 1) / JP_SEG;
-    if (X > 0x7fffffff || nseg > 65535 || T > 0x7fffffff) return PRE_E_SHAPE;
-    hipLaunchKernelGGL(segmin_kernel, dim3((unsigned)X, (unsigned)nseg), dim3(64), 0, as_stream(stream), mod, (int)T, (int)X, (int)Y,
-                       crop_t, crop_x, crop_y, (int)nseg, segmin);
+    if (crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
+    const long long nseg = (Y + JP_SEG - 1) / JP_SEG, TC = (T + MS_TMAX - 1) / MS_TMAX;
+    if (X > 0x7fffffff || nseg > 65535 || TC > 65535) return PRE_E_SHAPE;
+    hipLaunchKernelGGL(segmin_kernel, dim3((unsigned)X, (unsigned)nseg, (unsigned)TC), dim3(64), 0, as_stream(stream), mod, (int)T,
+                       (int)X, (int)Y, crop_x, crop_y, (int)nseg, segmin);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }
 
-int pre_joint_score_pruned_f32(const float *res, const float *mod, const uint32_t *segmax, const float *segmin, int64_t n,
-                               int64_t T, int64_t X, int64_t Y, int crop_t, int crop_x, int crop_y, float *scores, void *stream)
+int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float *mod, const uint32_t *segmax, const float *segmin,
+                               int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y, float *scores, void *stream)
 {
     if (!res || !mod || !segmax || !segmin || !scores || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
-    if (crop_t < 0 || crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
-    const long long nseg = (Y + JP_SEG - 1) / JP_SEG, total = X * nseg;
-    if (n > 0x7fffffff || total * 4 > 150 * 1024 || T > 0x7fffffff) return PRE_E_SHAPE;      // the work list lives in LDS
-    hipLaunchKernelGGL(joint_score_pruned_kernel, dim3((unsigned)n), dim3(256), (size_t)total * 4, as_stream(stream), res, mod,
-                       segmax, segmin, (int)T, (int)X, (int)Y, crop_t, crop_x, crop_y, (int)nseg, scores);
+    if (crop_x < 0 || crop_y < 0 || row_stride < T * X * Y) return PRE_E_RANGE;
+    const long long nseg = (Y + JP_SEG - 1) / JP_SEG, TC = (T + MS_TMAX - 1) / MS_TMAX, total = TC * X * nseg;
+    if (n > 0x7fffffff || T > 0x7fffffff) return PRE_E_SHAPE;
+    if (total * 4 > 64 * 1024) return PRE_E_UNSUPPORTED;                                  // the work list lives in LDS
+    hipLaunchKernelGGL(joint_score_pruned_kernel, dim3((unsigned)n), dim3(256), (size_t)total * 4, as_stream(stream), res,
+                       (long long)row_stride, mod, segmax, segmin, (int)T, (int)X, (int)Y, crop_x, crop_y, (int)nseg, (int)total,
+                       scores);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }

@@ -84,39 +84,47 @@ class HipOps:
             _lib.check(_lib.load().pre_joint_score_f32(_lib.ptr(res), None, _lib.ptr(mod), n, T, X, Y, ct, cx, cy,
                                                        _lib.ptr(scores), _lib.stream()), "pre_joint_score_f32")
 
+    PRUNE_MIN_CELLS = 1 << 22      # below this the whole joint calibration is a few launch latencies either way
+
     @staticmethod
     def can_prune(res, crop):
-        """The branch-and-bound score needs a contiguous [n,T,X,Y] slab whose planes all count (no t crop), at most 16
-        of them, and whole 64-column segments."""
-        return (res.dim() == 4 and res.is_contiguous() and crop[0] == 0 and res.shape[1] <= 16 and res.shape[3] % 64 == 0
-                and (res.shape[2] * res.shape[3]) % 256 == 0)
+        """The branch-and-bound score takes a contiguous [n,T,X,Y] tensor with whole 64-column segments (Ny % 64 == 0,
+        Nx*Ny % 256 == 0), at least one plane inside the t crop, and at most 16384 segments of 16 planes x 64 columns
+        per sample (its work list lives in LDS)."""
+        if res.dim() != 4 or not res.is_contiguous() or res.numel() < HipOps.PRUNE_MIN_CELLS:
+            return False
+        T, X, Y = res.shape[1:]
+        planes = T - 2 * crop[0]
+        return planes >= 1 and Y % 64 == 0 and (X * Y) % 256 == 0 and ((planes + 15) // 16) * X * (Y // 64) <= 16384
 
     @staticmethod
     def add_moments_segmax(res, mom, crop):
-        """``add_moments`` + from the same read the per-(sample, row, 64-column segment) maxima of |res|, cells within
-        ``crop`` of the x / y rim excluded: int32 [n, X, Y/64] (bit patterns) for ``max_scores_pruned``."""
+        """``add_moments(res, mom, skip_t=crop[0])`` + from the same read the maxima of |res| per sample and segment
+        (16 planes x one row x 64 columns of the planes inside the t crop; cells within ``crop`` of the x / y rim
+        excluded): int32 bit patterns [n, ceil(planes/16), X, Y/64] for ``max_scores_pruned``."""
         n, (T, X, Y) = res.shape[0], res.shape[1:]
-        segmax = torch.empty(n, X, Y // 64, dtype=torch.int32, device=res.device)
+        planes = T - 2 * crop[0]
+        segmax = torch.empty(n, (planes + 15) // 16, X, Y // 64, dtype=torch.int32, device=res.device)
         with torch.cuda.device(res.device):
-            _lib.check(_lib.load().pre_moments_segmax_f64(_lib.ptr(res), n, T, X, Y, crop[1], crop[2], _lib.ptr(mom[0]),
-                                                          _lib.ptr(mom[1]), _lib.ptr(segmax), _lib.stream()),
-                       "pre_moments_segmax_f64")
+            _lib.check(_lib.load().pre_moments_segmax_f64(_lib.ptr(res[:, crop[0]:]), res.stride(0), n, planes, X, Y, crop[1],
+                                                          crop[2], _lib.ptr(mom[0]), _lib.ptr(mom[1]), _lib.ptr(segmax),
+                                                          _lib.stream()), "pre_moments_segmax_f64")
         return segmax
 
     @staticmethod
     def max_scores_pruned(res, mod, segmax, crop, scores):
-        """Branch-and-bound form of ``max_scores`` for the slab ``add_moments_segmax`` just read: same scores, bit for
+        """Branch-and-bound form of ``max_scores`` for the tensor ``add_moments_segmax`` just read: same scores, bit for
         bit, but only the segments whose bound (max |res| / min mod) exceeds a sample's best score so far are read."""
         n, (T, X, Y) = res.shape[0], res.shape[1:]
-        nseg = (Y + 63) // 64
-        segmin = torch.empty(X, nseg, dtype=torch.float32, device=res.device)
+        planes, mod_in = T - 2 * crop[0], mod[crop[0]:]
+        segmin = torch.empty(segmax.shape[1:], dtype=torch.float32, device=res.device)
         lib = _lib.load()
         with torch.cuda.device(res.device):
-            _lib.check(lib.pre_segmin_mod_f32(_lib.ptr(mod), T, X, Y, crop[0], crop[1], crop[2], _lib.ptr(segmin), _lib.stream()),
+            _lib.check(lib.pre_segmin_mod_f32(_lib.ptr(mod_in), planes, X, Y, crop[1], crop[2], _lib.ptr(segmin), _lib.stream()),
                        "pre_segmin_mod_f32")
-            _lib.check(lib.pre_joint_score_pruned_f32(_lib.ptr(res), _lib.ptr(mod), _lib.ptr(segmax), _lib.ptr(segmin), n, T, X, Y,
-                                                      crop[0], crop[1], crop[2], _lib.ptr(scores), _lib.stream()),
-                       "pre_joint_score_pruned_f32")
+            _lib.check(lib.pre_joint_score_pruned_f32(_lib.ptr(res[:, crop[0]:]), res.stride(0), _lib.ptr(mod_in), _lib.ptr(segmax),
+                                                      _lib.ptr(segmin), n, planes, X, Y, crop[1], crop[2], _lib.ptr(scores),
+                                                      _lib.stream()), "pre_joint_score_pruned_f32")
 
     @staticmethod
     def kth(scores, ks):
@@ -150,9 +158,9 @@ class JointCalibration:
         """``res``: UNCROPPED residual slab [n_local, T_slab, X, Y]; ``crop`` cells per side are excluded
         from the score (the reference's ``[...,1:-1,1:-1,1:-1]``).  The t-rim planes may hold garbage
         (``PRE_FLAG_INTERIOR_T``): they are neither reduced nor scored.
-        When the slab allows it (``HipOps.can_prune``: contiguous, no t crop, <= 16 planes, Ny % 64 == 0) the moments
-        pass also delivers per-segment maxima of |res| and the score pass reads only the segments that can still raise
-        a sample's score - the same scores bit for bit (``prune=False`` forces the full pass)."""
+        When the slab allows it (``HipOps.can_prune``: contiguous, Ny % 64 == 0, ...) the moments pass also delivers
+        per-segment maxima of |res| and the score pass reads only the segments that can still raise a sample's
+        score - the same scores bit for bit (``prune=False`` forces the full pass)."""
         ops = self.ops
         M = res[0].numel() if hasattr(res[0], "numel") else res[0].size
         skip = crop[0] if (getattr(ops, "interior_t", False) and crop[0] > 0 and res.is_contiguous()
@@ -161,7 +169,7 @@ class JointCalibration:
         mom = ops.zeros_moments(M - 2 * skip * (M // res.shape[1]), self.device)
         segmax = None
         if self.prune and getattr(ops, "can_prune", None) and ops.can_prune(res, crop):
-            segmax = ops.add_moments_segmax(res, mom, crop)
+            segmax = ops.add_moments_segmax(res, mom, crop)              # (skip == crop[0] here)
         else:
             ops.add_moments(res, mom, **kw)
         if self.group is not None:

@@ -557,62 +557,75 @@ def test_joint_score_propagates_nan_like_numpy(gpu):
         assert np.isnan(icp.calibrate(ref2, n, 0.1)) and np.isnan(np.quantile(ref2, 0.5, method="higher"))
 
 
-@pytest.mark.parametrize("shape", [(37, 5, 24, 256), (16, 3, 8, 192), (64, 8, 40, 512), (9, 16, 12, 320)])
-def test_pruned_joint_score_equals_full_pass(gpu, shape):
+@pytest.mark.parametrize("shape,crop", [((37, 5, 24, 256), (0, 1, 1)), ((16, 3, 8, 192), (0, 1, 1)), ((64, 8, 40, 512), (0, 1, 1)),
+                                        ((9, 16, 12, 320), (0, 1, 1)), ((21, 40, 8, 128), (1, 1, 1)), ((70, 1, 36, 256), (0, 1, 1)),
+                                        ((12, 19, 4, 64), (2, 0, 3)), ((33, 4, 16, 64), (1, 1, 1))])
+def test_pruned_joint_score_equals_full_pass(gpu, shape, crop, monkeypatch):
     """Branch-and-bound joint score (segment maxima from the fused moments pass + pre_joint_score_pruned_f32) against the
     full pass: identical moments, identical scores for the same modulation, identical q-hat, slab after slab; the
     segment maxima themselves against torch; a NaN residual, a zero-modulation cell, an outlier sample and a sample
-    that is zero everywhere."""
+    that is zero everywhere.  Shapes: the C3 slab form (<= 16 planes, no t crop), several 16-plane chunks with a t crop
+    (C4), one plane (C5 arrives as [n,1,Nt,Nx]) and the 4-plane form."""
     from cp_pre_amd import pipeline
-    from cp_pre_amd.residuals import NavierStokes
     B, T, X, Y = shape
+    ct, cx, cy = crop
     g = torch.Generator().manual_seed(sum(shape))
-    ns = NavierStokes(0.01, 1.0 / X, 1.0 / Y)
     alphas = [0.1, 0.5, 0.9]
     ops = pipeline.HipOps
-    crop = (0, 1, 1)
+    monkeypatch.setattr(ops, "PRUNE_MIN_CELLS", 0)
     full_jc, pruned_jc = pipeline.JointCalibration(B, gpu, prune=False), pipeline.JointCalibration(B, gpu)
+    planes = T - 2 * ct
+    TC = (planes + 15) // 16
     for slab in range(3):
-        v = (torch.rand(B, 3, T + 2, X, Y, generator=g) + 0.5).to(gpu)
+        res = (torch.randn(B, T, X, Y, generator=g) * (0.5 + torch.rand(T, X, Y, generator=g))).to(gpu)
         if slab == 1:
-            v[3, :, :, 5:9, 70:140] += 40.0                               # an outlier sample
-            v[5] = 1.0                                                    # residual exactly zero everywhere
+            res[3, :, X // 2:X // 2 + 2, 70 % Y:] *= 40.0                  # an outlier sample
+            res[5] = 0.0                                                  # residual exactly zero everywhere
         if slab == 2 and B > 10:
-            v[7, 0, 2, 4, 100] = float("nan")
-        inner = torch.empty(B, T, X, Y, device=gpu)
-        ns.residual_momentum(v, boundary=True, out=inner, skip_t_rim=True)
+            res[7, T // 2, X // 2, 40] = float("nan")
         if slab == 0:
-            inner[:, :, 3, 77] = 0.0                                      # a constant cell: modulation 0 there
-        assert ops.can_prune(inner, crop)
-        # fused moments + segment maxima == plain moments, and the maxima against torch
-        m_ref, m_new = ops.zeros_moments(T * X * Y, gpu), ops.zeros_moments(T * X * Y, gpu)
-        ops.add_moments(inner, m_ref)
-        segmax = ops.add_moments_segmax(inner, m_new, crop)
-        assert torch.equal(torch.nan_to_num(m_ref, nan=7.0), torch.nan_to_num(m_new, nan=7.0))
-        a = inner.abs()
-        a[..., 0] = 0.0
-        a[..., -1] = 0.0
-        ref = a.view(B, T, X, Y // 64, 64)
-        ref = torch.where(torch.isnan(ref).any(-1).any(1), torch.full((), float("nan"), device=gpu), ref.amax(-1).amax(1))
-        ref[:, 0] = 0.0
-        ref[:, -1] = 0.0
+            res[:, :, min(3, X - 1), 13] = 0.25                           # a constant cell: modulation 0 there
+        assert ops.can_prune(res, crop)
+        # fused moments + segment maxima == plain moments (over the planes inside the t crop), maxima against torch
+        cells = planes * X * Y
+        m_ref, m_new = ops.zeros_moments(cells, gpu), ops.zeros_moments(cells, gpu)
+        ops.add_moments(res, m_ref, skip_t=ct)
+        segmax = ops.add_moments_segmax(res, m_new, crop)
+        assert tuple(segmax.shape) == (B, TC, X, Y // 64)
+        # (fp64 sums of fp32 values: equal up to the order of the additions)
+        assert torch.allclose(m_ref, m_new, rtol=1e-13, atol=0.0, equal_nan=True)
+        a = res[:, ct:T - ct].abs()
+        if cy:
+            a[..., :cy] = 0.0
+            a[..., Y - cy:] = 0.0
+        if cx:
+            a[:, :, :cx] = 0.0
+            a[:, :, X - cx:] = 0.0
+        a = torch.nn.functional.pad(a.permute(0, 2, 3, 1), (0, TC * 16 - planes)).view(B, X, Y // 64, 64, TC, 16)
+        nanseg = torch.isnan(a).any(-1).any(3)                                             # [B, X, nseg, TC]
+        ref = torch.where(nanseg, torch.full((), float("nan"), device=gpu), torch.nan_to_num(a, nan=0.0).amax(-1).amax(3))
+        ref = ref.permute(0, 3, 1, 2)
         assert torch.equal(torch.nan_to_num(segmax.view(torch.float32), nan=-5.0), torch.nan_to_num(ref, nan=-5.0)), (slab, shape)
         # same modulation -> same scores, accumulated over the slabs
-        mod = ops.std_from_moments(m_ref, B, (T, X, Y), 0.0, like=inner)
+        mod = ops.std_from_moments(m_ref, B, (T, X, Y), 0.0, like=res, skip_t=ct)
         s_full, s_pr = full_jc.scores.clone(), full_jc.scores.clone()
-        ops.max_scores(inner, mod, crop, s_full)
-        ops.max_scores_pruned(inner, mod, segmax, crop, s_pr)
+        ops.max_scores(res, mod, crop, s_full)
+        ops.max_scores_pruned(res, mod, segmax, crop, s_pr)
         assert torch.equal(torch.nan_to_num(s_full, nan=-1.0), torch.nan_to_num(s_pr, nan=-1.0)), (slab, shape, s_full, s_pr)
         # and through the drivers
-        m1 = full_jc.add_slab(inner, crop=crop)
-        m2 = pruned_jc.add_slab(inner, crop=crop)
-        assert torch.equal(torch.nan_to_num(m1, nan=1.0), torch.nan_to_num(m2, nan=1.0))
-        assert torch.equal(torch.nan_to_num(full_jc.scores, nan=-1.0), torch.nan_to_num(pruned_jc.scores, nan=-1.0))
+        m1 = full_jc.add_slab(res, crop=crop)
+        m2 = pruned_jc.add_slab(res, crop=crop)
+        assert torch.allclose(m1, m2, rtol=1e-6, atol=0.0, equal_nan=True)
+        assert torch.allclose(full_jc.scores, pruned_jc.scores, rtol=1e-5, atol=0.0, equal_nan=True)
     q1, q2 = full_jc.finish(alphas), pruned_jc.finish(alphas)
-    assert torch.equal(torch.nan_to_num(q1, nan=-1.0), torch.nan_to_num(q2, nan=-1.0))
-    # slabs the pruned form does not take fall back silently: 17 planes, a t crop, Ny not a multiple of 64
-    assert not ops.can_prune(torch.empty(2, 17, 8, 64, device=gpu), crop) and not ops.can_prune(inner, (1, 1, 1))
-    assert not ops.can_prune(torch.empty(2, 4, 8, 96, device=gpu), crop)
+    assert torch.allclose(q1, q2, rtol=1e-5, atol=0.0, equal_nan=True)
+    # tensors the pruned form does not take fall back silently: Ny not a multiple of 64, no plane inside the crop, too
+    # many segments, a strided view; and small tensors by default
+    assert not ops.can_prune(torch.empty(2, 4, 8, 96, device=gpu), crop) and not ops.can_prune(res, (T, 1, 1))
+    assert not ops.can_prune(torch.empty(1, 16 * 65, 256, 64, device=gpu), (0, 0, 0))
+    assert not ops.can_prune(res.transpose(2, 3), crop)
+    monkeypatch.undo()
+    assert not ops.can_prune(res[:1, :1], (0, cx, cy))
 
 
 def test_scalar_kth_large_and_absdiff(gpu):
