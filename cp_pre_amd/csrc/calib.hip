@@ -387,15 +387,15 @@ __global__ void __launch_bounds__(64) segmin_kernel(const float *__restrict__ mo
     if (threadIdx.x == 0) segmin[((long long)tc * X + x) * nseg + seg] = bad ? 0.f : m;
 }
 
-__global__ void __launch_bounds__(256) joint_score_pruned_kernel(const float *__restrict__ res, long long row_stride,
-                                                                 const float *__restrict__ mod,
-                                                                 const unsigned int *__restrict__ segmax,
-                                                                 const float *__restrict__ segmin, int T, int X, int Y, int cx,
-                                                                 int cy, int nseg, int total, float *__restrict__ scores)
+__global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *__restrict__ res, long long row_stride,
+                                                                  const float *__restrict__ mod,
+                                                                  const unsigned int *__restrict__ segmax,
+                                                                  const float *__restrict__ segmin, int T, int X, int Y, int cx,
+                                                                  int cy, int nseg, int total, float *__restrict__ scores)
 {
     extern __shared__ unsigned int work[];                        // `total` = TC * X * nseg segment ids
-    __shared__ unsigned int red[4], redi[4], nwork;
-    const int smp = blockIdx.x, tid = threadIdx.x;
+    __shared__ unsigned int red[16], redi[16], nwork, sbest;
+    const int smp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const float *pr = res + smp * row_stride;
     const unsigned int *pm = segmax + (long long)smp * total;
     const int per_chunk = X * nseg;
@@ -410,30 +410,32 @@ __global__ void __launch_bounds__(256) joint_score_pruned_kernel(const float *__
         const float q = __uint_as_float(mx) / sm;                 // mx NaN -> NaN
         return q != q ? NANBITS : __float_as_uint(q);
     };
-    // exact maximum of |r| / mod over one segment, by the whole block
+    // exact maximum of |r| / mod over one segment, by one wave (a lane per column, up to 16 planes in flight)
     auto evaluate = [&](int j) __attribute__((always_inline)) {
-        const int tc = j / per_chunk, r = j - tc * per_chunk, x = r / nseg, y0 = (r - x * nseg) * JP_SEG;
+        const int tc = j / per_chunk, r = j - tc * per_chunk, x = r / nseg, y = (r - x * nseg) * JP_SEG + lane;
         const int t0 = tc * MS_TMAX, planes = min(MS_TMAX, T - t0);
         unsigned int m = 0u;
-        for (int k = tid; k < planes * JP_SEG; k += 256) {
-            const int t = t0 + k / JP_SEG, y = y0 + (k & (JP_SEG - 1));
-            if (y >= cy && y < Y - cy) {
-                const long long o = ((long long)t * X + x) * Y + y;
-                const float q = fabsf(pr[o]) / mod[o];
-                m = max(m, q != q ? NANBITS : __float_as_uint(q));
-            }
+        if (y >= cy && y < Y - cy) {
+            const long long o = ((long long)t0 * X + x) * Y + y, plane = (long long)X * Y;
+            float rv[MS_TMAX], mv[MS_TMAX];
+#pragma unroll
+            for (int t = 0; t < MS_TMAX; ++t)
+                if (t < planes) { rv[t] = pr[o + t * plane]; mv[t] = mod[o + t * plane]; }
+#pragma unroll
+            for (int t = 0; t < MS_TMAX; ++t)
+                if (t < planes) {
+                    const float q = fabsf(rv[t]) / mv[t];
+                    m = max(m, q != q ? NANBITS : __float_as_uint(q));
+                }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o));
-        __syncthreads();                                          // red is free again
-        if ((tid & 63) == 0) red[tid >> 6] = m;
-        __syncthreads();
-        return max(max(red[0], red[1]), max(red[2], red[3]));
+        return m;
     };
 
-    // (1) the segment with the largest bound
+    // (1) the segment with the largest bound: evaluated first, so that most of the others never are
     unsigned int bb = 0u, bj = 0u;
-    for (int j = tid; j < total; j += 256) {
+    for (int j = tid; j < total; j += blockDim.x) {
         const unsigned int b = bound(j);
         if (b > bb) { bb = b; bj = (unsigned)j; }
     }
@@ -442,25 +444,33 @@ __global__ void __launch_bounds__(256) joint_score_pruned_kernel(const float *__
         const unsigned int ob = (unsigned int)__shfl_xor((int)bb, o), oj = (unsigned int)__shfl_xor((int)bj, o);
         if (ob > bb || (ob == bb && oj < bj)) { bb = ob; bj = oj; }
     }
-    if ((tid & 63) == 0) { red[tid >> 6] = bb; redi[tid >> 6] = bj; }
+    if (lane == 0) { red[wave] = bb; redi[wave] = bj; }
     if (tid == 0) nwork = 0u;
     __syncthreads();
     bb = red[0], bj = redi[0];                                    // (every thread the same)
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < nwaves; ++w)
         if (red[w] > bb || (red[w] == bb && redi[w] < bj)) { bb = red[w]; bj = redi[w]; }
     unsigned int best = __float_as_uint(scores[smp]);            // earlier slabs (non-negative or NaN: orders as uint)
     if (bb == 0u) return;                                         // nothing scored in this slab (block-uniform)
-    if (bb > best) best = max(best, evaluate((int)bj));
+    if (bb > best) best = max(best, evaluate((int)bj));          // (every wave evaluates it: no exchange needed)
     // (2) every other segment that can still beat it
-    for (int j = tid; j < total; j += 256)
+    for (int j = tid; j < total; j += blockDim.x)
         if ((unsigned)j != bj && bound(j) > best) work[atomicAdd(&nwork, 1u)] = (unsigned)j;
+    if (tid == 0) sbest = best;
     __syncthreads();
+    // the waves share the list; the best score so far is shared through LDS (it only grows, and skipping a segment
+    // whose bound does not exceed ANY score already seen is always safe)
     const unsigned int nw = nwork;
-    for (unsigned int i = 0; i < nw; ++i) {
+    for (unsigned int i = wave; i < nw; i += nwaves) {
         const int j = (int)work[i];
-        if (bound(j) > best) best = max(best, evaluate(j));      // (block-uniform: best and the bound are)
+        best = max(best, *(volatile unsigned int *)&sbest);
+        if (bound(j) > best) {                                    // (wave-uniform)
+            const unsigned int v = evaluate(j);
+            if (v > best) { best = v; if (lane == 0) atomicMax(&sbest, v); }
+        }
     }
-    if (tid == 0) atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, best);
+    __syncthreads();
+    if (tid == 0) atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, max(best, sbest));
 }
 
 // ------------------------------------------------------------------ scalar k-th (radix select)
@@ -796,7 +806,9 @@ int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float
     const long long nseg = (Y + JP_SEG - 1) / JP_SEG, TC = (T + MS_TMAX - 1) / MS_TMAX, total = TC * X * nseg;
     if (n > 0x7fffffff || T > 0x7fffffff) return PRE_E_SHAPE;
     if (total * 4 > 64 * 1024) return PRE_E_UNSUPPORTED;                                  // the work list lives in LDS
-    hipLaunchKernelGGL(joint_score_pruned_kernel, dim3((unsigned)n), dim3(256), (size_t)total * 4, as_stream(stream), res,
+    // a block per sample: few samples get more waves each to work through their lists
+    const int threads = n >= 2048 ? 256 : n >= 512 ? 512 : 1024;
+    hipLaunchKernelGGL(joint_score_pruned_kernel, dim3((unsigned)n), dim3(threads), (size_t)total * 4, as_stream(stream), res,
                        (long long)row_stride, mod, segmax, segmin, (int)T, (int)X, (int)Y, crop_x, crop_y, (int)nseg, (int)total,
                        scores);
     PRE_LAUNCH_CHECK();

@@ -84,14 +84,18 @@ class HipOps:
             _lib.check(_lib.load().pre_joint_score_f32(_lib.ptr(res), None, _lib.ptr(mod), n, T, X, Y, ct, cx, cy,
                                                        _lib.ptr(scores), _lib.stream()), "pre_joint_score_f32")
 
-    PRUNE_MIN_CELLS = 1 << 22      # below this the whole joint calibration is a few launch latencies either way
+    # measured (profiles/r02/prune_ab.txt): the pruned form pays from a few hundred samples and ~1e8 cells on; below,
+    # the joint calibration is a few launch latencies either way and sigma-hat is too noisy for tight bounds
+    PRUNE_MIN_CELLS = 1 << 27
+    PRUNE_MIN_SAMPLES = 256
 
     @staticmethod
     def can_prune(res, crop):
         """The branch-and-bound score takes a contiguous [n,T,X,Y] tensor with whole 64-column segments (Ny % 64 == 0,
         Nx*Ny % 256 == 0), at least one plane inside the t crop, and at most 16384 segments of 16 planes x 64 columns
         per sample (its work list lives in LDS)."""
-        if res.dim() != 4 or not res.is_contiguous() or res.numel() < HipOps.PRUNE_MIN_CELLS:
+        if (res.dim() != 4 or not res.is_contiguous() or res.numel() < HipOps.PRUNE_MIN_CELLS
+                or res.shape[0] < HipOps.PRUNE_MIN_SAMPLES):
             return False
         T, X, Y = res.shape[1:]
         planes = T - 2 * crop[0]

@@ -573,6 +573,7 @@ def test_pruned_joint_score_equals_full_pass(gpu, shape, crop, monkeypatch):
     alphas = [0.1, 0.5, 0.9]
     ops = pipeline.HipOps
     monkeypatch.setattr(ops, "PRUNE_MIN_CELLS", 0)
+    monkeypatch.setattr(ops, "PRUNE_MIN_SAMPLES", 0)
     full_jc, pruned_jc = pipeline.JointCalibration(B, gpu, prune=False), pipeline.JointCalibration(B, gpu)
     planes = T - 2 * ct
     TC = (planes + 15) // 16
@@ -625,7 +626,7 @@ def test_pruned_joint_score_equals_full_pass(gpu, shape, crop, monkeypatch):
     assert not ops.can_prune(torch.empty(1, 16 * 65, 256, 64, device=gpu), (0, 0, 0))
     assert not ops.can_prune(res.transpose(2, 3), crop)
     monkeypatch.undo()
-    assert not ops.can_prune(res[:1, :1], (0, cx, cy))
+    assert not ops.can_prune(res, crop)
 
 
 def test_scalar_kth_large_and_absdiff(gpu):
