@@ -6,10 +6,12 @@ import torch
 from cp_pre_amd import pipeline
 
 
-def bench(n, shape, prune, reps=20):
+def bench(n, shape, prune, reps=20, wild=False):
     dev = torch.device("cuda:0")
     torch.manual_seed(n + shape[0])
     res = torch.randn(n, *shape, device=dev)
+    if wild:            # worst case for the bounds: the scale changes by orders of magnitude from cell to cell
+        res *= torch.exp(3.0 * torch.randn(*shape, device=dev))
     al = [0.1 * k + 0.05 for k in range(10)]
 
     def once():
@@ -34,5 +36,10 @@ if __name__ == "__main__":
                 continue
             a, qa = bench(n, shape, False)
             b, qb = bench(n, shape, True)
+            if n >= 1000:
+                aw, qaw = bench(n, shape, False, wild=True)
+                bw, qbw = bench(n, shape, True, wild=True)
+                print(f"n={n:5d} {list(shape)!s:16s} WILD per-cell scale e^(3 N(0,1))          full {aw:8.3f} ms  pruned {bw:8.3f} ms  "
+                      f"x{aw/bw:5.2f}  same={bool(torch.allclose(qaw, qbw, rtol=1e-5, equal_nan=True))}", flush=True)
             print(f"n={n:5d} {list(shape)!s:16s} cells={n*shape[0]*shape[1]*shape[2]:>12d}  full {a:8.3f} ms  pruned {b:8.3f} ms  x{a/b:5.2f}  "
                   f"same={bool(torch.allclose(qa, qb, rtol=1e-5, equal_nan=True))}", flush=True)
