@@ -62,7 +62,8 @@ def counters(src):
     return res
 
 
-OURS = ("march_kernel", "moments_kernel", "joint_score_kernel", "std_from_moments_kernel", "kth_")
+OURS = ("march_kernel", "moments_kernel", "moments_segmax_kernel", "joint_score_kernel", "joint_score_pruned_kernel", "segmin_kernel",
+        "std_from_moments_kernel", "kth_")
 sys.path.insert(0, os.getcwd())
 import bench                                             # split_slabs / CONFIGS: the workloads the passes ran
 
