@@ -1439,6 +1439,7 @@ def _sharded_worker(rank, world, port, n_local, shape, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda:0")
+        pipeline.HipOps.PRUNE_MIN_CELLS = pipeline.HipOps.PRUNE_MIN_SAMPLES = 0      # the shards take the branch-and-bound score
         full = torch.from_numpy(np.load(os.path.join(out_dir, "res.npy")))
         mine = full[rank * n_local:(rank + 1) * n_local].to(dev)
         alphas = [0.1, 0.3, 0.5, 0.7, 0.9]
@@ -1457,7 +1458,8 @@ def _sharded_worker(rank, world, port, n_local, shape, out_dir):
 @pytest.mark.timeout(300)
 def test_sharded_calibration_two_ranks_on_one_gpu(gpu, tmp_path):
     """Joint (all-reduce of moments + all-gather of scores) and marginal (all-to-all in bounded runs) calibration
-    with the HIP back end on two batch shards == the single-process result on the whole batch."""
+    with the HIP back end on two batch shards == the single-process result on the whole batch.  The shards score by
+    branch and bound (bounds from the all-reduced modulation), the single process with the full pass."""
     import socket
     import torch.multiprocessing as mp
     from cp_pre_amd import pipeline
@@ -1471,7 +1473,7 @@ def test_sharded_calibration_two_ranks_on_one_gpu(gpu, tmp_path):
     mp.spawn(_sharded_worker, args=(world, port, n_local, shape, str(tmp_path)), nprocs=world, join=True)
     alphas = [0.1, 0.3, 0.5, 0.7, 0.9]
     whole = torch.from_numpy(res).to(gpu)
-    jc = pipeline.JointCalibration(world * n_local, gpu)
+    jc = pipeline.JointCalibration(world * n_local, gpu, prune=False)
     T = shape[0]
     for s in range(2):
         jc.add_slab(whole[:, s * (T - 2) // 2:s * (T - 2) // 2 + (T - 2) // 2 + 2].contiguous(), crop=(1, 1, 1))
