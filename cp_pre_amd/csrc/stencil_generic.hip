@@ -4,8 +4,11 @@
 // pre_stencil3d_f32 first offers the tap list to the streaming star kernel
 // (star_march.hip); tap sets that are not on the 7-point star, views without a unit-stride
 // axis, and the last (extent % 4) columns of an odd-width grid run here:
-// Three forms:
-//   generic_tile_kernel  views with a unit-stride axis of >= 64 cells (relabelled to be the last one): 16 x 256
+// Four forms:
+//   plane_taps_kernel    tap sets on ONE input plane (Taylor-4/6 Laplacians, purely spatial kernels) on views with a
+//                        unit-stride axis of >= 64 cells: a wave marches down the rows of a 256-column strip with the
+//                        rows in a register window;
+//   generic_tile_kernel  other tap sets on such views (axis relabelled to be the last one): 16 x 256
 //                        output tiles, each needed input plane staged once in LDS, taps grouped by row;
 //   flat_taps_kernel     views whose unit-stride axis is short but contiguous with the next one (the surrogate's
 //                        Nt-fastest layout): the two axes merged into one row, chunks of 1024 cells staged in LDS;
@@ -146,6 +149,116 @@ __global__ void __launch_bounds__(256) generic_tile_kernel(const float *__restri
             float *o = out + b * oB + t * oT + x * oX + y;
             if (y + 3 < Y) *reinterpret_cast<G4u *>(o) = G4u{a[k][0], a[k][1], a[k][2], a[k][3]};
             else for (int j = 0; j < Y - y; ++j) o[j] = a[k][j];
+        }
+    }
+}
+
+// ---- single-plane tap sets on a long unit-stride axis: register-window row march ------------------------------
+// The Taylor-4 / Taylor-6 Laplacians (Utils/ConvOps_2d.py:36-62 through kernel_3d: every tap on kernel slab 1) and any
+// purely spatial kernel read ONE input plane per output plane, so the only reuse is along the row axis.  A wave owns a
+// 256-column strip of one plane and marches down its rows, a lane = 4 adjacent columns.  Each input row is loaded once
+// (one 16-byte buffer load per lane; lanes 0 and 63 also fetch the quad left / right of the strip), lives in a register
+// window of 2R+1 rows plus 5-6 rows of lookahead (their loads are in flight while older rows are used) and is never
+// re-read: no LDS, no barrier, no halo rows except at segment ends.  Columns left / right of a lane's quad come from
+// the neighbouring lanes by DPP wavefront shifts.  Zero padding = buffer descriptors whose extent is the row (or 0 for
+// rows / planes outside the domain): out-of-range lanes read 0 and their stores are dropped by the hardware.
+struct PlaneTaps {
+    int d0;                     // offset of the input plane
+    int mask[7];                // per row offset d1 = -3..3: bit k set = tap at d2 = k-3
+    float w[7][7];
+};
+
+typedef float pt_v4 __attribute__((ext_vector_type(4)));
+typedef float pt_v3 __attribute__((ext_vector_type(3)));
+typedef unsigned int pt_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float pt_from_left(float halo, float c)     // lane i <- lane i-1; lane 0 keeps its halo value
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(halo), __float_as_int(c), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float pt_from_right(float halo, float c)    // lane i <- lane i+1; lane 63 keeps its halo value
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(halo), __float_as_int(c), 0x130, 0xf, 0xf, false));
+}
+
+// CROSS: rows d1 != 0 hold at most their centre tap (the Taylor Laplacians, any "plus"-shaped set): straight-line code,
+// every weight of the footprint multiplied (zeros included, as the dense F.conv3d does).  Otherwise per-row masks.
+template <int R, bool CROSS>
+__global__ void __launch_bounds__(256, (R == 1 ? 5 : 4)) plane_taps_kernel(const float *__restrict__ in, long long sB, long long s0,
+                                                                           long long s1, float *__restrict__ out, long long oB,
+                                                                           long long o0, long long o1, int E0, int E1, int E2,
+                                                                           int nstrips, int nseg, int seg, long long units,
+                                                                           int flags, const PlaneTaps taps)
+{
+    constexpr int W = 2 * R + 1, LA = R == 3 ? 5 : 6, NS = W + LA;      // LA rows of lookahead: their loads are in flight
+    const int lane = threadIdx.x & 63;
+    // (readfirstlane: the wave index is uniform, and saying so keeps descriptors, row indices and branches scalar)
+    long long u = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (u >= units) return;
+    const int strip = (int)(u % nstrips);
+    u /= nstrips;
+    const int sg = (int)(u % nseg);
+    u /= nseg;
+    const int e0 = (int)(u % E0), b = (int)(u / E0);
+    const int xs = sg * seg, xe = min(E1, xs + seg);
+    const int pin = e0 + taps.d0;
+    const bool plane_ok = pin >= 0 && pin < E0;
+    const float *ip = in + b * sB + (plane_ok ? pin : 0) * s0;
+    float *op = out + b * oB + e0 * o0;
+    const unsigned int rowbytes = (unsigned)E2 * 4u;
+    const unsigned int voff = (unsigned)(strip * 256 + 4 * lane) * 4u;
+    // the three cells left of the strip for lane 0, right of it for lane 63 (strip 0: wraps to an out-of-range offset -> 0)
+    const unsigned int hoff = lane == 0 ? voff - 12u : lane == 63 ? voff + 16u : 0xfffffff0u;
+
+    pt_v4 C[NS];
+    pt_v3 H[NS];
+    auto load_row = [&](pt_v4 &c, pt_v3 &h, int xr) __attribute__((always_inline)) {
+        const bool ok = plane_ok && xr >= 0 && xr < E1 && xr < xe + R;
+        const __amdgpu_buffer_rsrc_t r =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ip + (ok ? xr : 0) * s1), 0, ok ? rowbytes : 0u, 0x00020000);
+        c = __builtin_bit_cast(pt_v4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+        h = __builtin_bit_cast(pt_v3, __builtin_amdgcn_raw_buffer_load_b96(r, hoff, 0, 0));
+    };
+    // rows xs-R .. xs+R+LA-1 into slots 0 .. NS-2; slot(row) = (row - (xs - R)) mod NS
+#pragma unroll
+    for (int k = 0; k < NS - 1; ++k) load_row(C[k], H[k], xs - R + k);
+
+    for (int xb = xs; xb < xe; xb += NS) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int x = xb + i;
+            if (x < xe) {                                         // (wave-uniform)
+                load_row(C[(i + NS - 1) % NS], H[(i + NS - 1) % NS], x + R + LA);        // into the slot of row x-R-1
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int d = -R; d <= R; ++d) {
+                    const pt_v4 c = C[(i + d + R) % NS];
+                    const int m = CROSS ? (d ? 8 : 0x7f) : taps.mask[d + 3];
+                    if (m == 0) continue;
+                    if (m == 8) {                                 // the centre column only
+                        const float wd = taps.w[d + 3][3];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] += wd * c[j];
+                        continue;
+                    }
+                    const pt_v3 h = H[(i + d + R) % NS];
+                    float e[12] = {0.f, 0.f, 0.f, 0.f, c[0], c[1], c[2], c[3], 0.f, 0.f, 0.f, 0.f};
+                    if (m & 0x07) { e[1] = pt_from_left(h[0], c[1]); e[2] = pt_from_left(h[1], c[2]); e[3] = pt_from_left(h[2], c[3]); }
+                    if (m & 0x70) { e[8] = pt_from_right(h[0], c[0]); e[9] = pt_from_right(h[1], c[1]); e[10] = pt_from_right(h[2], c[2]); }
+#pragma unroll
+                    for (int dd = 0; dd < 7; ++dd)                // d2 = dd - 3, ascending: the dense kernel's tap order
+                        if (m & (1 << dd)) {
+                            const float wd = taps.w[d + 3][dd];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) a[j] += wd * e[1 + dd + j];
+                        }
+                }
+                if (flags & PRE_FLAG_ABS)
+                    for (int j = 0; j < 4; ++j) a[j] = fabsf(a[j]);
+                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(op + x * o1, 0, rowbytes, 0x00020000);
+                const pt_v4 av = {a[0], a[1], a[2], a[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pt_u4, av), ro, voff, 0, 0);
+            }
         }
     }
 }
@@ -414,6 +527,45 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *
                     rows.hi = o1 - 3 > rows.hi ? o1 - 3 : rows.hi;
                     ++rows.n;
                 }
+            // every tap on one input plane, quads aligned: the register-window row march
+            int d0only = 99, r1 = 0;
+            for (int i = 0; i < ntaps; ++i) {
+                const int o0 = tap_off[3 * i + p[0]], o1 = tap_off[3 * i + p[1]];
+                d0only = d0only == 99 || d0only == o0 ? o0 : 100;
+                r1 = (o1 < 0 ? -o1 : o1) > r1 ? (o1 < 0 ? -o1 : o1) : r1;
+            }
+            const long long E0 = D[p[0]], E1 = D[p[1]], E2 = D[p[2]];
+            const bool aligned = E2 % 4 == 0 && !((uintptr_t)in->ptr & 15) && !((uintptr_t)out->ptr & 15) &&
+                                 !((in->sB | si[p[0]] | si[p[1]] | out->sB | so[p[0]] | so[p[1]]) & 3);
+            if (d0only < 99 && aligned && E2 <= (1 << 28)) {
+                PlaneTaps pt;
+                pt.d0 = d0only;
+                for (int o1 = 0; o1 < 7; ++o1) {
+                    pt.mask[o1] = mask[d0only + 3][o1];
+                    for (int d = 0; d < 7; ++d) pt.w[o1][d] = w[d0only + 3][o1][d];
+                }
+                const long long pstrips = (E2 + 255) / 256, units0 = B * E0 * pstrips;
+                long long nseg = (8192 + units0 - 1) / units0;                 // enough waves to fill the chip ...
+                if (nseg > E1 / 32) nseg = E1 / 32;                            // ... from segments of at least 32 rows
+                if (nseg < 1) nseg = 1;
+                const long long seg = (E1 + nseg - 1) / nseg;
+                nseg = (E1 + seg - 1) / seg;
+                const long long units = units0 * nseg, blocks = (units + 3) / 4;
+                if (blocks <= 0x7fffffffLL) {
+#define PRE_PT_LAUNCH(RR, CR)                                                                                                   \
+    hipLaunchKernelGGL((plane_taps_kernel<RR, CR>), dim3((unsigned)blocks), dim3(256), 0, st, in->ptr, (long long)in->sB,          \
+                       (long long)si[p[0]], (long long)si[p[1]], out->ptr, (long long)out->sB, (long long)so[p[0]],               \
+                       (long long)so[p[1]], (int)E0, (int)E1, (int)E2, (int)pstrips, (int)nseg, (int)seg, units, flags, pt)
+                    bool cross = true;
+                    for (int o1 = 0; o1 < 7; ++o1) cross = cross && (o1 == 3 || !(pt.mask[o1] & ~8));
+                    if (r1 <= 1) { if (cross) PRE_PT_LAUNCH(1, true); else PRE_PT_LAUNCH(1, false); }
+                    else if (r1 == 2) { if (cross) PRE_PT_LAUNCH(2, true); else PRE_PT_LAUNCH(2, false); }
+                    else { if (cross) PRE_PT_LAUNCH(3, true); else PRE_PT_LAUNCH(3, false); }
+#undef PRE_PT_LAUNCH
+                    PRE_LAUNCH_CHECK();
+                    return PRE_OK;
+                }
+            }
             const dim3 grid((unsigned)tiles, (unsigned)(D[p[0]] < 65535 ? D[p[0]] : 65535), (unsigned)(B < 65535 ? B : 65535));
             hipLaunchKernelGGL(generic_tile_kernel, grid, dim3(256), 0, st, in->ptr, (long long)in->sB, (long long)si[p[0]],
                                (long long)si[p[1]], out->ptr, (long long)out->sB, (long long)so[p[0]], (long long)so[p[1]],

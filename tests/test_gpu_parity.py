@@ -162,6 +162,75 @@ def test_tiled_tap_list_kernel_vs_oracle(gpu):
     assert rel_err(xg.grad.cpu().numpy(), xc.grad.numpy()) <= 1e-4
 
 
+def test_single_plane_tap_sets_row_march_vs_oracle(gpu):
+    """Tap sets that read one input plane per output plane (register-window row march, plane_taps_kernel): Taylor-4 / 6
+    Laplacians, in-plane crosses and dense in-plane 3x3 / 5x5 / 7x7 kernels on every kernel slab (plane offsets -3..3),
+    widths from one partial strip to several strips, fewer rows than the window, many rows (several segments), batch
+    / plane strides of views, the Nt-fastest layout with a long Nt (the plane axis is then Nx), |.|; and the fall-back
+    to the tiled kernel when the width is not a multiple of 4 or the view is not 16-byte aligned."""
+    from cp_pre_amd import _dispatch
+    from cp_pre_amd.convops_2d import ConvOperator
+    from oracle.cstencil import xcorr_c
+    g = torch.Generator().manual_seed(23)
+
+    def in_plane(k, slab, dense, r):
+        out = torch.zeros(k, k, k)
+        c = k // 2
+        if dense:
+            blk = torch.randn(2 * r + 1, 2 * r + 1, generator=g)
+            out[slab, c - r:c + r + 1, c - r:c + r + 1] = blk
+        else:
+            out[slab, c - r:c + r + 1, c] = torch.randn(2 * r + 1, generator=g)
+            out[slab, c, c - r:c + r + 1] = torch.randn(2 * r + 1, generator=g)
+        return out
+
+    kernels = [("t4", ConvOperator(("x", "y"), 2, taylor_order=4).kernel), ("t6", ConvOperator(("x", "y"), 2, taylor_order=6).kernel)]
+    for k, r in ((3, 1), (5, 2), (7, 3), (7, 1), (5, 1)):
+        for slab in range(k):
+            kernels.append((f"cross k{k} r{r} slab{slab}", in_plane(k, slab, False, r)))
+        kernels.append((f"dense k{k} r{r}", in_plane(k, int(torch.randint(0, k, (1,), generator=g)), True, r)))
+    rows_only = torch.zeros(5, 5, 5)
+    rows_only[2, :, 2] = torch.randn(5, generator=g)
+    rows_only[2, 2, 2] = 0.0
+    rows_only[2, 1, 0] = 0.7                                              # a row with a single off-centre tap
+    kernels.append(("rows", rows_only))
+    shapes = [(2, 3, 20, 64), (1, 4, 3, 128), (2, 2, 70, 260), (1, 2, 9, 516), (1, 3, 150, 72)]
+    for name, k in kernels:
+        D = ConvOperator()
+        D.kernel = k
+        for shape in shapes:
+            x = torch.randn(*shape, generator=g)
+            want = xcorr_c(x.numpy(), k.numpy())
+            assert rel_err(D(x.to(gpu)).cpu().numpy(), want) <= RES_TOL, (name, shape)
+    for name, k in kernels[:2] + kernels[-3:]:
+        D = ConvOperator()
+        D.kernel = k
+        wide = torch.randn(3, 6, 19, 144, generator=g)
+        view = wide[1:, 1:5, 2:, 4:132]                                  # offset base (16-byte aligned), strides != extents
+        got = D(wide.to(gpu)[1:, 1:5, 2:, 4:132])
+        assert rel_err(got.cpu().numpy(), xcorr_c(view.contiguous().numpy(), k.numpy())) <= RES_TOL, name
+        off = wide[:, :, :, 3:131]                                       # misaligned base: tiled kernel
+        got = D(wide.to(gpu)[:, :, :, 3:131])
+        assert rel_err(got.cpu().numpy(), xcorr_c(off.contiguous().numpy(), k.numpy())) <= RES_TOL, name
+        odd = torch.randn(2, 3, 21, 130, generator=g)                    # width % 4 != 0: tiled kernel
+        assert rel_err(D(odd.to(gpu)).cpu().numpy(), xcorr_c(odd.numpy(), k.numpy())) <= RES_TOL, name
+        surrogate = torch.randn(2, 11, 14, 72, generator=g)              # [BS,Nx,Ny,Nt]: Nt is the unit-stride axis
+        v = surrogate.permute(0, 3, 1, 2)
+        got = D(v.to(gpu))
+        assert got.stride() == v.stride()
+        assert rel_err(got.cpu().numpy(), xcorr_c(v.contiguous().numpy(), k.numpy())) <= RES_TOL, name
+        x = torch.randn(2, 4, 18, 100, generator=g)
+        got = _dispatch.xcorr(x.to(gpu), k, 3, flags=1)                  # PRE_FLAG_ABS
+        assert rel_err(got.cpu().numpy(), np.abs(xcorr_c(x.numpy(), k.numpy()))) <= RES_TOL, name
+    # many segments and strips at once, against the tiled kernel's result on a misaligned copy of the same data
+    big = torch.randn(3, 5, 300, 1028, generator=g).to(gpu)
+    D = ConvOperator()
+    D.kernel = kernels[1][1]
+    pad = torch.zeros(3, 5, 300, 1029, device=gpu)
+    pad[..., 1:] = big
+    assert rel_err(D(big).cpu().numpy(), D(pad[..., 1:]).cpu().numpy()) <= 1e-6
+
+
 @pytest.mark.parametrize("nt", [10, 12, 20, 30, 40, 63])
 def test_flat_tap_list_kernel_short_nt_vs_oracle(gpu, nt):
     """Tap sets off the 7-point star on the surrogate's native layout [BS,Nx,Ny,Nt] with a SHORT Nt (the reference's
