@@ -70,15 +70,19 @@ constexpr int MAX_ROWS = 49;             // 7 * 7
 constexpr int TILE_R = 16, TILE_C = 256;
 constexpr int LDS_R = TILE_R + 6, LDS_Q = TILE_C / 4 + 2;     // +-3 rows, one quad left and right
 
+struct __attribute__((aligned(32))) RowEnt {
+    int off;                    // (dt+8) | (dx+8)<<4 | mask<<8, mask bit k: dy = k-3 present
+    float w[7];                 // dy = -3..3
+};
 struct RowList {
     int n;
     int lo, hi;                 // reach of the tap set along the row (dx) axis
-    int off[MAX_ROWS];          // sorted by (dt, dx): (dt+8) | (dx+8)<<4 | mask<<8, mask bit k: dy = k-3 present
-    float w[MAX_ROWS][7];       // dy = -3..3
+    RowEnt e[MAX_ROWS];         // sorted by (dt, dx); one 32-byte entry = one scalar load per tap row
 };
 
 struct __attribute__((aligned(4))) G4u { float x, y, z, w; };
 
+template <bool A16>                                              // A16: every quad of the views is 16-byte aligned
 __global__ void __launch_bounds__(256) generic_tile_kernel(const float *__restrict__ in, long long sB, long long sT,
                                                            long long sX, float *__restrict__ out, long long oB,
                                                            long long oT, long long oX, int B, int T, int X, int Y,
@@ -95,7 +99,8 @@ __global__ void __launch_bounds__(256) generic_tile_kernel(const float *__restri
         float a[4][4] = {};
         int staged = 99;                                          // dt of the plane now in LDS
         for (int i = 0; i < rows.n; ++i) {
-            const int of = rows.off[i];
+            const RowEnt ent = rows.e[i];
+            const int of = ent.off;
             const int dt = (of & 15) - 8, dx = ((of >> 4) & 15) - 8, mask = of >> 8;
             if (t + dt < 0 || t + dt >= T) continue;              // whole plane is padding
             if (dt != staged) {
@@ -109,8 +114,11 @@ __global__ void __launch_bounds__(256) generic_tile_kernel(const float *__restri
                     if (gx >= 0 && gx < X) {
                         const float *src = pl + gx * sX + gy;
                         if (gy >= 0 && gy + 3 < Y) {
-                            const G4u u = *reinterpret_cast<const G4u *>(src);
-                            v = make_float4(u.x, u.y, u.z, u.w);
+                            if (A16) v = *reinterpret_cast<const float4 *>(src);
+                            else {
+                                const G4u u = *reinterpret_cast<const G4u *>(src);      // (four dword loads)
+                                v = make_float4(u.x, u.y, u.z, u.w);
+                            }
                         } else {
                             if (gy >= 0 && gy < Y) v.x = src[0];
                             if (gy + 1 >= 0 && gy + 1 < Y) v.y = src[1];
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(256) generic_tile_kernel(const float *__restri
 #pragma unroll
                 for (int d = 0; d < 7; ++d)                       // dy = d - 3, ascending: the dense kernel's tap order
                     if (mask & (1 << d)) {                        // wave-uniform
-                        const float wd = rows.w[i][d];
+                        const float wd = ent.w[d];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) a[k][j] += wd * e[1 + d + j];
                     }
@@ -147,8 +155,10 @@ __global__ void __launch_bounds__(256) generic_tile_kernel(const float *__restri
             if (flags & PRE_FLAG_ABS)
                 for (int j = 0; j < 4; ++j) a[k][j] = fabsf(a[k][j]);
             float *o = out + b * oB + t * oT + x * oX + y;
-            if (y + 3 < Y) *reinterpret_cast<G4u *>(o) = G4u{a[k][0], a[k][1], a[k][2], a[k][3]};
-            else for (int j = 0; j < Y - y; ++j) o[j] = a[k][j];
+            if (y + 3 < Y) {
+                if (A16) *reinterpret_cast<float4 *>(o) = make_float4(a[k][0], a[k][1], a[k][2], a[k][3]);
+                else *reinterpret_cast<G4u *>(o) = G4u{a[k][0], a[k][1], a[k][2], a[k][3]};
+            } else for (int j = 0; j < Y - y; ++j) o[j] = a[k][j];
         }
     }
 }
@@ -521,8 +531,8 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *
             for (int o0 = 0; o0 < 7; ++o0)
                 for (int o1 = 0; o1 < 7; ++o1) {
                     if (!mask[o0][o1]) continue;
-                    rows.off[rows.n] = (o0 - 3 + 8) | ((o1 - 3 + 8) << 4) | (mask[o0][o1] << 8);
-                    for (int d = 0; d < 7; ++d) rows.w[rows.n][d] = w[o0][o1][d];
+                    rows.e[rows.n].off = (o0 - 3 + 8) | ((o1 - 3 + 8) << 4) | (mask[o0][o1] << 8);
+                    for (int d = 0; d < 7; ++d) rows.e[rows.n].w[d] = w[o0][o1][d];
                     rows.lo = o1 - 3 < rows.lo ? o1 - 3 : rows.lo;
                     rows.hi = o1 - 3 > rows.hi ? o1 - 3 : rows.hi;
                     ++rows.n;
@@ -567,9 +577,17 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *
                 }
             }
             const dim3 grid((unsigned)tiles, (unsigned)(D[p[0]] < 65535 ? D[p[0]] : 65535), (unsigned)(B < 65535 ? B : 65535));
-            hipLaunchKernelGGL(generic_tile_kernel, grid, dim3(256), 0, st, in->ptr, (long long)in->sB, (long long)si[p[0]],
-                               (long long)si[p[1]], out->ptr, (long long)out->sB, (long long)so[p[0]], (long long)so[p[1]],
-                               (int)B, (int)D[p[0]], (int)D[p[1]], (int)D[p[2]], (int)nstrips, flags, rows);
+            // (`aligned` without the width condition: a ragged last quad is handled element-wise either way)
+            const bool a16 = !((uintptr_t)in->ptr & 15) && !((uintptr_t)out->ptr & 15) &&
+                             !((in->sB | si[p[0]] | si[p[1]] | out->sB | so[p[0]] | so[p[1]]) & 3);
+            if (a16)
+                hipLaunchKernelGGL(generic_tile_kernel<true>, grid, dim3(256), 0, st, in->ptr, (long long)in->sB, (long long)si[p[0]],
+                                   (long long)si[p[1]], out->ptr, (long long)out->sB, (long long)so[p[0]], (long long)so[p[1]],
+                                   (int)B, (int)D[p[0]], (int)D[p[1]], (int)D[p[2]], (int)nstrips, flags, rows);
+            else
+                hipLaunchKernelGGL(generic_tile_kernel<false>, grid, dim3(256), 0, st, in->ptr, (long long)in->sB, (long long)si[p[0]],
+                                   (long long)si[p[1]], out->ptr, (long long)out->sB, (long long)so[p[0]], (long long)so[p[1]],
+                                   (int)B, (int)D[p[0]], (int)D[p[1]], (int)D[p[2]], (int)nstrips, flags, rows);
             PRE_LAUNCH_CHECK();
             return PRE_OK;
         }

@@ -231,6 +231,65 @@ def test_single_plane_tap_sets_row_march_vs_oracle(gpu):
     assert rel_err(D(big).cpu().numpy(), D(pad[..., 1:]).cpu().numpy()) <= 1e-6
 
 
+def test_two_and_three_plane_tap_sets_vs_oracle(gpu):
+    """Tap sets on two or three input planes (the LDS-tiled tap-list kernel, with aligned quads and without): the additive
+    wave kernel with a Taylor-4 / Taylor-6 Laplacian (README.md:47-54 with taylor_order 4 / 6: three planes with different
+    row reach), dense 3^3, dense in-plane blocks on 2 or 3 arbitrary slabs of 5^3 / 7^3 kernels, planes holding a single
+    off-centre tap; few and many rows, several strips, strided views, the Nt-fastest layout, |.|."""
+    from cp_pre_amd import _dispatch
+    from cp_pre_amd.convops_2d import ConvOperator
+    from oracle.cstencil import xcorr_c
+    g = torch.Generator().manual_seed(29)
+    kernels = []
+    for to in (4, 6):
+        lap = ConvOperator(("x", "y"), 2, taylor_order=to).kernel
+        dtt = torch.zeros_like(lap)                                       # the 3^3 time stencil centred in the 5^3 / 7^3 kernel
+        o = lap.shape[0] // 2 - 1
+        dtt[o:o + 3, o:o + 3, o:o + 3] = ConvOperator("t", 2).kernel
+        kernels.append((f"wave taylor-{to}", dtt - 0.25 * lap))
+    kernels.append(("dense 3^3", torch.randn(3, 3, 3, generator=g)))
+    for k, r, slabs in ((5, 2, (0, 3)), (5, 1, (1, 2, 4)), (7, 3, (0, 6)), (7, 2, (2, 3, 5)), (7, 3, (1, 3, 4)), (3, 1, (0, 2))):
+        kk = torch.zeros(k, k, k)
+        c = k // 2
+        for sl in slabs:
+            kk[sl, c - r:c + r + 1, c - r:c + r + 1] = torch.randn(2 * r + 1, 2 * r + 1, generator=g) * \
+                (torch.rand(2 * r + 1, 2 * r + 1, generator=g) < 0.6)
+        kk[slabs[0], c, c] = 1.5                                          # (never an empty plane)
+        kernels.append((f"blocks k{k} r{r} {slabs}", kk))
+    lone = torch.zeros(5, 5, 5)
+    lone[1, 0, 4] = 0.3                                                   # one off-centre tap on a plane of its own
+    lone[3, 2, 1:4] = torch.tensor([1.0, -2.0, 1.0])
+    kernels.append(("lone tap", lone))
+    shapes = [(2, 3, 20, 64), (1, 4, 7, 128), (2, 2, 70, 260), (1, 3, 9, 516), (1, 2, 150, 72), (1, 1, 8, 64), (1, 2, 1, 68)]
+    for name, k in kernels:
+        D = ConvOperator()
+        D.kernel = k
+        for shape in shapes:
+            x = torch.randn(*shape, generator=g)
+            want = xcorr_c(x.numpy(), k.numpy())
+            assert rel_err(D(x.to(gpu)).cpu().numpy(), want) <= RES_TOL, (name, shape)
+        wide = torch.randn(3, 6, 19, 144, generator=g)
+        view = wide[1:, 1:5, 2:, 4:132]
+        got = D(wide.to(gpu)[1:, 1:5, 2:, 4:132])
+        assert rel_err(got.cpu().numpy(), xcorr_c(view.contiguous().numpy(), k.numpy())) <= RES_TOL, name
+        surrogate = torch.randn(2, 11, 14, 72, generator=g)              # [BS,Nx,Ny,Nt]: Nt is the unit-stride axis
+        v = surrogate.permute(0, 3, 1, 2)
+        got = D(v.to(gpu))
+        assert got.stride() == v.stride()
+        assert rel_err(got.cpu().numpy(), xcorr_c(v.contiguous().numpy(), k.numpy())) <= RES_TOL, name
+        x = torch.randn(2, 4, 18, 100, generator=g)
+        got = _dispatch.xcorr(x.to(gpu), k, 3, flags=1)                  # PRE_FLAG_ABS
+        assert rel_err(got.cpu().numpy(), np.abs(xcorr_c(x.numpy(), k.numpy()))) <= RES_TOL, name
+    # many tiles at once: aligned quads against a misaligned copy of the same data
+    big = torch.randn(2, 5, 300, 1028, generator=g).to(gpu)
+    pad = torch.zeros(2, 5, 300, 1029, device=gpu)
+    pad[..., 1:] = big
+    for name, k in kernels[:3]:
+        D = ConvOperator()
+        D.kernel = k
+        assert rel_err(D(big).cpu().numpy(), D(pad[..., 1:]).cpu().numpy()) <= 1e-6, name
+
+
 @pytest.mark.parametrize("nt", [10, 12, 20, 30, 40, 63])
 def test_flat_tap_list_kernel_short_nt_vs_oracle(gpu, nt):
     """Tap sets off the 7-point star on the surrogate's native layout [BS,Nx,Ny,Nt] with a SHORT Nt (the reference's
