@@ -302,3 +302,53 @@ def test_fuzz_round2_flat_tap_list_and_joint_score(gpu):
         want = oc.ncf_metric_joint(inner, np.zeros_like(inner), mod_full[1:-1, 1:-1, 1:-1])
         got = icp.ncf_metric_joint(res.to(gpu), None, torch.from_numpy(mod_full).to(gpu), crop=1)
         assert np.array_equal(got.cpu().numpy(), want), (case, "joint score", rn.shape)
+
+
+def test_fuzz_round2_pruned_joint_score(gpu):
+    """Branch-and-bound joint score against the full pass on random slabs: plane counts around the 16-plane chunks, row and
+    segment counts, crops, per-cell scales from smooth to wild (loose bounds: everything is evaluated), spikes, zero and
+    NaN cells, scores carried over from an earlier slab - bit-identical scores for the same modulation, and the fused
+    moments against the plain moments pass."""
+    from cp_pre_amd import pipeline
+    ops = pipeline.HipOps
+    rng = np.random.default_rng(99)
+    gen = torch.Generator().manual_seed(99)
+    for case in range(max(16, CASES // 2)):
+        n = int(rng.integers(1, 40))
+        T = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 31, 33]))
+        Y = 64 * int(rng.integers(1, 6))
+        X = 4 * int(rng.integers(1, 8))                                    # X*Y % 256 == 0
+        crop = (int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 3)))
+        if T - 2 * crop[0] < 1:
+            crop = (0, crop[1], crop[2])
+        scale = torch.exp(float(rng.choice([0.0, 0.3, 3.0])) * torch.randn(T, X, Y, generator=gen))
+        res = (torch.randn(n, T, X, Y, generator=gen) * scale).to(gpu)
+        kind = rng.choice(["plain", "spike", "zero", "nan", "const"])
+        t_in, x_in, y_in = T // 2, X // 2, Y // 2
+        if kind == "spike":
+            res[int(rng.integers(0, n)), t_in, x_in, y_in] = 1e6
+        elif kind == "zero":
+            res[int(rng.integers(0, n))] = 0.0
+        elif kind == "nan":
+            res[int(rng.integers(0, n)), t_in, x_in, y_in] = float("nan")
+        elif kind == "const":
+            res[:, t_in, x_in, y_in] = 0.0                                # modulation 0 and residual 0: 0/0
+        ct = crop[0]
+        planes = T - 2 * ct
+        old = (ops.PRUNE_MIN_CELLS, ops.PRUNE_MIN_SAMPLES)
+        ops.PRUNE_MIN_CELLS = ops.PRUNE_MIN_SAMPLES = 0
+        try:
+            assert ops.can_prune(res, crop), (case, res.shape, crop)
+            m_ref, m_new = ops.zeros_moments(planes * X * Y, gpu), ops.zeros_moments(planes * X * Y, gpu)
+            ops.add_moments(res, m_ref, skip_t=ct)
+            segmax = ops.add_moments_segmax(res, m_new, crop)
+            assert torch.allclose(m_ref, m_new, rtol=1e-13, atol=0.0, equal_nan=True), (case, "moments")
+            mod = ops.std_from_moments(m_ref, n, (T, X, Y), 0.0, like=res, skip_t=ct)
+            carried = torch.rand(n, generator=gen).to(gpu) * float(rng.choice([0.0, 3.0, 6.0]))     # an earlier slab's scores
+            s_full, s_pr = carried.clone(), carried.clone()
+            ops.max_scores(res, mod, crop, s_full)
+            ops.max_scores_pruned(res, mod, segmax, crop, s_pr)
+            assert torch.equal(torch.nan_to_num(s_full, nan=-1.0), torch.nan_to_num(s_pr, nan=-1.0)), \
+                (case, kind, tuple(res.shape), crop, s_full, s_pr)
+        finally:
+            ops.PRUNE_MIN_CELLS, ops.PRUNE_MIN_SAMPLES = old
