@@ -35,9 +35,15 @@ def _check_joint(icp, pipeline, res, crop, n, gpu):
     """Streaming joint calibration on `res` + the guarantees; returns (q, modulation, scores)."""
     alphas = _alphas()
     jc = pipeline.JointCalibration(n, gpu)
+    assert pipeline.HipOps.can_prune(res, crop)                         # these sizes take the branch-and-bound score pass
     mod = jc.add_slab(res, crop=crop)
     q = jc.finish(alphas)
     sc = jc.all_scores
+    full = pipeline.JointCalibration(n, gpu, prune=False)               # ... which must agree with the full pass
+    mod_full = full.add_slab(res, crop=crop)
+    q_full = full.finish(alphas)
+    assert torch.allclose(mod, mod_full, rtol=1e-6, atol=0.0, equal_nan=True)    # (fp64 sums in a different order)
+    assert torch.allclose(sc, full.all_scores, rtol=1e-6, atol=0.0) and torch.allclose(q, q_full, rtol=1e-6, atol=0.0)
     assert q.shape == (len(alphas),) and torch.isfinite(q).all() and (q[:-1] >= q[1:]).all()
     srt = torch.sort(sc).values
     for j, a in enumerate(alphas):
