@@ -79,7 +79,7 @@ def parse():
     ap.add_argument("--nx", type=int, default=None)
     ap.add_argument("--ny", type=int, default=None)
     ap.add_argument("--slab", type=int, default=0,
-                    help="interior planes per t-slab (c3); 0 = the largest of 16 / 13 / 8 whose resident set fits the free HBM")
+                    help="interior planes per t-slab (c3); 0 = the largest of Nt, Nt/2, Nt/3, 16, 13, 8 whose resident set fits the free HBM")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch samples per rank; strong: --batch samples in total, split over the ranks")
     ap.add_argument("--plumbing-check", action="store_true",
@@ -385,9 +385,11 @@ def main():
     free = torch.cuda.mem_get_info(dev)[0]
     if not args.slab:
         # fewer, thicker slabs re-read fewer halo planes (64 planes: 16 -> 4 slabs, 13 -> 5, 8 -> 8); the resident
-        # set of S = 16 at the full batch is 301 GB of the 309 GB the device reports, so it is taken only if it fits
+        # set of S = 16 at the full batch is 301 GB of the 309 GB the device reports, so it is taken only if it fits.
+        # Smaller per-rank batches (--scaling strong, --batch) afford thicker slabs, up to the whole T axis (no halo).
         extra = 4 * (4 << 30) if (args.mode == "marginal" and world > 1) else 0       # the exchange's staging buffers
-        args.slab = next((c for c in (16, 13, 8) if resident_bytes(B, args.nt, c, X, Y) + extra <= free - (4 << 30)), 8)
+        cands = [c for c in (args.nt, (args.nt + 1) // 2, (args.nt + 2) // 3, 16, 13, 8) if 0 < c <= args.nt]
+        args.slab = next((c for c in cands if resident_bytes(B, args.nt, c, X, Y) + extra <= free - (4 << 30)), 8)
     slabs = split_slabs(args.nt, args.slab)                   # interior planes per slab position
     n_slabs, S = len(slabs), max(slabs)
     alphas = [float(a) for a in icp.ALPHA_LEVELS]
