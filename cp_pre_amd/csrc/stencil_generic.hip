@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) generic_tile_kernel(const float *__restri
 // The Taylor-4 / Taylor-6 Laplacians (Utils/ConvOps_2d.py:36-62 through kernel_3d: every tap on kernel slab 1) and any
 // purely spatial kernel read ONE input plane per output plane, so the only reuse is along the row axis.  A wave owns a
 // 256-column strip of one plane and marches down its rows, a lane = 4 adjacent columns.  Each input row is loaded once
-// (one 16-byte buffer load per lane; lanes 0 and 63 also fetch the quad left / right of the strip), lives in a register
+// (one 16-byte buffer load per lane; lanes 0 and 63 also fetch the three cells left / right of the strip), lives in a register
 // window of 2R+1 rows plus 5-6 rows of lookahead (their loads are in flight while older rows are used) and is never
 // re-read: no LDS, no barrier, no halo rows except at segment ends.  Columns left / right of a lane's quad come from
 // the neighbouring lanes by DPP wavefront shifts.  Zero padding = buffer descriptors whose extent is the row (or 0 for
