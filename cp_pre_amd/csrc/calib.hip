@@ -128,28 +128,34 @@ __device__ __forceinline__ void ms_butterfly(unsigned int (&m)[US], int lane)
     }
 }
 
-// US samples starting at sample i of one thread's column: loads first, then sums and the per-sample wave maxima.
+// US samples starting at sample i of one thread's column: ms_load issues the loads, ms_use adds them to the sums and
+// writes the per-sample wave maxima.
 template <int TCH, int US>
-__device__ __forceinline__ void ms_step(const float *__restrict__ a, long long row_stride, long long plane, int i, int nt, bool scored,
-                                        double (&s)[TCH], double (&q)[TCH], unsigned int *__restrict__ seg, long long seg_stride)
+__device__ __forceinline__ void ms_load(const float *__restrict__ a, long long row_stride, long long plane, int i, int nt, float (&v)[US][TCH])
 {
-    float v[US][TCH];
 #pragma unroll
     for (int u = 0; u < US; ++u)
 #pragma unroll
-        for (int t = 0; t < TCH; ++t) v[u][t] = (TCH == 1 || t < nt) ? a[(i + u) * row_stride + t * plane] : 0.f;
+        for (int t = 0; t < TCH; ++t)       // (no branch around a load: planes past the chunk's last re-read it and are not used)
+            v[u][t] = a[(i + u) * row_stride + (TCH == 1 || t < nt ? t : nt - 1) * plane];
+}
+
+template <int TCH, int US>
+__device__ __forceinline__ void ms_use(const float (&v)[US][TCH], int i, int nt, bool scored, double (&s)[TCH], double (&q)[TCH],
+                                       unsigned int *__restrict__ seg, long long seg_stride)
+{
     unsigned int m[US];
 #pragma unroll
     for (int u = 0; u < US; ++u) {
         m[u] = 0u;
 #pragma unroll
-        for (int t = 0; t < TCH; ++t)
-            if (TCH == 1 || t < nt) {
-                const double d = (double)v[u][t];
-                s[t] += d;
-                q[t] += d * d;
-                m[u] = max(m[u], __float_as_uint(v[u][t]) & 0x7fffffffu);   // non-negative floats order like their patterns, NaN on top
-            }
+        for (int t = 0; t < TCH; ++t) {     // (branch-free: a plane past the chunk's last adds +0 to sums that are never stored)
+            const float x = (TCH == 1 || t < nt) ? v[u][t] : 0.f;
+            const double d = (double)x;
+            s[t] += d;
+            q[t] += d * d;
+            m[u] = max(m[u], __float_as_uint(x) & 0x7fffffffu);             // non-negative floats order like their patterns, NaN on top
+        }
         m[u] = scored ? m[u] : 0u;
     }
     // wave maxima of US samples at once: each butterfly step halves the samples a lane is responsible for (US-1
@@ -158,8 +164,9 @@ __device__ __forceinline__ void ms_step(const float *__restrict__ a, long long r
     const int lane = threadIdx.x & 63;
     if constexpr (US == 1) {
         // one sample: the wave maximum by DPP (row shifts, then the two row broadcasts) lands in lane 63 after six
-        // VALU steps, without the LDS-pipe round trips of six ds_bpermute shuffles (same time on the C3 slab, 13.3 ms
-        // against 11.1 ms for the plain moments pass; 3.4 -> 3.1 ms on the C4 shard)
+        // VALU steps, without the LDS-pipe round trips of six ds_bpermute shuffles.  (C3 slab, in units of the residual
+        // launch of the same run: 0.254 with shuffles and a branch around every load; 0.233 with DPP, branch-free
+        // loads and sums, and the next sample's loads issued before this one is summed; the plain moments pass: 0.218)
         m[0] = wave_max_u32_to_lane63(m[0]);
         if (lane == 63) seg[i * seg_stride] = m[0];
     } else {
@@ -188,9 +195,28 @@ __global__ void __launch_bounds__(256) moments_segmax_kernel(const float *__rest
 #pragma unroll
     for (int t = 0; t < TCH; ++t) s[t] = q[t] = 0.0;
     int i = i0;
-    for (; i + US <= i1; i += US) ms_step<TCH, US>(a, row_stride, plane, i, nt, scored, s, q, seg, seg_stride);
-    if (US > 1)
-        for (; i < i1; ++i) ms_step<TCH, 1>(a, row_stride, plane, i, nt, scored, s, q, seg, seg_stride);
+    if constexpr (US == 1) {
+        // two buffers: the next sample's loads are in flight while this one is summed (the last trip re-reads its own)
+        float va[1][TCH], vb[1][TCH];
+        if (i < i1) ms_load<TCH, 1>(a, row_stride, plane, i, nt, va);
+        for (; i < i1; i += 2) {
+            ms_load<TCH, 1>(a, row_stride, plane, min(i + 1, i1 - 1), nt, vb);
+            ms_use<TCH, 1>(va, i, nt, scored, s, q, seg, seg_stride);
+            if (i + 1 >= i1) break;
+            ms_load<TCH, 1>(a, row_stride, plane, min(i + 2, i1 - 1), nt, va);
+            ms_use<TCH, 1>(vb, i + 1, nt, scored, s, q, seg, seg_stride);
+        }
+    } else {
+        float v[US][TCH], v1[1][TCH];
+        for (; i + US <= i1; i += US) {
+            ms_load<TCH, US>(a, row_stride, plane, i, nt, v);
+            ms_use<TCH, US>(v, i, nt, scored, s, q, seg, seg_stride);
+        }
+        for (; i < i1; ++i) {
+            ms_load<TCH, 1>(a, row_stride, plane, i, nt, v1);
+            ms_use<TCH, 1>(v1, i, nt, scored, s, q, seg, seg_stride);
+        }
+    }
     sum += (long long)t0 * plane + c;
     sumsq += (long long)t0 * plane + c;
 #pragma unroll
