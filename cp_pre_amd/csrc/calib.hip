@@ -207,10 +207,15 @@ __global__ void __launch_bounds__(256) moments_segmax_kernel(const float *__rest
             ms_use<TCH, 1>(vb, i + 1, nt, scored, s, q, seg, seg_stride);
         }
     } else {
-        float v[US][TCH], v1[1][TCH];
-        for (; i + US <= i1; i += US) {
-            ms_load<TCH, US>(a, row_stride, plane, i, nt, v);
+        float v[US][TCH], w[US][TCH], v1[1][TCH];
+        const int ilast = i0 + (i1 - i0) / US * US - US;                                   // start of the last full group
+        if (i + US <= i1) ms_load<TCH, US>(a, row_stride, plane, i, nt, v);
+        for (; i + US <= i1; i += 2 * US) {                                                // (two buffers, as above)
+            ms_load<TCH, US>(a, row_stride, plane, min(i + US, ilast), nt, w);
             ms_use<TCH, US>(v, i, nt, scored, s, q, seg, seg_stride);
+            if (i + 2 * US > i1) { i += US; break; }
+            ms_load<TCH, US>(a, row_stride, plane, min(i + 2 * US, ilast), nt, v);
+            ms_use<TCH, US>(w, i + US, nt, scored, s, q, seg, seg_stride);
         }
         for (; i < i1; ++i) {
             ms_load<TCH, 1>(a, row_stride, plane, i, nt, v1);
