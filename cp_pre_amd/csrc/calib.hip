@@ -474,14 +474,16 @@ __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *_
             const long long o = ((long long)t0 * X + x) * Y + y, plane = (long long)X * Y;
             float rv[MS_TMAX], mv[MS_TMAX];
 #pragma unroll
-            for (int t = 0; t < MS_TMAX; ++t)
-                if (t < planes) { rv[t] = pr[o + t * plane]; mv[t] = mod[o + t * plane]; }
+            for (int t = 0; t < MS_TMAX; ++t) {                   // (no branch around a load: a short chunk re-reads its last plane)
+                const int tt = t < planes ? t : planes - 1;
+                rv[t] = pr[o + tt * plane];
+                mv[t] = mod[o + tt * plane];
+            }
 #pragma unroll
-            for (int t = 0; t < MS_TMAX; ++t)
-                if (t < planes) {
-                    const float q = fabsf(rv[t]) / mv[t];
-                    m = max(m, q != q ? NANBITS : __float_as_uint(q));
-                }
+            for (int t = 0; t < MS_TMAX; ++t) {
+                const float q = fabsf(rv[t]) / mv[t];
+                m = max(m, q != q ? NANBITS : __float_as_uint(q));
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o));
