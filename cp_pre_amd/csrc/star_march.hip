@@ -621,7 +621,8 @@ int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st, const BCInfo
     // (profiles/r02/tile_ab_mhd.txt): 4x64 -2..-12 %, 8x32 -1..-14 %, 16x16 0..-7 % at [1024,64,256,256]; only at
     // T = 10 do 8x32 / 16x16 gain (+6 % induction, +2 % momentum / energy): not worth 45 more instantiations;
     // 12x64 (768 threads: 3 waves per SIMD where the 82 KB tile of 8x64 leaves induction 2) -5..-8 %;
-    // own cells prefetched three planes ahead instead of two on induction (200 VGPRs): within the +-5 % run-to-run noise
+    // own cells prefetched three planes ahead instead of two on induction (200 VGPRs): within the +-5 % run-to-run noise;
+    // induction capped at 128 VGPRs (17 dwords spilled) so that two of its 80 KB workgroups share a CU: -30 %
     if (g.Y >= 192) return launch_tiled<Fn, 8, 64, BC>(g, prm, st, bc);
     if (g.Y >= 96) return launch_tiled<Fn, 16, 32, BC>(g, prm, st, bc);
     return launch_tiled<Fn, 32, 16, BC>(g, prm, st, bc);

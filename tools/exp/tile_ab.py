@@ -3,7 +3,9 @@
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
-from cp_pre_amd import residuals as R
+from cp_pre_amd import _lib, residuals as R
+if os.environ.get("PROBE_SO"):                       # an experimental build of the library (tools/exp/*.so)
+    _lib.SO_PATH = os.path.abspath(os.environ["PROBE_SO"])
 
 dev = torch.device("cuda:0")
 
