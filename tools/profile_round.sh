@@ -30,4 +30,6 @@ for c in c2 c4 c5; do
     run fetch_$c --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch_$c" -- $B --config $c --steps 1 --warmup 0
     run write_$c --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write_$c" -- $B --config $c --steps 1 --warmup 0
 done
+# gpurun copies back at most 64 MiB: the per-dispatch traces are not needed once rocprofv3 has written the statistics
+find "$P" -name "*_kernel_trace.csv" -delete
 echo done >&2
