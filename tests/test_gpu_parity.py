@@ -547,7 +547,7 @@ def test_marginal_qhat_large_n_wide_counters(gpu, n, M):
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize("n", [40, 256, 1500, 2049, 5000, 12000])
+@pytest.mark.parametrize("n", [40, 130, 200, 255, 256, 1500, 2049, 5000, 12000])
 def test_marginal_qhat_window_and_fallback_paths(gpu, n):
     """The sample-guided first digit must never decide the RESULT: columns whose sampled rows are unrepresentative
     (sorted data, outliers only between the sampled rows, mixed signs, huge dynamic range, heavy ties, denormals)
@@ -594,6 +594,34 @@ def test_marginal_qhat_window_and_fallback_paths(gpu, n):
     with np.errstate(all="ignore"):
         col = s[:, 109].cpu().numpy()
         assert np.isnan(np.quantile(col, 0.5, method="higher")) and np.isnan(icp.kth_axis0(s, [n // 2])[0, 109].item())
+
+
+@pytest.mark.parametrize("n", [129, 131, 192, 250, 256])
+def test_marginal_qhat_two_lanes_per_cell_form(gpu, n):
+    """128 < n <= 256 (register sort with two lanes per cell, kth_pair_kernel): cell counts around the 32-cell wave
+    tiles and the 4-wave blocks, one rank and more than ten, both extremes, the ranks on either side of the lane split
+    (127, 128), ties across the split, a NaN / an infinity in either half - against torch.sort, bit for bit."""
+    from cp_pre_amd import inductive_cp as icp
+    g = torch.Generator(device=gpu).manual_seed(n)
+    for M in (1, 31, 32, 33, 127, 128, 129, 1000, 100003):
+        s = torch.randn(n, M, device=gpu, generator=g) * torch.exp(2 * torch.randn(M, device=gpu, generator=g))
+        s[: n // 2, 0] = 1.25                                             # ties across the two halves
+        if M > 3:
+            s[:, 1] = -4.0                                                # a constant column
+            s[5, 2] = float("nan")                                        # NaN in the first half
+            s[n - 1, 3] = float("nan")                                    # ... in the second
+        if M > 6:
+            s[130 % n, 4] = float("inf")
+            s[7, 5] = float("-inf")
+            s[:, 6] = torch.sort(s[:, 6]).values                          # sorted: every row of the 2nd half above the 1st
+        has_nan = torch.isnan(s).any(dim=0)
+        ks_all = sorted({0, 1, 63, 64, 126, 127, 128, 129 % n, n // 2, n - 2, n - 1}
+                        | {icp.kth_index(n, n, float(a)) for a in icp.ALPHA_LEVELS})
+        for group in (ks_all[:1], ks_all[:10], ks_all[-10:], ks_all):
+            got = icp.kth_axis0(s, group)
+            ref = torch.sort(s, dim=0).values[group]
+            same = torch.where(has_nan[None, :], torch.isnan(got), got == ref)
+            assert bool(same.all()), (n, M, group)
 
 
 def test_joint_recipe_vs_numpy(gpu):
