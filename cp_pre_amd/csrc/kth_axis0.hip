@@ -709,11 +709,12 @@ __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict_
 // 127 - i, the low lane keeping the minima - leaves the 128 smallest scores of the cell in the low lane and the 128
 // largest in the high lane, each a bitonic sequence that seven more in-register stages sort.  Rank k is then element
 // k & 127 of lane (cell + 32 (k >> 7)).  The radix form needs ~1500 instructions of per-tile set-up per thread and
-// several barriers for the same tile: 0.9 - 1.45 TB/s at n = 130 .. 256 against 2.7 at n = 128.
+// several barriers for the same tile: 0.9 - 1.45 TB/s at n = 130 .. 256 against 2.7 at n = 128.  (N = 64 with two lanes
+// per cell for 64 < n <= 128 was measured as well: 13 - 20 % slower than one lane with N = 128.)
+template <int N>
 __global__ void __launch_bounds__(256) kth_pair_kernel(const float *__restrict__ s, int n, long long M, const KAList kl,
                                                        float *__restrict__ out)
 {
-    constexpr int N = 128;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int cell = lane & 31, half = lane >> 5;
     const long long c0 = ((long long)blockIdx.x * 4 + wave) * 32, c = c0 + cell;
@@ -722,7 +723,7 @@ __global__ void __launch_bounds__(256) kth_pair_kernel(const float *__restrict__
     // row i of the first half through a descriptor whose base advances by one row per load; the second half adds
     // 128 rows to the lane offset (host: 128 M 4 < 2^32).  The descriptor ends where the tensor does (or 4 GiB on), so
     // rows >= n read 0 - they are replaced by the padding key - and nothing past the allocation is touched.
-    const unsigned int voff = (unsigned)cell * 4u + (half ? (unsigned)(128 * M * 4) : 0u);
+    const unsigned int voff = (unsigned)cell * 4u + (half ? (unsigned)(N * M * 4) : 0u);
     const float *p = s + c0;
     long long left = ((long long)n * M - c0) * 4;              // bytes from the row base to the end of the tensor
     float raw[N];
@@ -751,18 +752,19 @@ __global__ void __launch_bounds__(256) kth_pair_kernel(const float *__restrict__
     // np.quantile: a NaN in the column makes every quantile of the cell NaN (positive NaNs sort above +inf at the top
     // of the n real entries, negative ones below -inf at the bottom)
     const unsigned int top = ks_take<N>(v, (n - 1) & (N - 1));
-    const unsigned int top_g = (unsigned int)__shfl((int)top, cell + 32 * ((n - 1) >> 7));
+    const unsigned int top_g = (unsigned int)__shfl((int)top, cell + 32 * ((n - 1) / N));
     const unsigned int bot_g = (unsigned int)__shfl((int)v[0], cell);
     const bool nan = top_g > 0xff800000u || bot_g < 0x007fffffu;
 #pragma unroll
     for (int j = 0; j < KA_MAXK; ++j) {
         if (j >= kl.nk) break;                                    // wave-uniform
         const unsigned int e = ks_take<N>(v, kl.k[j] & (N - 1));
-        const unsigned int r = (unsigned int)__shfl((int)e, cell + 32 * (kl.k[j] >> 7));
+        const unsigned int r = (unsigned int)__shfl((int)e, cell + 32 * (kl.k[j] / N));
         if (cok && half == 0) out[(long long)j * M + c] = nan ? __uint_as_float(0x7fc00000u) : key2f(r);
     }
 }
 
+template <int N>
 int launch_kth_pair(const float *scores, int n, long long M, const int32_t *ks, int nk, float *out, hipStream_t st)
 {
     const long long blocks = ((M + 31) / 32 + 3) / 4;
@@ -771,7 +773,7 @@ int launch_kth_pair(const float *scores, int n, long long M, const int32_t *ks, 
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < KA_MAXK; ++j) kl.k[j] = j < kl.nk ? ks[j0 + j] : 0;
-        hipLaunchKernelGGL(kth_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, kl, out + (long long)j0 * M);
+        hipLaunchKernelGGL(kth_pair_kernel<N>, dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, kl, out + (long long)j0 * M);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
@@ -826,7 +828,7 @@ extern "C" int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, cons
     hipStream_t st = as_stream(stream);
     if (n <= 64) return launch_kth_small<64>(scores, (int)n, (long long)M, ks, nk, out, st);
     if (n <= 128) return launch_kth_small<128>(scores, (int)n, (long long)M, ks, nk, out, st);
-    if (n <= 256 && 128 * M * 4 < 0xffffffffLL) return launch_kth_pair(scores, (int)n, (long long)M, ks, nk, out, st);
+    if (n <= 256 && 128 * M * 4 < 0xffffffffLL) return launch_kth_pair<128>(scores, (int)n, (long long)M, ks, nk, out, st);
     // 16-bit counters hold n < 65536; 1024 first-digit buckets (one workgroup per CU) pay off once 512 buckets
     // would leave more than CAP elements per bucket (n above ~2000)
     if (n >= 65536) return launch_kth<9, true>(scores, (int)n, (long long)M, ks, nk, out, st);
