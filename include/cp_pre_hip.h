@@ -195,8 +195,9 @@ int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float
 
 /* ---- a11: calibrate(scores, n, alpha) ---------------------------------------------------
  * (Neural_PDE.UQ.inductive_cp, absent; call sites Marginal/Wave_Residuals_CP.py:288,
- * Joint/Burgers_Residuals_CP.py:283).  Exact order statistics by bucket / MSD radix select on the
- * order-preserving uint32 image of fp32; result is bit-for-bit an input value.
+ * Joint/Burgers_Residuals_CP.py:283).  Exact order statistics on the order-preserving uint32 image of fp32 (n <= 256:
+ * the cell's column sorted in registers; above: sample-guided bucket / MSD radix select); result is bit-for-bit an
+ * input value.
  * ks: host array of 0-based sorted ranks (the caller derives them from alpha).
  * pre_kth_f32:       scores[N]            -> out[nk]; any NaN score makes every result NaN (np.quantile)
  * pre_kth_axis0_f32: scores[n, M] contiguous -> out[nk, M]   (per-cell over the batch axis),
