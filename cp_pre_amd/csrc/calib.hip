@@ -183,14 +183,20 @@ __global__ void __launch_bounds__(256) moments_segmax_kernel(const float *__rest
                                                              int Y, int cx, int cy, int rows_per_split, double *__restrict__ sum,
                                                              double *__restrict__ sumsq, unsigned int *__restrict__ segmax)
 {
-    const long long plane = (long long)X * Y, c = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // c < plane (X*Y % 256 == 0)
-    const int x = (int)(c / Y), y = (int)(c - (long long)x * Y), nseg = Y / 64;
-    const bool scored = x >= cx && x < X - cx && y >= cy && y < Y - cy;
+    // a segment = 64 consecutive cells of the flattened (x, y) plane x 16 planes (it may straddle rows: a bound needs no
+    // geometry); lanes past the plane's last cell re-read it and count nowhere
+    const long long plane = (long long)X * Y, cl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((cl & ~63LL) >= plane) return;                                                     // a wave wholly past the plane
+    const bool live = cl < plane;
+    const long long c = live ? cl : plane - 1;
+    const int x = (int)(c / Y), y = (int)(c - (long long)x * Y);
+    const long long nseg = (plane + 63) / 64;
+    const bool scored = live && x >= cx && x < X - cx && y >= cy && y < Y - cy;
     const int i0 = blockIdx.y * rows_per_split, i1 = min(n, i0 + rows_per_split);
     const int tc = blockIdx.z, TC = gridDim.z, t0 = tc * MS_TMAX, nt = min(TCH, T - t0);
     a += (long long)t0 * plane + c;
-    const long long seg_stride = (long long)TC * X * nseg;                                 // segmax [n][TC][X][nseg]
-    unsigned int *seg = segmax + ((long long)tc * X + x) * nseg + (y >> 6);
+    const long long seg_stride = (long long)TC * nseg;                                     // segmax [n][TC][nseg]
+    unsigned int *seg = segmax + (long long)tc * nseg + (cl >> 6);
     double s[TCH], q[TCH];
 #pragma unroll
     for (int t = 0; t < TCH; ++t) s[t] = q[t] = 0.0;
@@ -226,7 +232,7 @@ __global__ void __launch_bounds__(256) moments_segmax_kernel(const float *__rest
     sumsq += (long long)t0 * plane + c;
 #pragma unroll
     for (int t = 0; t < TCH; ++t)
-        if (t < nt) {
+        if (t < nt && live) {
             if (gridDim.y == 1) { sum[t * plane] += s[t]; sumsq[t * plane] += q[t]; }
             else { atomicAdd(&sum[t * plane], s[t]); atomicAdd(&sumsq[t * plane], q[t]); }
         }
@@ -415,7 +421,8 @@ __global__ void __launch_bounds__(256) joint_score_flat_kernel(const float *__re
 }
 
 // ------------------------------------------------------------------ pruned joint score (branch and bound)
-// The score of a sample is a MAXIMUM over cells, and for a segment S (one row x, 64 columns, the slab's planes)
+// The score of a sample is a MAXIMUM over cells, and for a segment S (64 consecutive cells of the flattened (x, y)
+// plane x up to 16 planes)
 //     max_{c in S} fl(|r_c| / mod_c)  <=  fl( max_S |r_c| / min_S mod_c )
 // because correctly rounded division is monotone in both arguments.  moments_segmax_kernel delivers max_S |r| per
 // sample (segmax) from the read the moments need anyway, segmin_kernel min_S mod once per slab; a block per sample then (1) evaluates the segment with the
@@ -424,36 +431,37 @@ __global__ void __launch_bounds__(256) joint_score_flat_kernel(const float *__re
 // the pass reads the 16 KB of bounds per sample instead of 13.6 MB of residual.
 constexpr int JP_SEG = 64;
 
-__global__ void __launch_bounds__(64) segmin_kernel(const float *__restrict__ mod, int T, int X, int Y, int cx, int cy, int nseg,
-                                                    float *__restrict__ segmin)
+__global__ void __launch_bounds__(64) segmin_kernel(const float *__restrict__ mod, int T, int X, int Y, int cx, int cy,
+                                                    long long nseg, float *__restrict__ segmin)
 {
-    const int x = blockIdx.x, seg = blockIdx.y, tc = blockIdx.z, y = seg * JP_SEG + (int)threadIdx.x;
+    const long long plane = (long long)X * Y, seg = blockIdx.x, c = seg * JP_SEG + (long long)threadIdx.x;
+    const int tc = blockIdx.y, x = (int)(c / Y), y = (int)(c - (long long)x * Y);
     float m = __builtin_inff();
     bool bad = false;
-    if (x >= cx && x < X - cx && y >= cy && y < Y - cy)
+    if (c < plane && x >= cx && x < X - cx && y >= cy && y < Y - cy)
         for (int t = tc * MS_TMAX; t < min(T, (tc + 1) * MS_TMAX); ++t) {
-            const float v = mod[((long long)t * X + x) * Y + y];
+            const float v = mod[t * plane + c];
             bad |= !(v > 0.f);                                    // NaN or <= 0: no usable bound
             m = fminf(m, v);
         }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
     bad = __ballot(bad) != 0;
-    if (threadIdx.x == 0) segmin[((long long)tc * X + x) * nseg + seg] = bad ? 0.f : m;
+    if (threadIdx.x == 0) segmin[(long long)tc * nseg + seg] = bad ? 0.f : m;
 }
 
 __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *__restrict__ res, long long row_stride,
                                                                   const float *__restrict__ mod,
                                                                   const unsigned int *__restrict__ segmax,
                                                                   const float *__restrict__ segmin, int T, int X, int Y, int cx,
-                                                                  int cy, int nseg, int total, float *__restrict__ scores)
+                                                                  int cy, int per_chunk, int total, float *__restrict__ scores)
 {
     extern __shared__ unsigned int work[];                        // `total` = TC * X * nseg segment ids
     __shared__ unsigned int red[16], redi[16], nwork, sbest;
     const int smp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const float *pr = res + smp * row_stride;
     const unsigned int *pm = segmax + (long long)smp * total;
-    const int per_chunk = X * nseg;
+    const long long plane = (long long)X * Y;
     const unsigned int NANBITS = 0x7fc00000u;
 
     // upper bound of a segment's scores as a bit pattern (NaN above everything: "must be read")
@@ -467,11 +475,13 @@ __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *_
     };
     // exact maximum of |r| / mod over one segment, by one wave (a lane per column, up to 16 planes in flight)
     auto evaluate = [&](int j) __attribute__((always_inline)) {
-        const int tc = j / per_chunk, r = j - tc * per_chunk, x = r / nseg, y = (r - x * nseg) * JP_SEG + lane;
+        const int tc = j / per_chunk;
+        const long long c = (long long)(j - tc * per_chunk) * JP_SEG + lane;               // cell of the flattened plane
+        const int x = (int)(c / Y), y = (int)(c - (long long)x * Y);
         const int t0 = tc * MS_TMAX, planes = min(MS_TMAX, T - t0);
         unsigned int m = 0u;
-        if (y >= cy && y < Y - cy) {
-            const long long o = ((long long)t0 * X + x) * Y + y, plane = (long long)X * Y;
+        if (c < plane && x >= cx && x < X - cx && y >= cy && y < Y - cy) {
+            const long long o = (long long)t0 * plane + c;
             float rv[MS_TMAX], mv[MS_TMAX];
 #pragma unroll
             for (int t = 0; t < MS_TMAX; ++t) {                   // (no branch around a load: a short chunk re-reads its last plane)
@@ -775,8 +785,7 @@ int pre_moments_segmax_f64(const float *a, int64_t row_stride, int64_t n, int64_
 {
     if (!a || !sum || !sumsq || !segmax || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
     if (crop_x < 0 || crop_y < 0 || row_stride < T * X * Y) return PRE_E_RANGE;
-    if (Y % 64 != 0 || (X * Y) % 256 != 0) return PRE_E_UNSUPPORTED;                      // caller: plain moments + plain score
-    const long long bx = X * Y / 256, TC = (T + MS_TMAX - 1) / MS_TMAX;
+    const long long bx = (X * Y + 255) / 256, TC = (T + MS_TMAX - 1) / MS_TMAX;
     if (n > 0x7fffffff || bx > 0x7fffffffLL || TC > 65535 || T > 0x7fffffff) return PRE_E_SHAPE;
     const int us = T == 1 ? 16 : T <= 4 ? 4 : 1;
     long long splits = 1;
@@ -847,10 +856,10 @@ int pre_segmin_mod_f32(const float *mod, int64_t T, int64_t X, int64_t Y, int cr
 {
     if (!mod || !segmin || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
     if (crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
-    const long long nseg = (Y + JP_SEG - 1) / JP_SEG, TC = (T + MS_TMAX - 1) / MS_TMAX;
-    if (X > 0x7fffffff || nseg > 65535 || TC > 65535) return PRE_E_SHAPE;
-    hipLaunchKernelGGL(segmin_kernel, dim3((unsigned)X, (unsigned)nseg, (unsigned)TC), dim3(64), 0, as_stream(stream), mod, (int)T,
-                       (int)X, (int)Y, crop_x, crop_y, (int)nseg, segmin);
+    const long long nseg = (X * Y + JP_SEG - 1) / JP_SEG, TC = (T + MS_TMAX - 1) / MS_TMAX;
+    if (X > 0x7fffffff || Y > 0x7fffffff || nseg > 0x7fffffffLL || TC > 65535) return PRE_E_SHAPE;
+    hipLaunchKernelGGL(segmin_kernel, dim3((unsigned)nseg, (unsigned)TC), dim3(64), 0, as_stream(stream), mod, (int)T, (int)X, (int)Y,
+                       crop_x, crop_y, nseg, segmin);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }
@@ -860,8 +869,8 @@ int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float
 {
     if (!res || !mod || !segmax || !segmin || !scores || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
     if (crop_x < 0 || crop_y < 0 || row_stride < T * X * Y) return PRE_E_RANGE;
-    const long long nseg = (Y + JP_SEG - 1) / JP_SEG, TC = (T + MS_TMAX - 1) / MS_TMAX, total = TC * X * nseg;
-    if (n > 0x7fffffff || T > 0x7fffffff) return PRE_E_SHAPE;
+    const long long nseg = (X * Y + JP_SEG - 1) / JP_SEG, TC = (T + MS_TMAX - 1) / MS_TMAX, total = TC * nseg;
+    if (n > 0x7fffffff || T > 0x7fffffff || X > 0x7fffffff || Y > 0x7fffffff) return PRE_E_SHAPE;
     if (total * 4 > 64 * 1024) return PRE_E_UNSUPPORTED;                                  // the work list lives in LDS
     // a block per sample: few samples get more waves each to work through their lists
     const int threads = n >= 2048 ? 256 : n >= 512 ? 512 : 1024;

@@ -91,24 +91,24 @@ class HipOps:
 
     @staticmethod
     def can_prune(res, crop):
-        """The branch-and-bound score takes a contiguous [n,T,X,Y] tensor with whole 64-column segments (Ny % 64 == 0,
-        Nx*Ny % 256 == 0), at least one plane inside the t crop, and at most 16384 segments of 16 planes x 64 columns
-        per sample (its work list lives in LDS)."""
+        """The branch-and-bound score takes a contiguous [n,T,X,Y] tensor with at least one plane inside the t crop and
+        at most 16384 segments (64 consecutive cells of the flattened (x, y) plane x 16 planes) per sample - its work
+        list lives in LDS - and pays from a few hundred samples and ~1e8 cells on."""
         if (res.dim() != 4 or not res.is_contiguous() or res.numel() < HipOps.PRUNE_MIN_CELLS
                 or res.shape[0] < HipOps.PRUNE_MIN_SAMPLES):
             return False
         T, X, Y = res.shape[1:]
         planes = T - 2 * crop[0]
-        return planes >= 1 and Y % 64 == 0 and (X * Y) % 256 == 0 and ((planes + 15) // 16) * X * (Y // 64) <= 16384
+        return planes >= 1 and ((planes + 15) // 16) * ((X * Y + 63) // 64) <= 16384
 
     @staticmethod
     def add_moments_segmax(res, mom, crop):
         """``add_moments(res, mom, skip_t=crop[0])`` + from the same read the maxima of |res| per sample and segment
-        (16 planes x one row x 64 columns of the planes inside the t crop; cells within ``crop`` of the x / y rim
-        excluded): int32 bit patterns [n, ceil(planes/16), X, Y/64] for ``max_scores_pruned``."""
+        (64 consecutive cells of the flattened (x, y) plane x 16 planes of those inside the t crop; cells within ``crop``
+        of the x / y rim excluded): int32 bit patterns [n, ceil(planes/16), ceil(X*Y/64)] for ``max_scores_pruned``."""
         n, (T, X, Y) = res.shape[0], res.shape[1:]
         planes = T - 2 * crop[0]
-        segmax = torch.empty(n, (planes + 15) // 16, X, Y // 64, dtype=torch.int32, device=res.device)
+        segmax = torch.empty(n, (planes + 15) // 16, (X * Y + 63) // 64, dtype=torch.int32, device=res.device)
         with torch.cuda.device(res.device):
             _lib.check(_lib.load().pre_moments_segmax_f64(_lib.ptr(res[:, crop[0]:]), res.stride(0), n, planes, X, Y, crop[1],
                                                           crop[2], _lib.ptr(mom[0]), _lib.ptr(mom[1]), _lib.ptr(segmax),
@@ -162,7 +162,7 @@ class JointCalibration:
         """``res``: UNCROPPED residual slab [n_local, T_slab, X, Y]; ``crop`` cells per side are excluded
         from the score (the reference's ``[...,1:-1,1:-1,1:-1]``).  The t-rim planes may hold garbage
         (``PRE_FLAG_INTERIOR_T``): they are neither reduced nor scored.
-        When the slab allows it (``HipOps.can_prune``: contiguous, Ny % 64 == 0, ...) the moments pass also delivers
+        When the slab allows it (``HipOps.can_prune``: contiguous, large enough, ...) the moments pass also delivers
         per-segment maxima of |res| and the score pass reads only the segments that can still raise a sample's
         score - the same scores bit for bit (``prune=False`` forces the full pass)."""
         ops = self.ops

@@ -174,15 +174,16 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod,
  * is monotone), so a segment whose bound does not exceed the sample's best score so far - scores[i] from earlier slabs,
  * then the segment with the largest bound - is never read.  Bit-identical to pre_joint_score_f32; on noise-like
  * residuals it reads well under 1 % of them.
- * A segment is 16 planes x one row x 64 columns: TC = ceil(T/16) plane chunks, index [tc][x][y/64].
+ * A segment is 64 consecutive cells of the flattened (x, y) plane x 16 planes: NS = ceil(X*Y/64) segments per
+ * chunk of planes, TC = ceil(T/16) chunks, index [tc][s] (a segment may straddle rows: a bound needs no geometry).
  *   pre_moments_segmax_f64: pre_moments_axis0_f64 for n samples of T contiguous planes [T,X,Y] each, sample i at
- *     a + i*row_stride (Y % 64 == 0, X*Y % 256 == 0; else PRE_E_UNSUPPORTED) that ALSO writes, from the same read,
- *     segmax (uint32 [n][TC][X][Y/64]) = the bit pattern of max |a| of sample i over the segment, cells within crop_x /
- *     crop_y of the x / y rim excluded (0 for rim rows).  sum, sumsq: [T*X*Y] as pre_moments_axis0_f64 (fp64 sums of the
- *     same terms; only the order of the additions may differ).
- *   pre_segmin_mod_f32: segmin[tc][x][y/64] = min of mod[T,X,Y] over the segment's uncropped cells; +inf for rim
- *     rows, 0 if the segment holds a NaN or a non-positive modulation (-> always read).
- *   pre_joint_score_pruned_f32: scores as pre_joint_score_f32 with crop_t = 0 over the same planes; TC*X*Y/64 <= 16384
+ *     a + i*row_stride, that ALSO writes, from the same read, segmax (uint32 [n][TC][NS]) = the bit pattern of
+ *     max |a| of sample i over the segment, cells within crop_x / crop_y of the x / y rim excluded (0 if none is
+ *     left).  sum, sumsq: [T*X*Y] as pre_moments_axis0_f64 (fp64 sums of the same terms; only the order of the
+ *     additions may differ).
+ *   pre_segmin_mod_f32: segmin[tc][s] = min of mod[T,X,Y] over the segment's uncropped cells; +inf if there is none,
+ *     0 if the segment holds a NaN or a non-positive modulation (-> always read).
+ *   pre_joint_score_pruned_f32: scores as pre_joint_score_f32 with crop_t = 0 over the same planes; TC*NS <= 16384
  *     (the work list lives in LDS; else PRE_E_UNSUPPORTED).
  * A t crop is applied by handing in the interior planes: a + crop_t*X*Y with T - 2*crop_t planes, row_stride unchanged. */
 int pre_moments_segmax_f64(const float *a, int64_t row_stride, int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x,
