@@ -90,16 +90,28 @@ class HipOps:
     PRUNE_MIN_SAMPLES = 256
 
     @staticmethod
+    def prune_view(res, crop):
+        """(contiguous view of ``res`` with its cell axes in memory order, the crop in that order) when the
+        branch-and-bound score applies, else None.  It takes a dense [n,T,X,Y] tensor in any axis order (the surrogate's
+        Nt-fastest layout included: a segment is defined on the memory order) with at least one plane of the slowest
+        cell axis inside its crop and at most 16384 segments (64 consecutive cells of the two faster axes' flattened
+        plane x 16 planes) per sample - the work list lives in LDS; it pays from a few hundred samples and ~1e8 cells
+        on."""
+        if res.dim() != 4 or res.numel() < HipOps.PRUNE_MIN_CELLS or res.shape[0] < HipOps.PRUNE_MIN_SAMPLES:
+            return None
+        resc, order = icp.canon(res)
+        if order is None and not res.is_contiguous():
+            return None                                            # not dense: canon copied it
+        cropc = tuple(crop) if order is None else tuple(crop[o - 1] for o in order)
+        A0, A1, A2 = resc.shape[1:]
+        planes = A0 - 2 * cropc[0]
+        if planes < 1 or ((planes + 15) // 16) * ((A1 * A2 + 63) // 64) > 16384:
+            return None
+        return resc, cropc
+
+    @staticmethod
     def can_prune(res, crop):
-        """The branch-and-bound score takes a contiguous [n,T,X,Y] tensor with at least one plane inside the t crop and
-        at most 16384 segments (64 consecutive cells of the flattened (x, y) plane x 16 planes) per sample - its work
-        list lives in LDS - and pays from a few hundred samples and ~1e8 cells on."""
-        if (res.dim() != 4 or not res.is_contiguous() or res.numel() < HipOps.PRUNE_MIN_CELLS
-                or res.shape[0] < HipOps.PRUNE_MIN_SAMPLES):
-            return False
-        T, X, Y = res.shape[1:]
-        planes = T - 2 * crop[0]
-        return planes >= 1 and ((planes + 15) // 16) * ((X * Y + 63) // 64) <= 16384
+        return HipOps.prune_view(res, crop) is not None
 
     @staticmethod
     def add_moments_segmax(res, mom, crop):
@@ -162,25 +174,29 @@ class JointCalibration:
         """``res``: UNCROPPED residual slab [n_local, T_slab, X, Y]; ``crop`` cells per side are excluded
         from the score (the reference's ``[...,1:-1,1:-1,1:-1]``).  The t-rim planes may hold garbage
         (``PRE_FLAG_INTERIOR_T``): they are neither reduced nor scored.
-        When the slab allows it (``HipOps.can_prune``: contiguous, large enough, ...) the moments pass also delivers
+        When the slab allows it (``HipOps.prune_view``: dense, large enough, ...) the moments pass also delivers
         per-segment maxima of |res| and the score pass reads only the segments that can still raise a sample's
         score - the same scores bit for bit (``prune=False`` forces the full pass)."""
         ops = self.ops
         M = res[0].numel() if hasattr(res[0], "numel") else res[0].size
-        skip = crop[0] if (getattr(ops, "interior_t", False) and crop[0] > 0 and res.is_contiguous()
-                           and res.shape[1] > 2 * crop[0]) else 0
+        view = ops.prune_view(res, crop) if self.prune and getattr(ops, "prune_view", None) else None
+        if view is not None:
+            resc, cropc = view                                           # cell axes in memory order
+            skip = cropc[0]                                              # planes of the slowest axis inside its crop only
+        else:
+            skip = crop[0] if (getattr(ops, "interior_t", False) and crop[0] > 0 and res.is_contiguous()
+                               and res.shape[1] > 2 * crop[0]) else 0
         kw = {"skip_t": skip} if skip else {}
-        mom = ops.zeros_moments(M - 2 * skip * (M // res.shape[1]), self.device)
-        segmax = None
-        if self.prune and getattr(ops, "can_prune", None) and ops.can_prune(res, crop):
-            segmax = ops.add_moments_segmax(res, mom, crop)              # (skip == crop[0] here)
+        mom = ops.zeros_moments(M - 2 * skip * (M // (resc if view is not None else res).shape[1]), self.device)
+        if view is not None:
+            segmax = ops.add_moments_segmax(resc, mom, cropc)
         else:
             ops.add_moments(res, mom, **kw)
         if self.group is not None:
             torch.distributed.all_reduce(mom, group=self.group)          # RCCL: sum of (sum, sumsq) per cell
         mod = ops.std_from_moments(mom, self.n_total, tuple(res.shape[1:]), self.eps, like=res, **kw)
-        if segmax is not None:
-            ops.max_scores_pruned(res, mod, segmax, crop, self.scores)
+        if view is not None:
+            ops.max_scores_pruned(resc, icp.canon_cells(mod, icp.canon(res)[1]), segmax, cropc, self.scores)
         else:
             ops.max_scores(res, mod, crop, self.scores)
         self.modulation.append(mod)

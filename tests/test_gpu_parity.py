@@ -779,13 +779,43 @@ def test_pruned_joint_score_equals_full_pass(gpu, shape, crop, monkeypatch):
         assert torch.allclose(full_jc.scores, pruned_jc.scores, rtol=1e-5, atol=0.0, equal_nan=True)
     q1, q2 = full_jc.finish(alphas), pruned_jc.finish(alphas)
     assert torch.allclose(q1, q2, rtol=1e-5, atol=0.0, equal_nan=True)
-    # tensors the pruned form does not take fall back silently: no plane inside the crop, too many segments, a strided
-    # view; and small tensors by default
+    # tensors the pruned form does not take fall back silently: no plane inside the crop, too many segments, a view
+    # that is not dense; and small tensors by default
     assert not ops.can_prune(res, (T, 1, 1))
     assert not ops.can_prune(torch.empty(1, 16 * 65, 256, 64, device=gpu), (0, 0, 0))
-    assert X == 1 or Y == 1 or not ops.can_prune(res.transpose(2, 3), crop)
+    assert Y < 3 or not ops.can_prune(res[..., ::2], crop)                 # not dense
     monkeypatch.undo()
     assert not ops.can_prune(res, crop)
+
+
+@pytest.mark.parametrize("order", [(2, 3, 1), (3, 1, 2), (1, 3, 2)])
+def test_pruned_joint_score_on_permuted_layouts(gpu, order, monkeypatch):
+    """The branch-and-bound score pass on residuals whose cell axes are permuted in memory (``order`` = the logical axes
+    1..3 = t, x, y from slowest to fastest; (2,3,1) is the surrogate's Nt-fastest layout [n,Nx,Ny,Nt]): segments are laid
+    over the MEMORY order, the crop follows the axes - same modulation, scores and q-hat as the full pass on the same view
+    and as the pruned pass on a contiguous copy, over two slabs."""
+    from cp_pre_amd import pipeline
+    ops = pipeline.HipOps
+    monkeypatch.setattr(ops, "PRUNE_MIN_CELLS", 0)
+    monkeypatch.setattr(ops, "PRUNE_MIN_SAMPLES", 0)
+    g = torch.Generator().manual_seed(sum(10 ** i * o for i, o in enumerate(order)))
+    n, crop, alphas = 40, (1, 2, 1), [0.1, 0.5, 0.9]
+    logical = (12, 18, 37)                                                # (T, X, Y)
+    phys = [logical[a - 1] for a in order]
+    back = [0] + [order.index(k) + 1 for k in (1, 2, 3)]                  # memory -> logical
+    jcs = {k: pipeline.JointCalibration(n, gpu, prune=p) for k, p in (("view", True), ("view_full", False), ("copy", True))}
+    inner = tuple(slice(c, e - c) for c, e in zip(crop, logical))
+    for slab in range(2):
+        base = (torch.randn(n, *phys, generator=g) * (0.5 + torch.rand(*phys, generator=g))).to(gpu)
+        res = base.permute(*back)                                         # logical [n,T,X,Y], memory order `phys`
+        assert tuple(res.shape[1:]) == logical and not res.is_contiguous() and ops.can_prune(res, crop)
+        mods = {"view": jcs["view"].add_slab(res, crop=crop), "view_full": jcs["view_full"].add_slab(res, crop=crop),
+                "copy": jcs["copy"].add_slab(res.contiguous(), crop=crop)}
+        for k in ("view_full", "copy"):
+            assert torch.allclose(mods["view"][inner], mods[k][inner], rtol=1e-6, atol=0.0), (order, slab, k)
+            assert torch.allclose(jcs["view"].scores, jcs[k].scores, rtol=1e-5, atol=0.0), (order, slab, k)
+    q = {k: jc.finish(alphas) for k, jc in jcs.items()}
+    assert torch.allclose(q["view"], q["view_full"], rtol=1e-5) and torch.allclose(q["view"], q["copy"], rtol=1e-5)
 
 
 def test_scalar_kth_large_and_absdiff(gpu):
