@@ -63,7 +63,7 @@ namespace {
 constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16;
 constexpr int KA_LATE_WORDS = KA_MAXK * 64 * 32;          // later sweeps (and up to 31-entry collect lists): 80 KiB
 constexpr int KA_FLAGS_AT = 1008;                         // per-wave flags (words 640..1023 are never used otherwise)
-struct KAList { int nk; int k[KA_MAXK]; };
+struct KAList { int nk; int k[KA_MAXK]; int o[KA_MAXK]; };    // ranks (ascending) and the output row of each
 
 template <bool WIDE> struct Ctr {
     static constexpr int CW = WIDE ? 64 : 32;             // words per histogram row
@@ -570,7 +570,7 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
     if (fast) {
         unsigned int key = 0u;
         if (ka_fast<LOG_NB1, WIDE>(col, cok, n, M, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid)) {
-            if (state && cok) out[(long long)wave * M + c] = key2f(key);
+            if (state && cok) out[(long long)kl.o[wave] * M + c] = key2f(key);
             return;
         }
         __syncthreads();                   // (every wave has read the flags before the histogram memory is cleared again)
@@ -605,7 +605,7 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
     __syncthreads();
     if (nanl) hist[lane] = 1u;
     __syncthreads();
-    if (state && cok) out[(long long)wave * M + c] = hist[lane] ? __uint_as_float(0x7fc00000u) : key2f(myp + klo);
+    if (state && cok) out[(long long)kl.o[wave] * M + c] = hist[lane] ? __uint_as_float(0x7fc00000u) : key2f(myp + klo);
 }
 
 // ---- small calibration sets (n <= 128; the reference scripts use n_cal = 100 and 1000): the whole column of a
@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict_
     for (int j = 0; j < KA_MAXK; ++j) {
         if (j >= kl.nk) break;                                    // wave-uniform
         const unsigned int r = ks_take<N>(v, kl.k[j]);
-        if (cok) out[(long long)j * M + c] = nan ? __uint_as_float(0x7fc00000u) : key2f(r);
+        if (cok) out[(long long)kl.o[j] * M + c] = nan ? __uint_as_float(0x7fc00000u) : key2f(r);
     }
 }
 
@@ -760,55 +760,55 @@ __global__ void __launch_bounds__(256) kth_pair_kernel(const float *__restrict__
         if (j >= kl.nk) break;                                    // wave-uniform
         const unsigned int e = ks_take<N>(v, kl.k[j] & (N - 1));
         const unsigned int r = (unsigned int)__shfl((int)e, cell + 32 * (kl.k[j] / N));
-        if (cok && half == 0) out[(long long)j * M + c] = nan ? __uint_as_float(0x7fc00000u) : key2f(r);
+        if (cok && half == 0) out[(long long)kl.o[j] * M + c] = nan ? __uint_as_float(0x7fc00000u) : key2f(r);
     }
 }
 
 template <int N>
-int launch_kth_pair(const float *scores, int n, long long M, const int32_t *ks, int nk, float *out, hipStream_t st)
+int launch_kth_pair(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
 {
     const long long blocks = ((M + 31) / 32 + 3) / 4;
     if (blocks > 0x7fffffffLL) return PRE_E_SHAPE;
     for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
-        for (int j = 0; j < KA_MAXK; ++j) kl.k[j] = j < kl.nk ? ks[j0 + j] : 0;
-        hipLaunchKernelGGL(kth_pair_kernel<N>, dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, kl, out + (long long)j0 * M);
+        for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
+        hipLaunchKernelGGL(kth_pair_kernel<N>, dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, kl, out);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
 }
 
 template <int N>
-int launch_kth_small(const float *scores, int n, long long M, const int32_t *ks, int nk, float *out, hipStream_t st)
+int launch_kth_small(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
 {
     const long long blocks = ((M + KA_W - 1) / KA_W + 3) / 4;
     if (blocks > 0x7fffffffLL) return PRE_E_SHAPE;
     for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
-        for (int j = 0; j < KA_MAXK; ++j) kl.k[j] = j < kl.nk ? ks[j0 + j] : -1;
-        hipLaunchKernelGGL((kth_small_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, kl, out + (long long)j0 * M);
+        for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : -1; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
+        hipLaunchKernelGGL((kth_small_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, kl, out);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
 }
 
 template <int LOG_NB1, bool WIDE>
-int launch_kth(const float *scores, int n, long long M, const int32_t *ks, int nk, float *out, hipStream_t st)
+int launch_kth(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
 {
     const long long tiles = (M + KA_W - 1) / KA_W;
     const long long per_launch = 1LL << 21;                     // x 1024 threads: the dispatch packet counts work-items in 32 bits
     for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
-        for (int j = 0; j < kl.nk; ++j) kl.k[j] = ks[j0 + j];
+        for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
         for (long long t0 = 0; t0 < tiles; t0 += per_launch) {
             const long long nt = tiles - t0 < per_launch ? tiles - t0 : per_launch;
             // the fast first digit pays while a full bucket holds well under CAP elements (n <= ~6 NB1 on
             // bell-shaped scores); beyond that it would be a wasted sweep
             hipLaunchKernelGGL((kth_axis0_kernel<LOG_NB1, WIDE>), dim3((unsigned)nt), dim3(1024), 0, st, scores, n, M, t0, kl,
-                               n <= 6 * (1 << LOG_NB1) ? 1 : 0, out + (long long)j0 * M);
+                               n <= 6 * (1 << LOG_NB1) ? 1 : 0, out);
             PRE_LAUNCH_CHECK();
         }
     }
@@ -821,17 +821,23 @@ extern "C" int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, cons
 {
     if (!scores || !ks || !out || n <= 0 || M <= 0 || nk <= 0) return PRE_E_NULL;
     if (n > 0x7fffffff || nk > 64) return PRE_E_SHAPE;
+    // the kernels want ascending ranks (their slots rely on it): sort here, each result goes to its caller's row
+    int32_t sk[64], rows[64];
     for (int j = 0; j < nk; ++j) {
         if (ks[j] < 0 || ks[j] >= n) return PRE_E_RANGE;
-        if (j > 0 && ks[j] < ks[j - 1]) return PRE_E_RANGE;      // ascending (slots rely on it)
+        int i = j;
+        for (; i > 0 && sk[i - 1] > ks[j]; --i) { sk[i] = sk[i - 1]; rows[i] = rows[i - 1]; }
+        sk[i] = ks[j];
+        rows[i] = j;
     }
+    ks = sk;
     hipStream_t st = as_stream(stream);
-    if (n <= 64) return launch_kth_small<64>(scores, (int)n, (long long)M, ks, nk, out, st);
-    if (n <= 128) return launch_kth_small<128>(scores, (int)n, (long long)M, ks, nk, out, st);
-    if (n <= 256 && 128 * M * 4 < 0xffffffffLL) return launch_kth_pair<128>(scores, (int)n, (long long)M, ks, nk, out, st);
+    if (n <= 64) return launch_kth_small<64>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    if (n <= 128) return launch_kth_small<128>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    if (n <= 256 && 128 * M * 4 < 0xffffffffLL) return launch_kth_pair<128>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     // 16-bit counters hold n < 65536; 1024 first-digit buckets (one workgroup per CU) pay off once 512 buckets
     // would leave more than CAP elements per bucket (n above ~2000)
-    if (n >= 65536) return launch_kth<9, true>(scores, (int)n, (long long)M, ks, nk, out, st);
-    if (n > 2048) return launch_kth<10, false>(scores, (int)n, (long long)M, ks, nk, out, st);
-    return launch_kth<9, false>(scores, (int)n, (long long)M, ks, nk, out, st);
+    if (n >= 65536) return launch_kth<9, true>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    if (n > 2048) return launch_kth<10, false>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    return launch_kth<9, false>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
 }

@@ -103,23 +103,23 @@ def kth_axis0(scores, ks):
     lib = _lib.load()
     scores, cell_order = canon(scores)
     n = scores.shape[0]
-    order = sorted(range(len(ks)), key=lambda i: ks[i])
-    sk = [int(ks[i]) for i in order]
     with torch.cuda.device(scores.device):
         if scores.dim() == 1:
+            order = sorted(range(len(ks)), key=lambda i: ks[i])     # the scalar select wants ascending ranks
+            sk = [int(ks[i]) for i in order]
             out = torch.empty(len(sk), dtype=torch.float32, device=scores.device)
             _lib.check(lib.pre_kth_f32(_lib.ptr(scores), n, _lib.iarr64(sk), len(sk), _lib.ptr(out), _lib.stream()),
                        "pre_kth_f32")
+            inv = [0] * len(ks)
+            for pos, i in enumerate(order):
+                inv[i] = pos
+            if inv != list(range(len(ks))):      # device-only reorder (no index upload: stays HIP-graph capturable)
+                out = out.flip(0) if inv == list(range(len(ks) - 1, -1, -1)) else torch.stack([out[i] for i in inv])
         else:
             M = scores.numel() // n
-            out = torch.empty((len(sk),) + tuple(scores.shape[1:]), dtype=torch.float32, device=scores.device)
-            _lib.check(lib.pre_kth_axis0_f32(_lib.ptr(scores), n, M, _lib.iarr32(sk), len(sk), _lib.ptr(out),
-                                             _lib.stream()), "pre_kth_axis0_f32")
-    inv = [0] * len(ks)
-    for pos, i in enumerate(order):
-        inv[i] = pos
-    if inv != list(range(len(ks))):              # device-only reorder (no index upload: stays HIP-graph capturable)
-        out = out.flip(0) if inv == list(range(len(ks) - 1, -1, -1)) else torch.stack([out[i] for i in inv])
+            out = torch.empty((len(ks),) + tuple(scores.shape[1:]), dtype=torch.float32, device=scores.device)
+            _lib.check(lib.pre_kth_axis0_f32(_lib.ptr(scores), n, M, _lib.iarr32([int(k) for k in ks]), len(ks), _lib.ptr(out),
+                                             _lib.stream()), "pre_kth_axis0_f32")      # (any rank order: out[j] <-> ks[j])
     return uncanon(out, cell_order, 1)
 
 

@@ -202,8 +202,8 @@ int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float
  * ks: host array of 0-based sorted ranks (the caller derives them from alpha).
  * pre_kth_f32:       scores[N]            -> out[nk]; any NaN score makes every result NaN (np.quantile)
  * pre_kth_axis0_f32: scores[n, M] contiguous -> out[nk, M]   (per-cell over the batch axis),
- *                    n < 2^31 (32-bit counters from n = 65536 on), ks ascending, nk <= 64; a NaN anywhere in
- *                    a cell's column makes every result of that cell NaN (np.quantile). */
+ *                    n < 2^31 (32-bit counters from n = 65536 on), ks in any order (out[j] belongs to ks[j]),
+ *                    nk <= 64; a NaN anywhere in a cell's column makes every result of that cell NaN (np.quantile). */
 int pre_kth_f32(const float *scores, int64_t N, const int64_t *ks /*host*/, int nk, float *out, void *stream);
 int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks /*host*/, int nk,
                       float *out, void *stream);

@@ -128,8 +128,20 @@ int main(void)
             for (int j = 0; j < 3; ++j) exact &= (hq[j * M + c] == col[ks[j]]);
         }
         EXPECT(rc == PRE_OK && rc2 == PRE_OK && exact, "pre_absdiff_f32 + pre_kth_axis0_f32: bit-exact vs qsort per cell");
-        int32_t bad[2] = {5, 2};
-        EXPECT(pre_kth_axis0_f32(dout, n, M, bad, 2, dq, st) == PRE_E_RANGE, "descending ranks -> PRE_E_RANGE");
+        /* ranks in any order: out[j] belongs to ks[j] */
+        int32_t mixed[3] = {ks[2], ks[0], ks[1]};
+        int rc3 = pre_kth_axis0_f32(dout, n, M, mixed, 3, dq, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(hq, dq, sizeof hq, hipMemcpyDeviceToHost));
+        int exact2 = 1;
+        for (int c = 0; c < M; ++c) {
+            for (int i = 0; i < n; ++i) col[i] = fabsf(hu[i * M + c] - hv[i * M + c]);
+            qsort(col, n, sizeof(float), cmp_float);
+            for (int j = 0; j < 3; ++j) exact2 &= (hq[j * M + c] == col[mixed[j]]);
+        }
+        EXPECT(rc3 == PRE_OK && exact2, "pre_kth_axis0_f32: ranks in any order, out[j] <-> ks[j]");
+        int32_t bad[2] = {2, (int32_t)n};
+        EXPECT(pre_kth_axis0_f32(dout, n, M, bad, 2, dq, st) == PRE_E_RANGE, "rank >= n -> PRE_E_RANGE");
         EXPECT(pre_kth_axis0_f32(NULL, n, M, ks, 3, dq, st) == PRE_E_NULL, "null pointer -> PRE_E_NULL");
         CHECK_HIP(hipFree(dq));
     }
