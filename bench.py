@@ -389,7 +389,15 @@ def main():
         # Smaller per-rank batches (--scaling strong, --batch) afford thicker slabs, up to the whole T axis (no halo).
         extra = 4 * (4 << 30) if (args.mode == "marginal" and world > 1) else 0       # the exchange's staging buffers
         cands = [c for c in (args.nt, (args.nt + 1) // 2, (args.nt + 2) // 3, 16, 13, 8) if 0 < c <= args.nt]
-        args.slab = next((c for c in cands if resident_bytes(B, args.nt, c, X, Y) + extra <= free - (4 << 30)), 8)
+        idx = next((i for i, c in enumerate(cands) if resident_bytes(B, args.nt, c, X, Y) + extra <= free - (4 << 30)),
+                   len(cands) - 1)
+        if group is not None:
+            # the ranks must stream the SAME slabs (the per-slab collectives carry one slab's cells): free memory differs
+            # a little from GPU to GPU, so take the most conservative choice of any rank
+            t = torch.tensor([idx], dtype=torch.int64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+            idx = int(t.item())
+        args.slab = cands[idx]
     slabs = split_slabs(args.nt, args.slab)                   # interior planes per slab position
     n_slabs, S = len(slabs), max(slabs)
     alphas = [float(a) for a in icp.ALPHA_LEVELS]
@@ -401,8 +409,14 @@ def main():
     # n_slabs - 1 extra samples: slab position s reads the batch window [s, s + B), so no two slab passes of a
     # step see the same input (and no layer of the memory system could serve one from another)
     need = resident_bytes(B, args.nt, args.slab, X, Y)
-    if need > free - (2 << 30):
+    short = need > free - (2 << 30)
+    if short:
         print(f"bench.py: --slab {args.slab} needs {need / 1e9:.0f} GB resident, {free / 1e9:.0f} GB free", file=sys.stderr, flush=True)
+    if group is not None:                                    # every rank leaves, or none (a lone exit would hang the others)
+        t = torch.tensor([int(short)], dtype=torch.int64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+        short = bool(t.item())
+    if short:
         return 2
     vars_ = torch.empty(B + n_slabs - 1, 3, S + 2, X, Y, dtype=torch.float32, device=dev)
     for i in range(3):
