@@ -387,8 +387,8 @@ def main():
         # fewer, thicker slabs re-read fewer halo planes (64 planes: 16 -> 4 slabs, 13 -> 5, 8 -> 8); the resident
         # set of S = 16 at the full batch is 301 GB of the 309 GB the device reports, so it is taken only if it fits.
         # Smaller per-rank batches (--scaling strong, --batch) afford thicker slabs, up to the whole T axis (no halo).
-        extra = 4 * (4 << 30) if (args.mode == "marginal" and world > 1) else 0       # the exchange's staging buffers
-        extra += (1 << 30) if world > 1 else 0                 # headroom for RCCL's own scratch beyond the warm-up collective
+        extra = 4 * (4 << 30) if (args.mode == "marginal" and group is not None) else 0   # the exchange's staging buffers
+        extra += (1 << 30) if group is not None else 0                 # headroom for RCCL's own scratch beyond the warm-up collective
         cands = [c for c in (args.nt, (args.nt + 1) // 2, (args.nt + 2) // 3, 16, 13, 8) if 0 < c <= args.nt]
         idx = next((i for i, c in enumerate(cands) if resident_bytes(B, args.nt, c, X, Y) + extra <= free - (4 << 30)),
                    len(cands) - 1)
