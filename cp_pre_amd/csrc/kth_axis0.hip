@@ -177,6 +177,15 @@ __device__ __forceinline__ void ka_sweep(const float *__restrict__ col, bool cok
     for (; i < n; i += KA_WAVES) { f(ka_row(p, loff)); p += stride; }
 }
 
+// where a sweep takes the tile's elements from: memory (every sweep re-reads the column tile)
+struct HbmSrc {
+    const float *col;
+    bool cok;
+    int n;
+    long long M;
+    int wave;
+    template <int U, class F> __device__ __forceinline__ void sweep(F &&f) const { ka_sweep<U>(col, cok, n, M, wave, f); }
+};
 // the match against the cell's prefixes costs 2 VALU instructions per slot and element: instantiate the sweep for
 // a few static slot counts and branch (wave-uniformly) on the tile's actual maximum
 template <class G>
@@ -427,18 +436,18 @@ __device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok,
 // ---- step 1, general form: buckets (key - klo) >> shift (clamped to the overflow bucket NB1-1) in rows
 // 0..NB1-1, row NB1 = key < klo.  `window`: a rank that lands in the overflow bucket or below the window is
 // reported through `outside`.  Returns (block-uniform) whether some pair has more than CAP elements left.
-template <int LOG_NB1, bool WIDE>
-__device__ __forceinline__ bool ka_first(const float *__restrict__ col, bool cok, int n, long long M, int nk, int shift,
+template <int LOG_NB1, bool WIDE, int U, int CAP, class Src>
+__device__ __forceinline__ bool ka_first(const Src &src, int nk, int shift,
                                          unsigned int klo, bool window, unsigned int *hist, unsigned int &myp,
                                          unsigned int &myr, bool &outside, bool &nanl, int lane, int wave, int tid)
 {
     using C = Ctr<WIDE>;
-    constexpr int NB1 = 1 << LOG_NB1, U = KACfg<LOG_NB1, WIDE>::U, CAP = KACfg<LOG_NB1, WIDE>::CAP;
+    constexpr int NB1 = 1 << LOG_NB1;
     const bool state = wave < nk;
     for (int i = tid; i < (NB1 + 1) * C::CW; i += 1024) hist[i] = 0u;
     __syncthreads();
     const unsigned int inc = C::inc(lane);
-    ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+    src.template sweep<U>([&](float v) __attribute__((always_inline)) {
         nanl |= v != v;                    // (this sweep sees every element of my cell in my wave's rows)
         const unsigned int key = f2key(v);
         const unsigned int d = min((key - klo) >> shift, (unsigned)(NB1 - 1));
@@ -462,8 +471,8 @@ __device__ __forceinline__ bool ka_first(const float *__restrict__ col, bool cok
 // cell; shift + BITS may exceed pshift for the last digit: the overlapping bits are fixed by the prefix match, so
 // only consistent bins fill; a cell that is already fully known, pshift == 0, just recounts its ties).  Returns
 // whether some pair still has more than CAP elements under its prefix.
-template <int BITS, bool WIDE, int U, int CAP>
-__device__ __forceinline__ bool ka_pass(const float *__restrict__ col, bool cok, int n, long long M, int nk, int pshift,
+template <int BITS, bool WIDE, int U, int CAP, class Src>
+__device__ __forceinline__ bool ka_pass(const Src &src, int nk, int pshift,
                                         int shift, unsigned int klo, unsigned int *hist, unsigned int &myp,
                                         unsigned int &myr, int lane, int wave, int tid)
 {
@@ -479,7 +488,7 @@ __device__ __forceinline__ bool ka_pass(const float *__restrict__ col, bool cok,
 
     const unsigned int inc = C::inc(lane);
     ka_by_slots(lmax, [&](auto lm) __attribute__((always_inline)) {
-        ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+        src.template sweep<U>([&](float v) __attribute__((always_inline)) {
             const unsigned int kk = ka_kk(v, klo);
             const int m = ka_match<decltype(lm)::value>(kk & mask, pf);
             if (m) atomicAdd(&hist[C::word((m - 1) * NB + (int)((kk >> shift) & (NB - 1)), lane)], inc);
@@ -516,8 +525,8 @@ __device__ __forceinline__ bool ka_pass(const float *__restrict__ col, bool cok,
 // ---- step 3, general form: every (cell, rank) of the tile has at most CAP elements left under its prefix
 // (known down to bit `known`, per cell): ONE sweep appends each surviving kk to the list of its slot -
 // list[slot][i][cell], fill counter in row CAP - and the owner thread picks its rank.
-template <int U, int LS>
-__device__ __forceinline__ void ka_collect(const float *__restrict__ col, bool cok, int n, long long M, int nk, int known,
+template <int U, int LS, class Src>
+__device__ __forceinline__ void ka_collect(const Src &src, int nk, int known,
                                            unsigned int klo, unsigned int *hist, unsigned int &myp, unsigned int myr,
                                            int lane, int wave, int tid)
 {
@@ -529,7 +538,7 @@ __device__ __forceinline__ void ka_collect(const float *__restrict__ col, bool c
     __syncthreads();
 
     ka_by_slots(lmax, [&](auto lm) __attribute__((always_inline)) {
-        ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+        src.template sweep<U>([&](float v) __attribute__((always_inline)) {
             const unsigned int kk = ka_kk(v, klo);
             const int m = ka_match<decltype(lm)::value>(kk & mask, pf);
             if (m) {
@@ -549,7 +558,7 @@ __device__ __forceinline__ void ka_collect(const float *__restrict__ col, bool c
 
 template <int LOG_NB1, bool WIDE>
 __global__ void __launch_bounds__(1024, (4 * KACfg<LOG_NB1, WIDE>::WG_PER_CU))
-kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile0, const KAList kl, int fast,
+kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile0, const KAList kl, int fast, int marked,
                  float *__restrict__ out)
 {
     using Cfg = KACfg<LOG_NB1, WIDE>;
@@ -559,6 +568,8 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
     const int nk = kl.nk;
     const long long c0 = (tile0 + blockIdx.x) * KA_W, c = c0 + lane;
     const bool cok = c < M;
+    // behind kth_tile_kernel: only the tiles it marked (block-uniform; the mark is overwritten by the result at the end)
+    if (marked && __float_as_uint(out[(long long)kl.o[0] * M + c0]) != 0xffc0deadu) return;
     const float *col = s + c0;             // the tile's first cell: wave-uniform (lane offsets are added at the loads)
     const bool state = wave < nk;
     const unsigned int k0 = state ? (unsigned)kl.k[wave] : 0u;
@@ -577,8 +588,9 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
     }
     unsigned int myp = 0u, myr = k0;
     bool many = true, nanl = false;
+    const HbmSrc src{col, cok, n, M, wave};
     if (!outside) {
-        many = ka_first<LOG_NB1, WIDE>(col, cok, n, M, nk, shift, klo, true, hist, myp, myr, outside, nanl, lane, wave, tid);
+        many = ka_first<LOG_NB1, WIDE, U, Cfg::CAP>(src, nk, shift, klo, true, hist, myp, myr, outside, nanl, lane, wave, tid);
         if (outside) __syncthreads();
     }
     if (outside) {                         // some rank lies outside its cell's sampled window: plain top digit
@@ -586,18 +598,18 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
         shift = 32 - LOG_NB1;
         myp = 0u;
         myr = k0;
-        many = ka_first<LOG_NB1, WIDE>(col, cok, n, M, nk, shift, klo, false, hist, myp, myr, outside, nanl, lane, wave, tid);
+        many = ka_first<LOG_NB1, WIDE, U, Cfg::CAP>(src, nk, shift, klo, false, hist, myp, myr, outside, nanl, lane, wave, tid);
     }
     int known = shift;                     // lowest known bit of my cell's kk so far (per lane)
 #pragma unroll 1
     while (many) {
         const int sh = known > BITS ? known - BITS : 0;
-        many = ka_pass<BITS, WIDE, U, Cfg::CAP>(col, cok, n, M, nk, known, sh, klo, hist, myp, myr, lane, wave, tid);
+        many = ka_pass<BITS, WIDE, U, Cfg::CAP>(src, nk, known, sh, klo, hist, myp, myr, lane, wave, tid);
         known = sh;
     }
     __syncthreads();
     if (ka_or(hist, __ballot(state && known > 0) != 0 ? 1u : 0u, lane, wave))      // else every bit of every cell is counted
-        ka_collect<U, Cfg::LS>(col, cok, n, M, nk, known, klo, hist, myp, myr, lane, wave, tid);
+        ka_collect<U, Cfg::LS>(src, nk, known, klo, hist, myp, myr, lane, wave, tid);
     // np.quantile: a NaN anywhere in a cell's column makes every quantile of that cell NaN (the fast form never
     // finishes a tile that holds one).  Cell flags are OR-ed across the waves through 64 LDS words.
     __syncthreads();
@@ -606,6 +618,316 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
     if (nanl) hist[lane] = 1u;
     __syncthreads();
     if (state && cok) out[(long long)kl.o[wave] * M + c] = hist[lane] ? __uint_as_float(0x7fc00000u) : key2f(myp + klo);
+}
+
+// ---- 256 < n <= 1024: the tile lives in REGISTERS ---------------------------------------------------------------
+// (the reference's own calibration sets: n_cal = 1000, Marginal/Wave_Residuals_CP.py:284-290; BASELINE C2: n = 512.)
+// At these n the sweeps above are short - 16 to 64 rows per thread - and what a tile costs is the chain
+// sample -> count -> narrow -> collect -> pick with an HBM round trip per batch of loads, twice over, plus two reads of
+// the scores.  Here ONE persistent 1024-thread workgroup per CU keeps the whole 64-cell tile in its registers
+// (thread (wave, lane) holds rows wave, wave + 16, ... of cell lane: R = 32 or 64 registers), so the scores are read
+// from HBM exactly ONCE, every sweep runs out of registers, and the window of a cell is its exact [min, max] instead
+// of a sample's.  The next tile is loaded INTO THE SAME REGISTERS while the last sweep of the current one consumes
+// them (row u is re-loaded right after its element has been collected), so the loads are in flight during the rest
+// of that sweep, the pick and the next tile's set-up; the barriers in between fence the LDS only and leave vmcnt
+// alone.  The arithmetic is the fast form's: NB1 value-linear buckets over the window (16-bit counters, two cells
+// per word), narrow, then every element looks its row up in a byte map "which list wants this row" and the owner
+// picks its rank among the <= CAP candidates; cells whose column is constant, or holds a NaN, are settled by the window
+// alone.  Tiles the fast form cannot finish (a bucket above CAP: ties, one huge outlier stretching the window; an
+// infinite window) run the general radix form above, streaming the tile again (it is still in L2 / the Infinity Cache).
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+constexpr unsigned int KT_MARK = 0xffc0dead;      // "left to the streaming kernel" (results are input values or 0x7fc00000)
+
+template <int LOG_NB1>
+struct KTCfg {
+    static constexpr int NB1 = 1 << LOG_NB1, LS = 32, CAP = LS - 1;
+    static constexpr int FIRST_WORDS = (NB1 + 1) * 32 + KA_WAVES * 64;       // first-digit histogram + group sums
+    static constexpr int LIST_WORDS = KA_MAXK * LS * 64;                     // (aliases the histogram: filled after the narrowing)
+    static constexpr int W1 = FIRST_WORDS > LIST_WORDS ? FIRST_WORDS : LIST_WORDS;
+    static constexpr int WORDS = W1 > KA_LATE_WORDS ? W1 : KA_LATE_WORDS;
+    static constexpr int MAP_WORDS = (NB1 + 1) * 16;                         // a byte per (row, cell): list + 1, 0 = not wanted
+    // side arrays that are NOT aliased: window (min key, max key, NaN flag per cell), published rows, list fill
+    // counters, per-wave flags
+    static constexpr int WIN_AT = 0, PUB_AT = 192, CNT_AT = PUB_AT + KA_MAXK * 64, FLG_AT = CNT_AT + KA_MAXK * 64,
+                         CMX_AT = FLG_AT + KA_WAVES, SIDE_WORDS = CMX_AT + KA_WAVES;
+    static_assert((WORDS + MAP_WORDS + SIDE_WORDS) * 4 <= 160 * 1024, "does not fit the 160 KiB LDS");
+};
+
+// one row of a tile: 64 consecutive floats at the wave-uniform address p, `valid` bytes of them inside the tensor
+// (0: a row beyond n, or no next tile - the load then returns 0 and moves nothing)
+__device__ __forceinline__ float kt_row(const float *p, int valid, int loff)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, valid, 0x00020000);
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, loff, 0, 0));
+}
+
+// (loop-invariant values derived from the lane / wave index - LDS addresses for every phase, 64 row offsets, 64
+// comparisons u < nu - are otherwise all hoisted out of the tile loop and kept live next to the 64 data registers:
+// the phases take opaque copies, so that each recomputes the few it needs)
+__device__ __forceinline__ int kt_opq_v(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int kt_opq_s(int x) { asm volatile("" : "+s"(x)); return x; }
+__device__ __forceinline__ float kt_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float kt_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// the narrowing after the first-digit sweep of the register-resident form (exact window: nothing below it, nothing in
+// the overflow row).  Same walks as ka_narrow_first, kept short in registers: the tile's 64 data registers are live.
+template <int LOG_NB1>
+__device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsigned int &myr, int &digit, unsigned int &count,
+                                          int lane, int wave)
+{
+    constexpr int NB1 = 1 << LOG_NB1, GB = NB1 / KA_WAVES, GROUPS_AT = (NB1 + 1) * 32;
+    const int l31 = lane & 31, sh = 16 * (lane >> 5);
+    // 16 groups of GB bins (rows 1 + d) are summed by all 1024 threads first; the two cells of a word are added
+    // together (no carry: a sum is at most n < 65536) and taken apart at the end
+    {
+        unsigned int gs = 0;
+        const unsigned int *h = hist + (1 + wave * GB) * 32 + l31;
+#pragma unroll 4
+        for (int u = 0; u < GB; ++u) gs += h[u * 32];
+        hist[GROUPS_AT + wave * 64 + lane] = (gs >> sh) & 0xffffu;
+    }
+    __syncthreads();
+    digit = 0;
+    count = 0;
+    if (state) {
+        unsigned int run = 0, cum = 0;
+        int g = 0;
+#pragma unroll 4
+        for (int u = 0; u < KA_WAVES; ++u) {
+            run += hist[GROUPS_AT + u * 64 + lane];
+            const bool le = run <= myr;
+            g += le;
+            cum = le ? run : cum;
+        }
+        g = min(g, KA_WAVES - 1);
+        const unsigned int *h = hist + (1 + g * GB) * 32 + l31;
+        run = cum;
+        int d = 0;
+#pragma unroll 4
+        for (int u = 0; u < GB; ++u) {
+            run += (h[u * 32] >> sh) & 0xffffu;
+            const bool le = run <= myr;
+            d += le;
+            cum = le ? run : cum;
+        }
+        d = min(d, GB - 1);
+        digit = g * GB + d;
+        count = (h[d * 32] >> sh) & 0xffffu;
+        myr -= cum;
+    }
+}
+
+template <int LOG_NB1, int R>
+__global__ void __launch_bounds__(1024, 4)
+kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntiles, const KAList kl, float *__restrict__ out)
+{
+    using Cfg = KTCfg<LOG_NB1>;
+    using C = Ctr<false>;
+    constexpr int NB1 = Cfg::NB1, LS = Cfg::LS, CAP = Cfg::CAP;
+    __shared__ unsigned int hist[Cfg::WORDS];
+    __shared__ unsigned int mapw[Cfg::MAP_WORDS];
+    __shared__ unsigned int side[Cfg::SIDE_WORDS];
+    unsigned char *map = reinterpret_cast<unsigned char *>(mapw);
+    unsigned int *win = side + Cfg::WIN_AT, *pub = side + Cfg::PUB_AT, *cnt = side + Cfg::CNT_AT, *flg = side + Cfg::FLG_AT;
+    unsigned int *cmx = side + Cfg::CMX_AT;
+    const int tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int nk = kl.nk;
+
+    // one-time LDS state: empty byte map, zero list counters, empty window
+    for (int i = tid0; i < Cfg::MAP_WORDS; i += 1024) mapw[i] = 0u;
+    for (int i = tid0; i < Cfg::SIDE_WORDS; i += 1024) side[i] = i < 64 ? 0xffffffffu : 0u;
+
+    long long tile = blockIdx.x;
+    float v[R];
+    {
+        const long long c0 = tile * KA_W;
+        const int valid = (int)((M - c0) * 4 < 256 ? (M - c0) * 4 : 256);
+        const int nu = (n - wave0 + KA_WAVES - 1) / KA_WAVES;
+        const float *p = s + c0 + (long long)wave0 * M;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            v[u] = kt_row(p, u < nu ? valid : 0, (tid0 & 63) * 4);
+            p += (long long)KA_WAVES * M;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int wave = kt_opq_s(wave0);
+        const bool state = wave < nk;
+        const unsigned int k0 = state ? (unsigned)kl.k[wave] : 0u;
+        const int nu0 = (n - wave + KA_WAVES - 1) / KA_WAVES;      // my rows below n (wave-uniform; host: R/2 < nu0 <= R)
+
+        // ---- the cell's exact window; clear the histogram meanwhile
+        {
+            const int lane = kt_opq_v(tid0) & 63, nu = kt_opq_s(nu0);
+            float mn = v[0], mx = v[0];
+            bool nanl = v[0] != v[0];
+#pragma unroll
+            for (int u = 1; u < R; ++u)
+                if (u < R / 2 || u < nu) {
+                    mn = kt_min(mn, v[u]);
+                    mx = kt_max(mx, v[u]);
+                    nanl |= v[u] != v[u];
+                }
+            // (v_min / v_max return the other operand when one is a NaN; a column of NaNs only leaves a NaN, whose key is
+            // above every number's either way - such a cell is settled by its flag)
+            atomicMin(&win[lane], f2key(mn));
+            atomicMax(&win[64 + lane], f2key(mx));
+            if (nanl) win[128 + lane] = 1u;
+            uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+            for (int i = kt_opq_v(tid0); i < ((NB1 + 1) * 32) / 4; i += 1024) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+        unsigned int kmin, kmax;
+        float vlo, sf;
+        bool flat, badwin, nancell;
+        {
+            const int lane = kt_opq_v(tid0) & 63;
+            kmin = win[lane];
+            kmax = win[64 + lane];
+            nancell = win[128 + lane] != 0u;
+            vlo = key2f(kmin);
+            const float r = key2f(kmax) - vlo;
+            // a constant column (r == 0) or one with a NaN (whatever its other values): settled by the window alone
+            flat = !(r > 0.f) || nancell;
+            sf = ((float)(NB1 - 1) / r) * 0.999999f;
+            badwin = !flat && (!(r < __builtin_inff()) || !(fabsf(vlo) < __builtin_inff()) || !(sf < __builtin_inff()));
+            if (flat || badwin) sf = 0.f;
+        }
+
+        // ---- first digit: NB1 - 1 value-linear buckets over the window (rows 1 .. NB1-1; rows 0 and NB1 stay empty)
+        {
+            const int lane = kt_opq_v(tid0) & 63, nu = kt_opq_s(nu0);
+            const unsigned int inc = C::inc(lane);
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (u < R / 2 || u < nu) atomicAdd(&hist[C::word(ka_frow<NB1>(v[u], sf, vlo), lane)], inc);
+        }
+        __syncthreads();
+        unsigned int myr = k0, count, fl;
+        int digit;
+        bool open;
+        {
+            const int lane = kt_opq_v(tid0) & 63;
+            if (wave == KA_WAVES - 1) {                              // (everyone has read the window)
+                win[lane] = 0xffffffffu;
+                win[64 + lane] = 0u;
+                win[128 + lane] = 0u;
+            }
+            kt_narrow<LOG_NB1>(hist, state, myr, digit, count, lane, wave);
+            open = state && !flat;
+            const bool bad = open && badwin, many = open && count > (unsigned)CAP;
+            if (state) pub[wave * 64 + lane] = open ? (unsigned)(digit + 1) : 0u;
+            const unsigned int w = (__ballot(many) != 0 ? 1u : 0u) | (__ballot(bad) != 0 ? 2u : 0u);
+            if (lane == 0) flg[wave] = w;
+            __syncthreads();                                        // the histograms are read, rows and flags published
+            fl = flg[lane & (KA_WAVES - 1)];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) fl |= __shfl_xor(fl, o);
+            fl = __builtin_amdgcn_readfirstlane(fl);
+        }
+
+        const long long c0 = tile * KA_W;
+        const bool more = tile + gridDim.x < ntiles;               // (block-uniform)
+        const long long nc0 = more ? (tile + gridDim.x) * KA_W : c0;
+        const int nvalid = more ? (int)((M - nc0) * 4 < 256 ? (M - nc0) * 4 : 256) : 0;
+        const float *nbase = s + nc0 + (long long)wave * M;        // my first row of the next tile
+
+        // ---- collect + pick (when every pair has its <= CAP candidates: ok, block-uniform).  The list of a rank = the
+        // list of the FIRST rank of its cell with the same row.
+        const bool ok = fl == 0u;
+        const int myrow = digit + 1;
+        int myslot = wave, cmax = 0;
+        bool first = false;
+        if (ok) {
+            const int lane = kt_opq_v(tid0) & 63;
+            if (open) {
+#pragma unroll
+                for (int j = KA_MAXK - 1; j >= 0; --j)
+                    if (j < wave && pub[j * 64 + lane] == (unsigned)myrow) myslot = j;
+            }
+            first = open && myslot == wave;
+            cmax = open ? (int)count : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+            cmax = __builtin_amdgcn_readfirstlane(cmax);
+            if (first) map[myrow * 64 + lane] = (unsigned char)(wave + 1);
+            if (lane == 0) cmx[wave] = (unsigned)cmax;
+        }
+        __syncthreads();
+        {
+            // (the map is opaque to the optimiser: left alone it keeps the 64 row numbers of the first sweep for this
+            // one - in scratch memory, whose loads then queue behind the prefetch below and make every element wait)
+            float sf2 = sf, vlo2 = vlo;
+            asm volatile("" : "+v"(sf2), "+v"(vlo2));
+            const int lane = kt_opq_v(tid0) & 63, nu = kt_opq_s(nu0);
+            const float *np = nbase;
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const bool live = u < R / 2 || u < nu;
+                if (live && ok) {
+                    const float x = v[u];
+                    const int m = map[ka_frow<NB1>(x, sf2, vlo2) * 64 + lane];
+                    if (m) {
+                        const unsigned int pos = atomicAdd(&cnt[(m - 1) * 64 + lane], 1u);
+                        if (pos < (unsigned)CAP) hist[ka_list<LS>(m - 1, (int)pos, lane)] = f2key(x);   // (always: the histogram counted them)
+                    }
+                }
+                // the next tile, row by row into the register just consumed.  An unconditional load - rows beyond n, or
+                // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
+                // being finished or not: no copy has to wait for it here, no second definition to reconcile
+                v[u] = kt_row(np, live ? nvalid : 0, lane * 4);
+                np += (long long)KA_WAVES * M;
+            }
+        }
+        if (ok) {
+            // the pick's sentinels: a list is read by every rank that shares its row, up to the longest list of that
+            // rank's wave - so up to the longest list of the tile
+            const int lane = kt_opq_v(tid0) & 63;
+            unsigned int cb = cmx[lane & (KA_WAVES - 1)];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) cb = max(cb, (unsigned)__shfl_xor((int)cb, o));
+            const int cmaxb = (int)__builtin_amdgcn_readfirstlane(cb);
+            if (first)
+                for (int i = (int)count; i < cmaxb; ++i) hist[ka_list<LS>(wave, i, lane)] = 0xffffffffu;
+        }
+        lds_barrier();
+        if (ok) {
+            const int lane = kt_opq_v(tid0) & 63;
+            unsigned int ans = kmin;                                // flat: the column's one value
+            if (open) {
+                ans = 0xffffffffu;
+                for (int i = 0; i < cmax; ++i) {
+                    const unsigned int ki = hist[ka_list<LS>(myslot, i, lane)];
+                    unsigned int le = 0;
+                    for (int j = 0; j < cmax; ++j) le += hist[ka_list<LS>(myslot, j, lane)] <= ki;
+                    if (i < (int)count && le > myr) ans = min(ans, ki);
+                }
+            }
+            const long long c = c0 + lane;
+            if (state && c < M) out[(long long)kl.o[wave] * M + c] = nancell ? __uint_as_float(0x7fc00000u) : key2f(ans);
+            if (first) {                                            // leave the map and the counters as they were found
+                map[myrow * 64 + lane] = 0;
+                cnt[wave * 64 + lane] = 0u;
+            }
+        } else if (tid0 == 0) {
+            // not finished by the fast form (a bucket above CAP: ties, an outlier stretching the window; an infinite
+            // window): the tile is MARKED - a NaN pattern no result can have, in the first rank's output of its first
+            // cell - for the streaming kernel, which the host launches behind this one over the marked tiles only (its
+            // code in this loop would share the register file with the 64 data registers: measured, a quarter of them
+            // spilled)
+            out[(long long)kl.o[0] * M + c0] = __uint_as_float(KT_MARK);
+        }
+        lds_barrier();
+    }
 }
 
 // ---- small calibration sets (n <= 128; the reference scripts use n_cal = 100 and 1000): the whole column of a
@@ -795,11 +1117,13 @@ int launch_kth_small(const float *scores, int n, long long M, const int32_t *ks,
 }
 
 template <int LOG_NB1, bool WIDE>
-int launch_kth(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
+int launch_kth(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st,
+               int marked = 0, int j_only = -1)
 {
     const long long tiles = (M + KA_W - 1) / KA_W;
     const long long per_launch = 1LL << 21;                     // x 1024 threads: the dispatch packet counts work-items in 32 bits
     for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
+        if (j_only >= 0 && j0 != j_only) continue;
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
@@ -808,9 +1132,30 @@ int launch_kth(const float *scores, int n, long long M, const int32_t *ks, const
             // the fast first digit pays while a full bucket holds well under CAP elements (n <= ~6 NB1 on
             // bell-shaped scores); beyond that it would be a wasted sweep
             hipLaunchKernelGGL((kth_axis0_kernel<LOG_NB1, WIDE>), dim3((unsigned)nt), dim3(1024), 0, st, scores, n, M, t0, kl,
-                               n <= 6 * (1 << LOG_NB1) ? 1 : 0, out);
+                               n <= 6 * (1 << LOG_NB1) ? 1 : 0, marked, out);
             PRE_LAUNCH_CHECK();
         }
+    }
+    return PRE_OK;
+}
+
+template <int LOG_NB1, int R>
+int launch_kth_tile(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
+{
+    const long long tiles = (M + KA_W - 1) / KA_W;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const long long grid = tiles < cus ? tiles : cus;             // one persistent workgroup per CU
+    for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
+        KAList kl;
+        kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
+        for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
+        hipLaunchKernelGGL((kth_tile_kernel<LOG_NB1, R>), dim3((unsigned)grid), dim3(1024), 0, st, scores, n, M, tiles, kl, out);
+        PRE_LAUNCH_CHECK();
+        // the tiles it marked (ties beyond a list's capacity, an outlier stretching a window, infinities): streaming form
+        const int e = launch_kth<9, false>(scores, n, M, ks, rows, nk, out, st, 1, j0);
+        if (e != PRE_OK) return e;
     }
     return PRE_OK;
 }
@@ -837,6 +1182,8 @@ extern "C" int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, cons
     if (n <= 256 && 128 * M * 4 < 0xffffffffLL) return launch_kth_pair<128>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     // 16-bit counters hold n < 65536; 1024 first-digit buckets (one workgroup per CU) pay off once 512 buckets
     // would leave more than CAP elements per bucket (n above ~2000)
+    if (n <= 512) return launch_kth_tile<9, 32>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    if (n <= 1024) return launch_kth_tile<9, 64>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     if (n >= 65536) return launch_kth<9, true>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     if (n > 2048) return launch_kth<10, false>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     return launch_kth<9, false>(scores, (int)n, (long long)M, ks, rows, nk, out, st);

@@ -596,6 +596,52 @@ def test_marginal_qhat_window_and_fallback_paths(gpu, n):
         assert np.isnan(np.quantile(col, 0.5, method="higher")) and np.isnan(icp.kth_axis0(s, [n // 2])[0, 109].item())
 
 
+@pytest.mark.parametrize("n", [257, 300, 511, 512, 513, 640, 777, 1000, 1023, 1024])
+def test_marginal_qhat_register_resident_tiles(gpu, n):
+    """256 < n <= 1024 (kth_tile_kernel: one persistent workgroup per CU holds a 64-cell tile in registers, exact
+    [min, max] window, next tile prefetched into the same registers; tiles its fast form cannot finish are marked and
+    redone by the streaming kernel): ragged cell counts (fewer tiles than CUs, several tiles per workgroup, a partial
+    last tile), one rank / ten / more than ten, both extremes, and every column kind that decides a path - constant,
+    two-valued, heavy ties, one huge outlier (stretched window -> marked tile), infinities of either sign, NaNs,
+    denormals, sorted columns, mixed signs - against torch.sort, bit for bit."""
+    from cp_pre_amd import inductive_cp as icp
+    g = torch.Generator(device=gpu).manual_seed(7000 + n)
+    for M in (1, 63, 64, 65, 200, 4099, 40000):
+        s = torch.randn(n, M, device=gpu, generator=g) * torch.exp(2 * torch.randn(M, device=gpu, generator=g))
+        if M >= 200:
+            s[:, :20] = s[:, :20].abs()
+            s[:, 20] = -4.0                                              # constant column
+            s[: n // 2, 21] = 3.0
+            s[n // 2:, 21] = -3.0                                        # two values
+            s[:, 22:26] = torch.round(s[:, 22:26]) / 2                   # heavy ties: buckets above the list capacity
+            s[n // 3, 26] = 1e30                                         # one outlier stretches the window
+            s[5, 27] = float("inf")
+            s[n - 1, 28] = float("-inf")
+            s[:, 29] = float("inf")                                      # a column of infinities only
+            s[3, 30] = float("nan")
+            s[:, 31] = float("nan")                                      # a column of NaNs only
+            s[n - 1, 32] = float("nan")
+            s[7, 32] = float("inf")
+            s[:, 33:36] = s[:, 33:36] * 1e-42                            # denormals
+            s[:, 36] = torch.sort(s[:, 36]).values
+            s[:, 37] = torch.sort(s[:, 37], descending=True).values
+            s[::3, 38] = 0.0
+            s[1::3, 38] = -0.0
+            s[:, 39] = 1.0 + 1e-7 * torch.randn(n, device=gpu, generator=g)   # spread of a few ulps
+            s[:, 130:140] = s[:, 130:140].abs()                          # (a clean tile next to the special one)
+        if M == 40000:
+            s[:, 20000:20064] = torch.round(s[:, 20000:20064] * 4)       # a whole tile of ties deep in a workgroup's run
+        has_nan = torch.isnan(s).any(dim=0)
+        ks_all = sorted({0, 1, n // 2, n - 2, n - 1} | {icp.kth_index(n, n, float(a)) for a in icp.ALPHA_LEVELS
+                                                      if icp.quantile_level(n, float(a)) <= 1})
+        ref_sorted = torch.sort(s, dim=0).values
+        for group in (ks_all[:1], ks_all[:10], ks_all[-10:], ks_all):
+            got = icp.kth_axis0(s, group)
+            ref = ref_sorted[group]
+            same = torch.where(has_nan[None, :], torch.isnan(got), got == ref)
+            assert bool(same.all()), (n, M, group, torch.nonzero(~same)[:5].tolist())
+
+
 @pytest.mark.parametrize("n", [129, 131, 192, 250, 256])
 def test_marginal_qhat_two_lanes_per_cell_form(gpu, n):
     """128 < n <= 256 (register sort with two lanes per cell, kth_pair_kernel): cell counts around the 32-cell wave
