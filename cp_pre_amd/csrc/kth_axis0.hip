@@ -655,7 +655,7 @@ struct KTCfg {
     // side arrays that are NOT aliased: window (min key, max key, NaN flag per cell), published rows, list fill
     // counters, per-wave flags
     static constexpr int WIN_AT = 0, PUB_AT = 192, CNT_AT = PUB_AT + KA_MAXK * 64, FLG_AT = CNT_AT + KA_MAXK * 64,
-                         CMX_AT = FLG_AT + KA_WAVES, SIDE_WORDS = CMX_AT + KA_WAVES;
+                         SIDE_WORDS = FLG_AT + KA_WAVES;
     static_assert((WORDS + MAP_WORDS + SIDE_WORDS) * 4 <= 160 * 1024, "does not fit the 160 KiB LDS");
 };
 
@@ -672,8 +672,12 @@ __device__ __forceinline__ float kt_row(const float *p, int valid, int loff)
 // the phases take opaque copies, so that each recomputes the few it needs)
 __device__ __forceinline__ int kt_opq_v(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int kt_opq_s(int x) { asm volatile("" : "+s"(x)); return x; }
+// (as asm: fminf / fmaxf come with a canonicalising v_max x, x per operand; the hardware's min / max already return the
+// other operand when one is a NaN, which is what the window wants)
 __device__ __forceinline__ float kt_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float kt_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float kt_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float kt_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // the narrowing after the first-digit sweep of the register-resident form (exact window: nothing below it, nothing in
 // the overflow row).  Same walks as ka_narrow_first, kept short in registers: the tile's 64 data registers are live.
@@ -723,6 +727,26 @@ __device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsign
     }
 }
 
+// element `myr` of the `count` (<= N) keys of list `slot` in ascending order (`keep` for count == 0); the sort is
+// ks_sort's in-register bitonic network, declared below
+template <int N, int K> __device__ __forceinline__ void ks_sort(unsigned int (&v)[N]);
+template <int N, int LS>
+__device__ __forceinline__ unsigned int kt_pick(const unsigned int *hist, int slot, unsigned int count, unsigned int myr,
+                                                unsigned int keep, int lane)
+{
+    unsigned int c[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const unsigned int x = i < LS - 1 ? hist[ka_list<LS>(slot, i, lane)] : 0xffffffffu;
+        c[i] = (unsigned)i < count ? x : 0xffffffffu;
+    }
+    ks_sort<N, 2>(c);
+    unsigned int ans = count ? c[0] : keep;
+#pragma unroll
+    for (int i = 1; i < N; ++i) ans = myr == (unsigned)i ? c[i] : ans;
+    return ans;
+}
+
 template <int LOG_NB1, int R>
 __global__ void __launch_bounds__(1024, 4)
 kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntiles, const KAList kl, float *__restrict__ out)
@@ -735,7 +759,6 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
     __shared__ unsigned int side[Cfg::SIDE_WORDS];
     unsigned char *map = reinterpret_cast<unsigned char *>(mapw);
     unsigned int *win = side + Cfg::WIN_AT, *pub = side + Cfg::PUB_AT, *cnt = side + Cfg::CNT_AT, *flg = side + Cfg::FLG_AT;
-    unsigned int *cmx = side + Cfg::CMX_AT;
     const int tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int nk = kl.nk;
 
@@ -768,11 +791,19 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
         // ---- the cell's exact window; clear the histogram meanwhile
         {
             const int lane = kt_opq_v(tid0) & 63, nu = kt_opq_s(nu0);
-            float mn = v[0], mx = v[0];
-            bool nanl = v[0] != v[0];
+            // two rows per instruction (min3 / max3; "unordered" = either one a NaN); the rows beyond R/2 one by one under
+            // their scalar test
+            float mn = kt_min(v[0], v[1]), mx = kt_max(v[0], v[1]);
+            bool nanl = __builtin_isunordered(v[0], v[1]);
 #pragma unroll
-            for (int u = 1; u < R; ++u)
-                if (u < R / 2 || u < nu) {
+            for (int u = 2; u < R / 2; u += 2) {
+                mn = kt_min3(mn, v[u], v[u + 1]);
+                mx = kt_max3(mx, v[u], v[u + 1]);
+                nanl |= __builtin_isunordered(v[u], v[u + 1]);
+            }
+#pragma unroll
+            for (int u = R / 2; u < R; ++u)
+                if (u < nu) {
                     mn = kt_min(mn, v[u]);
                     mx = kt_max(mx, v[u]);
                     nanl |= v[u] != v[u];
@@ -860,7 +891,6 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
             for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
             cmax = __builtin_amdgcn_readfirstlane(cmax);
             if (first) map[myrow * 64 + lane] = (unsigned char)(wave + 1);
-            if (lane == 0) cmx[wave] = (unsigned)cmax;
         }
         __syncthreads();
         {
@@ -870,47 +900,41 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
             asm volatile("" : "+v"(sf2), "+v"(vlo2));
             const int lane = kt_opq_v(tid0) & 63, nu = kt_opq_s(nu0);
             const float *np = nbase;
+            // eight rows at a time: their map bytes are read together (one LDS latency per batch, not per element); an
+            // element that is wanted joins its list - a position below CAP always: the histogram counted the list's elements
 #pragma unroll
-            for (int u = 0; u < R; ++u) {
-                const bool live = u < R / 2 || u < nu;
-                if (live && ok) {
-                    const float x = v[u];
-                    const int m = map[ka_frow<NB1>(x, sf2, vlo2) * 64 + lane];
-                    if (m) {
-                        const unsigned int pos = atomicAdd(&cnt[(m - 1) * 64 + lane], 1u);
-                        if (pos < (unsigned)CAP) hist[ka_list<LS>(m - 1, (int)pos, lane)] = f2key(x);   // (always: the histogram counted them)
-                    }
+            for (int u0 = 0; u0 < R; u0 += 8) {
+                int m[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int u = u0 + i;
+                    m[i] = ((u < R / 2 || u < nu) && ok) ? (int)map[ka_frow<NB1>(v[u], sf2, vlo2) * 64 + lane] : 0;
                 }
-                // the next tile, row by row into the register just consumed.  An unconditional load - rows beyond n, or
-                // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
-                // being finished or not: no copy has to wait for it here, no second definition to reconcile
-                v[u] = kt_row(np, live ? nvalid : 0, lane * 4);
-                np += (long long)KA_WAVES * M;
-            }
-        }
-        if (ok) {
-            // the pick's sentinels: a list is read by every rank that shares its row, up to the longest list of that
-            // rank's wave - so up to the longest list of the tile
-            const int lane = kt_opq_v(tid0) & 63;
-            unsigned int cb = cmx[lane & (KA_WAVES - 1)];
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) cb = max(cb, (unsigned)__shfl_xor((int)cb, o));
-            const int cmaxb = (int)__builtin_amdgcn_readfirstlane(cb);
-            if (first)
-                for (int i = (int)count; i < cmaxb; ++i) hist[ka_list<LS>(wave, i, lane)] = 0xffffffffu;
+                for (int i = 0; i < 8; ++i) {
+                    const int u = u0 + i;
+                    if (m[i]) {
+                        const unsigned int pos = atomicAdd(&cnt[(m[i] - 1) * 64 + lane], 1u);
+                        hist[ka_list<LS>(m[i] - 1, (int)pos, lane)] = f2key(v[u]);
+                    }
+                    // the next tile, row by row into the register just consumed.  An unconditional load - rows beyond n, or
+                    // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
+                    // being finished or not: no copy has to wait for it here, no second definition to reconcile
+                    v[u] = kt_row(np, (u < R / 2 || u < nu) ? nvalid : 0, lane * 4);
+                    np += (long long)KA_WAVES * M;
+                }
+            }
         }
         lds_barrier();
         if (ok) {
             const int lane = kt_opq_v(tid0) & 63;
             unsigned int ans = kmin;                                // flat: the column's one value
-            if (open) {
-                ans = 0xffffffffu;
-                for (int i = 0; i < cmax; ++i) {
-                    const unsigned int ki = hist[ka_list<LS>(myslot, i, lane)];
-                    unsigned int le = 0;
-                    for (int j = 0; j < cmax; ++j) le += hist[ka_list<LS>(myslot, j, lane)] <= ki;
-                    if (i < (int)count && le > myr) ans = min(ans, ki);
-                }
+            if (wave < nk) {                                        // (whole waves: cmax is theirs)
+                // my rank among the <= CAP candidates of my list: all of them into registers at once (entries beyond my
+                // own count read as all ones), a sorting network, element myr
+                if (cmax <= 8) ans = kt_pick<8, LS>(hist, myslot, open ? count : 0u, myr, ans, lane);
+                else if (cmax <= 16) ans = kt_pick<16, LS>(hist, myslot, open ? count : 0u, myr, ans, lane);
+                else ans = kt_pick<32, LS>(hist, myslot, open ? count : 0u, myr, ans, lane);
             }
             const long long c = c0 + lane;
             if (state && c < M) out[(long long)kl.o[wave] * M + c] = nancell ? __uint_as_float(0x7fc00000u) : key2f(ans);
