@@ -556,20 +556,17 @@ __device__ __forceinline__ void ka_collect(const Src &src, int nk, int known,
     }
 }
 
+// one tile (64 cells from c0) of the streaming form, all phases, by the whole workgroup
 template <int LOG_NB1, bool WIDE>
-__global__ void __launch_bounds__(1024, (4 * KACfg<LOG_NB1, WIDE>::WG_PER_CU))
-kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile0, const KAList kl, int fast, int marked,
-                 float *__restrict__ out)
+__device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long long M, long long c0, const KAList &kl, int fast,
+                                        float *__restrict__ out, unsigned int *hist)
 {
     using Cfg = KACfg<LOG_NB1, WIDE>;
     constexpr int U = Cfg::U, BITS = Cfg::BITS;
-    __shared__ unsigned int hist[Cfg::WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = kl.nk;
-    const long long c0 = (tile0 + blockIdx.x) * KA_W, c = c0 + lane;
+    const long long c = c0 + lane;
     const bool cok = c < M;
-    // behind kth_tile_kernel: only the tiles it marked (block-uniform; the mark is overwritten by the result at the end)
-    if (marked && __float_as_uint(out[(long long)kl.o[0] * M + c0]) != 0xffc0deadu) return;
     const float *col = s + c0;             // the tile's first cell: wave-uniform (lane offsets are added at the loads)
     const bool state = wave < nk;
     const unsigned int k0 = state ? (unsigned)kl.k[wave] : 0u;
@@ -620,6 +617,14 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
     if (state && cok) out[(long long)kl.o[wave] * M + c] = hist[lane] ? __uint_as_float(0x7fc00000u) : key2f(myp + klo);
 }
 
+template <int LOG_NB1, bool WIDE>
+__global__ void __launch_bounds__(1024, (4 * KACfg<LOG_NB1, WIDE>::WG_PER_CU))
+kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile0, const KAList kl, int fast, float *__restrict__ out)
+{
+    __shared__ unsigned int hist[KACfg<LOG_NB1, WIDE>::WORDS];
+    ka_tile<LOG_NB1, WIDE>(s, n, M, (tile0 + blockIdx.x) * KA_W, kl, fast, out, hist);
+}
+
 // ---- 256 < n <= 1024: the tile lives in REGISTERS ---------------------------------------------------------------
 // (the reference's own calibration sets: n_cal = 1000, Marginal/Wave_Residuals_CP.py:284-290; BASELINE C2: n = 512.)
 // At these n the sweeps above are short - 16 to 64 rows per thread - and what a tile costs is the chain
@@ -634,7 +639,7 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
 // per word), narrow, then every element looks its row up in a byte map "which list wants this row" and the owner
 // picks its rank among the <= CAP candidates; cells whose column is constant, or holds a NaN, are settled by the window
 // alone.  Tiles the fast form cannot finish (a bucket above CAP: ties, one huge outlier stretching the window; an
-// infinite window) run the general radix form above, streaming the tile again (it is still in L2 / the Infinity Cache).
+// infinite window) are marked and redone by the streaming form above once the workgroup has finished its loop.
 __device__ __forceinline__ void lds_barrier()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -945,12 +950,33 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
         } else if (tid0 == 0) {
             // not finished by the fast form (a bucket above CAP: ties, an outlier stretching the window; an infinite
             // window): the tile is MARKED - a NaN pattern no result can have, in the first rank's output of its first
-            // cell - for the streaming kernel, which the host launches behind this one over the marked tiles only (its
-            // code in this loop would share the register file with the 64 data registers: measured, a quarter of them
-            // spilled)
+            // cell - and redone by the streaming form after this loop (in the loop its code would compete with the 64
+            // data registers)
             out[(long long)kl.o[0] * M + c0] = __uint_as_float(KT_MARK);
         }
         lds_barrier();
+    }
+    // ---- my own marked tiles, by the streaming form above: v[] is dead, its registers are free for it (64 marks per
+    // load, lane = one of my tiles; the result of a tile overwrites its mark)
+    __syncthreads();
+    {
+        static_assert(Cfg::WORDS >= KACfg<LOG_NB1, false>::WORDS, "the streaming form's LDS");
+        const int lane = tid0 & 63;
+        const float *marks = out + (long long)kl.o[0] * M;
+        const long long mine = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;      // tiles blockIdx.x + i gridDim.x
+#pragma unroll 1
+        for (long long ib = 0; ib < mine; ib += 64) {
+            const long long t = blockIdx.x + (ib + lane) * gridDim.x;
+            const bool mk = ib + lane < mine && __float_as_uint(marks[t * KA_W]) == KT_MARK;
+            unsigned long long todo = __ballot(mk);
+#pragma unroll 1
+            while (todo) {
+                const int b = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                ka_tile<LOG_NB1, false>(s, n, M, (blockIdx.x + (ib + b) * gridDim.x) * KA_W, kl, 1, out, hist);
+                __syncthreads();
+            }
+        }
     }
 }
 
@@ -1141,13 +1167,11 @@ int launch_kth_small(const float *scores, int n, long long M, const int32_t *ks,
 }
 
 template <int LOG_NB1, bool WIDE>
-int launch_kth(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st,
-               int marked = 0, int j_only = -1)
+int launch_kth(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
 {
     const long long tiles = (M + KA_W - 1) / KA_W;
     const long long per_launch = 1LL << 21;                     // x 1024 threads: the dispatch packet counts work-items in 32 bits
     for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
-        if (j_only >= 0 && j0 != j_only) continue;
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
@@ -1156,7 +1180,7 @@ int launch_kth(const float *scores, int n, long long M, const int32_t *ks, const
             // the fast first digit pays while a full bucket holds well under CAP elements (n <= ~6 NB1 on
             // bell-shaped scores); beyond that it would be a wasted sweep
             hipLaunchKernelGGL((kth_axis0_kernel<LOG_NB1, WIDE>), dim3((unsigned)nt), dim3(1024), 0, st, scores, n, M, t0, kl,
-                               n <= 6 * (1 << LOG_NB1) ? 1 : 0, marked, out);
+                               n <= 6 * (1 << LOG_NB1) ? 1 : 0, out);
             PRE_LAUNCH_CHECK();
         }
     }
@@ -1177,9 +1201,6 @@ int launch_kth_tile(const float *scores, int n, long long M, const int32_t *ks, 
         for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
         hipLaunchKernelGGL((kth_tile_kernel<LOG_NB1, R>), dim3((unsigned)grid), dim3(1024), 0, st, scores, n, M, tiles, kl, out);
         PRE_LAUNCH_CHECK();
-        // the tiles it marked (ties beyond a list's capacity, an outlier stretching a window, infinities): streaming form
-        const int e = launch_kth<9, false>(scores, n, M, ks, rows, nk, out, st, 1, j0);
-        if (e != PRE_OK) return e;
     }
     return PRE_OK;
 }
