@@ -756,6 +756,7 @@ template <int LOG_NB1, int R>
 __global__ void __launch_bounds__(1024, 4)
 kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntiles, const KAList kl, float *__restrict__ out)
 {
+    constexpr bool SAVE = R <= 32;
     using Cfg = KTCfg<LOG_NB1>;
     using C = Ctr<false>;
     constexpr int NB1 = Cfg::NB1, LS = Cfg::LS, CAP = Cfg::CAP;
@@ -840,12 +841,20 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
         }
 
         // ---- first digit: NB1 - 1 value-linear buckets over the window (rows 1 .. NB1-1; rows 0 and NB1 stay empty)
+        // SAVE (R = 32, where the registers allow it): the rows are kept, two per register and as byte offsets into the
+        // map (row * 64 < 2^16), for the second sweep
+        unsigned int rows[SAVE ? R / 2 : 1];
         {
             const int lane = kt_opq_v(tid0) & 63, nu = kt_opq_s(nu0);
             const unsigned int inc = C::inc(lane);
+            char *hb = reinterpret_cast<char *>(hist + (lane & 31));
 #pragma unroll
             for (int u = 0; u < R; ++u)
-                if (u < R / 2 || u < nu) atomicAdd(&hist[C::word(ka_frow<NB1>(v[u], sf, vlo), lane)], inc);
+                if (u < R / 2 || u < nu) {
+                    const unsigned int r64 = (unsigned)ka_frow<NB1>(v[u], sf, vlo) << 6;
+                    atomicAdd(reinterpret_cast<unsigned int *>(hb + (r64 << 1)), inc);       // word row * 32 + (lane & 31)
+                    if constexpr (SAVE) rows[u / 2] = (u & 1) ? rows[u / 2] | (r64 << 16) : r64;
+                }
         }
         __syncthreads();
         unsigned int myr = k0, count, fl;
@@ -905,6 +914,9 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
             asm volatile("" : "+v"(sf2), "+v"(vlo2));
             const int lane = kt_opq_v(tid0) & 63, nu = kt_opq_s(nu0);
             const float *np = nbase;
+            const unsigned char *mapl = map + lane;
+            char *cb = reinterpret_cast<char *>(cnt + lane) - 256;             // counter of list m - 1: cb + m * 256
+            char *lb = reinterpret_cast<char *>(hist + lane) - LS * 256;       // entry pos of list m - 1: lb + m * LS * 256 + pos * 256
             // eight rows at a time: their map bytes are read together (one LDS latency per batch, not per element); an
             // element that is wanted joins its list - a position below CAP always: the histogram counted the list's elements
 #pragma unroll
@@ -913,14 +925,17 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int u = u0 + i;
-                    m[i] = ((u < R / 2 || u < nu) && ok) ? (int)map[ka_frow<NB1>(v[u], sf2, vlo2) * 64 + lane] : 0;
+                    unsigned int r64;
+                    if constexpr (SAVE) r64 = (u & 1) ? rows[u / 2] >> 16 : rows[u / 2] & 0xffffu;
+                    else r64 = (unsigned)ka_frow<NB1>(v[u], sf2, vlo2) << 6;
+                    m[i] = ((u < R / 2 || u < nu) && ok) ? (int)mapl[r64] : 0;
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int u = u0 + i;
                     if (m[i]) {
-                        const unsigned int pos = atomicAdd(&cnt[(m[i] - 1) * 64 + lane], 1u);
-                        hist[ka_list<LS>(m[i] - 1, (int)pos, lane)] = f2key(v[u]);
+                        const unsigned int pos = atomicAdd(reinterpret_cast<unsigned int *>(cb + (m[i] << 8)), 1u);
+                        *reinterpret_cast<unsigned int *>(lb + m[i] * (LS * 256) + (pos << 8)) = f2key(v[u]);
                     }
                     // the next tile, row by row into the register just consumed.  An unconditional load - rows beyond n, or
                     // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
