@@ -649,19 +649,24 @@ __device__ __forceinline__ void lds_barrier()
 
 constexpr unsigned int KT_MARK = 0xffc0dead;      // "left to the streaming kernel" (results are input values or 0x7fc00000)
 
-template <int LOG_NB1>
+// WGS = workgroups per CU.  Two (R = 32: 64 registers per thread, 80 KiB each) hide each other's barriers and LDS round
+// trips - at these tile sizes the phases are latency chains, not throughput; that takes 256 first-digit buckets and
+// 21-entry lists.  One (R = 64: the data alone are half the register file) has 512 buckets and 31-entry lists.
+template <int LOG_NB1, int WGS>
 struct KTCfg {
-    static constexpr int NB1 = 1 << LOG_NB1, LS = 32, CAP = LS - 1;
+    static constexpr int NB1 = 1 << LOG_NB1, LS = WGS == 2 ? 22 : 32, CAP = LS - 1;
     static constexpr int FIRST_WORDS = (NB1 + 1) * 32 + KA_WAVES * 64;       // first-digit histogram + group sums
     static constexpr int LIST_WORDS = KA_MAXK * LS * 64;                     // (aliases the histogram: filled after the narrowing)
-    static constexpr int W1 = FIRST_WORDS > LIST_WORDS ? FIRST_WORDS : LIST_WORDS;
-    static constexpr int WORDS = W1 > KA_LATE_WORDS ? W1 : KA_LATE_WORDS;
+    static constexpr int WORDS = FIRST_WORDS > LIST_WORDS ? FIRST_WORDS : LIST_WORDS;
     static constexpr int MAP_WORDS = (NB1 + 1) * 16;                         // a byte per (row, cell): list + 1, 0 = not wanted
     // side arrays that are NOT aliased: window (min key, max key, NaN flag per cell), published rows, list fill
     // counters, per-wave flags
     static constexpr int WIN_AT = 0, PUB_AT = 192, CNT_AT = PUB_AT + KA_MAXK * 64, FLG_AT = CNT_AT + KA_MAXK * 64,
                          SIDE_WORDS = FLG_AT + KA_WAVES;
-    static_assert((WORDS + MAP_WORDS + SIDE_WORDS) * 4 <= 160 * 1024, "does not fit the 160 KiB LDS");
+    static constexpr int HOT_WORDS = WORDS + MAP_WORDS + SIDE_WORDS;
+    // (the marked tiles are redone by the streaming form with 512 buckets: 80 KiB from the start of the same block)
+    static constexpr int TOTAL = HOT_WORDS > KACfg<9, false>::WORDS ? HOT_WORDS : KACfg<9, false>::WORDS;
+    static_assert(TOTAL * 4 * WGS <= 160 * 1024, "does not fit the 160 KiB LDS");
 };
 
 // one row of a tile: 64 consecutive floats at the wave-uniform address p, `valid` bytes of them inside the tensor
@@ -752,17 +757,16 @@ __device__ __forceinline__ unsigned int kt_pick(const unsigned int *hist, int sl
     return ans;
 }
 
-template <int LOG_NB1, int R>
-__global__ void __launch_bounds__(1024, 4)
+template <int LOG_NB1, int R, int WGS>
+__global__ void __launch_bounds__(1024, 4 * WGS)
 kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntiles, const KAList kl, float *__restrict__ out)
 {
-    constexpr bool SAVE = R <= 32;
-    using Cfg = KTCfg<LOG_NB1>;
+    constexpr bool SAVE = false;
+    using Cfg = KTCfg<LOG_NB1, WGS>;
     using C = Ctr<false>;
     constexpr int NB1 = Cfg::NB1, LS = Cfg::LS, CAP = Cfg::CAP;
-    __shared__ unsigned int hist[Cfg::WORDS];
-    __shared__ unsigned int mapw[Cfg::MAP_WORDS];
-    __shared__ unsigned int side[Cfg::SIDE_WORDS];
+    __shared__ unsigned int lds[Cfg::TOTAL];
+    unsigned int *hist = lds, *mapw = lds + Cfg::WORDS, *side = mapw + Cfg::MAP_WORDS;
     unsigned char *map = reinterpret_cast<unsigned char *>(mapw);
     unsigned int *win = side + Cfg::WIN_AT, *pub = side + Cfg::PUB_AT, *cnt = side + Cfg::CNT_AT, *flg = side + Cfg::FLG_AT;
     const int tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -954,7 +958,16 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
                 // own count read as all ones), a sorting network, element myr
                 if (cmax <= 8) ans = kt_pick<8, LS>(hist, myslot, open ? count : 0u, myr, ans, lane);
                 else if (cmax <= 16) ans = kt_pick<16, LS>(hist, myslot, open ? count : 0u, myr, ans, lane);
-                else ans = kt_pick<32, LS>(hist, myslot, open ? count : 0u, myr, ans, lane);
+                else if constexpr (WGS == 1) ans = kt_pick<32, LS>(hist, myslot, open ? count : 0u, myr, ans, lane);
+                else if (open) {                                    // (no 32 registers to spare: count in place)
+                    ans = 0xffffffffu;
+                    for (int i = 0; i < (int)count; ++i) {
+                        const unsigned int ki = hist[ka_list<LS>(myslot, i, lane)];
+                        unsigned int le = 0;
+                        for (int j = 0; j < (int)count; ++j) le += hist[ka_list<LS>(myslot, j, lane)] <= ki;
+                        if (le > myr) ans = min(ans, ki);
+                    }
+                }
             }
             const long long c = c0 + lane;
             if (state && c < M) out[(long long)kl.o[wave] * M + c] = nancell ? __uint_as_float(0x7fc00000u) : key2f(ans);
@@ -975,7 +988,6 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
     // load, lane = one of my tiles; the result of a tile overwrites its mark)
     __syncthreads();
     {
-        static_assert(Cfg::WORDS >= KACfg<LOG_NB1, false>::WORDS, "the streaming form's LDS");
         const int lane = tid0 & 63;
         const float *marks = out + (long long)kl.o[0] * M;
         const long long mine = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;      // tiles blockIdx.x + i gridDim.x
@@ -988,7 +1000,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
             while (todo) {
                 const int b = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                ka_tile<LOG_NB1, false>(s, n, M, (blockIdx.x + (ib + b) * gridDim.x) * KA_W, kl, 1, out, hist);
+                ka_tile<9, false>(s, n, M, (blockIdx.x + (ib + b) * gridDim.x) * KA_W, kl, 1, out, lds);
                 __syncthreads();
             }
         }
@@ -1202,19 +1214,19 @@ int launch_kth(const float *scores, int n, long long M, const int32_t *ks, const
     return PRE_OK;
 }
 
-template <int LOG_NB1, int R>
+template <int LOG_NB1, int R, int WGS>
 int launch_kth_tile(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
 {
     const long long tiles = (M + KA_W - 1) / KA_W;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
-    const long long grid = tiles < cus ? tiles : cus;             // one persistent workgroup per CU
+    const long long grid = tiles < WGS * cus ? tiles : WGS * cus;   // persistent workgroups: WGS per CU
     for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
-        hipLaunchKernelGGL((kth_tile_kernel<LOG_NB1, R>), dim3((unsigned)grid), dim3(1024), 0, st, scores, n, M, tiles, kl, out);
+        hipLaunchKernelGGL((kth_tile_kernel<LOG_NB1, R, WGS>), dim3((unsigned)grid), dim3(1024), 0, st, scores, n, M, tiles, kl, out);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
@@ -1242,8 +1254,8 @@ extern "C" int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, cons
     if (n <= 256 && 128 * M * 4 < 0xffffffffLL) return launch_kth_pair<128>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     // 16-bit counters hold n < 65536; 1024 first-digit buckets (one workgroup per CU) pay off once 512 buckets
     // would leave more than CAP elements per bucket (n above ~2000)
-    if (n <= 512) return launch_kth_tile<9, 32>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
-    if (n <= 1024) return launch_kth_tile<9, 64>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    if (n <= 512) return launch_kth_tile<8, 32, 2>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    if (n <= 1024) return launch_kth_tile<9, 64, 1>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     if (n >= 65536) return launch_kth<9, true>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     if (n > 2048) return launch_kth<10, false>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     return launch_kth<9, false>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
