@@ -4,13 +4,19 @@
 //
 // Bound: HBM.  Algorithmic traffic 4 B per element per sweep; the point of the design is FEW sweeps.
 //
+// Three regimes by n (pre_kth_axis0_f32 at the end of the file):
+//   n <= 128         kth_small_kernel: a cell's column in its lane's registers, bitonic network, one read;
+//   128 < n <= 1024  kth_tile_kernel: a persistent workgroup keeps the 64-cell tile in registers (16, 32 or 64 rows per
+//                    thread), exact window, every sweep out of registers, next tile prefetched in place: one read;
+//   n > 1024         kth_axis0_kernel, the STREAMING form described next: sample + 2 sweeps on typical data.
+//
 // A 1024-thread workgroup owns 64 adjacent cells (256 B of every sample row - narrower column tiles lose DRAM
 // efficiency fast: 128 B -> 0.7x, 64 B -> 0.3x, tools/exp/colread.hip).  lane = cell everywhere, one wave = one
 // row, so the 64 LDS atomics of a wave-instruction never hit the same counter.
 //
 // MSD radix select on kk = key - klo[cell]  (key = order-preserving uint32 image of the fp32 score):
 //   0. SAMPLE (<= 1/16 sweep): 256 evenly spaced rows (64, with the range widened by half on each side, for
-//      n <= 1024) give each cell the window [klo, khi] of its sample and
+//      n <= 1024: a tile the register form left to this one) give each cell the window [klo, khi] of its sample and
 //      its own shift s = the smallest with (khi - klo) >> s <= NB1 - 2 (per cell: one tile-wide shift would be set
 //      by the cell whose sample happens to hold the smallest value, 15 binades instead of 9 on |N(0,1)| scores).
 //   1. FIRST DIGIT (1 sweep, one slot): NB1 = 512 or 1024 buckets over the cell's own window, + an underflow
@@ -625,7 +631,7 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile
     ka_tile<LOG_NB1, WIDE>(s, n, M, (tile0 + blockIdx.x) * KA_W, kl, fast, out, hist);
 }
 
-// ---- 256 < n <= 1024: the tile lives in REGISTERS ---------------------------------------------------------------
+// ---- 128 < n <= 1024: the tile lives in REGISTERS ---------------------------------------------------------------
 // (the reference's own calibration sets: n_cal = 1000, Marginal/Wave_Residuals_CP.py:284-290; BASELINE C2: n = 512.)
 // At these n the sweeps above are short - 16 to 64 rows per thread - and what a tile costs is the chain
 // sample -> count -> narrow -> collect -> pick with an HBM round trip per batch of loads, twice over, plus two reads of
@@ -681,6 +687,13 @@ __device__ __forceinline__ float kt_row(const float *p, int valid, int loff)
 // comparisons u < nu - are otherwise all hoisted out of the tile loop and kept live next to the 64 data registers:
 // the phases take opaque copies, so that each recomputes the few it needs)
 __device__ __forceinline__ int kt_opq_v(int x) { asm volatile("" : "+v"(x)); return x; }
+// the lane index, re-made where it is needed (two instructions, nothing kept live or spilled for it)
+__device__ __forceinline__ int kt_lane()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 __device__ __forceinline__ int kt_opq_s(int x) { asm volatile("" : "+s"(x)); return x; }
 // (as asm: fminf / fmaxf come with a canonicalising v_max x, x per operand; the hardware's min / max already return the
 // other operand when one is a NaN, which is what the window wants)
@@ -800,7 +813,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
 
         // ---- the cell's exact window; clear the histogram meanwhile
         {
-            const int lane = kt_opq_v(tid0) & 63, nu = kt_opq_s(nu0);
+            const int lane = kt_lane(), nu = kt_opq_s(nu0);
             // two rows per instruction (min3 / max3; "unordered" = either one a NaN); the rows beyond R/2 one by one under
             // their scalar test
             float mn = kt_min(v[0], v[1]), mx = kt_max(v[0], v[1]);
@@ -824,14 +837,14 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
             atomicMax(&win[64 + lane], f2key(mx));
             if (nanl) win[128 + lane] = 1u;
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-            for (int i = kt_opq_v(tid0); i < ((NB1 + 1) * 32) / 4; i += 1024) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (int i = wave * 64 + lane; i < ((NB1 + 1) * 32) / 4; i += 1024) h4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();
         unsigned int kmin, kmax;
         float vlo, sf;
         bool flat, badwin, nancell;
         {
-            const int lane = kt_opq_v(tid0) & 63;
+            const int lane = kt_lane();
             kmin = win[lane];
             kmax = win[64 + lane];
             nancell = win[128 + lane] != 0u;
@@ -849,7 +862,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
         // map (row * 64 < 2^16), for the second sweep
         unsigned int rows[SAVE ? R / 2 : 1];
         {
-            const int lane = kt_opq_v(tid0) & 63, nu = kt_opq_s(nu0);
+            const int lane = kt_lane(), nu = kt_opq_s(nu0);
             const unsigned int inc = C::inc(lane);
             char *hb = reinterpret_cast<char *>(hist + (lane & 31));
 #pragma unroll
@@ -865,7 +878,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
         int digit;
         bool open;
         {
-            const int lane = kt_opq_v(tid0) & 63;
+            const int lane = kt_lane();
             if (wave == KA_WAVES - 1) {                              // (everyone has read the window)
                 win[lane] = 0xffffffffu;
                 win[64 + lane] = 0u;
@@ -897,7 +910,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
         int myslot = wave, cmax = 0;
         bool first = false;
         if (ok) {
-            const int lane = kt_opq_v(tid0) & 63;
+            const int lane = kt_lane();
             if (open) {
 #pragma unroll
                 for (int j = KA_MAXK - 1; j >= 0; --j)
@@ -916,7 +929,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
             // one - in scratch memory, whose loads then queue behind the prefetch below and make every element wait)
             float sf2 = sf, vlo2 = vlo;
             asm volatile("" : "+v"(sf2), "+v"(vlo2));
-            const int lane = kt_opq_v(tid0) & 63, nu = kt_opq_s(nu0);
+            const int lane = kt_lane(), nu = kt_opq_s(nu0);
             const float *np = nbase;
             const unsigned char *mapl = map + lane;
             char *cb = reinterpret_cast<char *>(cnt + lane) - 256;             // counter of list m - 1: cb + m * 256
@@ -951,7 +964,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
         }
         lds_barrier();
         if (ok) {
-            const int lane = kt_opq_v(tid0) & 63;
+            const int lane = kt_lane();
             unsigned int ans = kmin;                                // flat: the column's one value
             if (wave < nk) {                                        // (whole waves: cmax is theirs)
                 // my rank among the <= CAP candidates of my list: all of them into registers at once (entries beyond my
@@ -975,7 +988,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
                 map[myrow * 64 + lane] = 0;
                 cnt[wave * 64 + lane] = 0u;
             }
-        } else if (tid0 == 0) {
+        } else if (wave == 0 && kt_lane() == 0) {
             // not finished by the fast form (a bucket above CAP: ties, an outlier stretching the window; an infinite
             // window): the tile is MARKED - a NaN pattern no result can have, in the first rank's output of its first
             // cell - and redone by the streaming form after this loop (in the loop its code would compete with the 64
@@ -988,7 +1001,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
     // load, lane = one of my tiles; the result of a tile overwrites its mark)
     __syncthreads();
     {
-        const int lane = tid0 & 63;
+        const int lane = threadIdx.x & 63;
         const float *marks = out + (long long)kl.o[0] * M;
         const long long mine = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;      // tiles blockIdx.x + i gridDim.x
 #pragma unroll 1
@@ -1101,83 +1114,6 @@ __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict_
     }
 }
 
-// ---- 128 < n <= 256: two lanes per cell -----------------------------------------------------------------------
-// lane l of a wave holds rows [128 (l >> 5), 128 (l >> 5) + 128) of cell l & 31: the same load stream and the same
-// in-register bitonic network as above (one 128-byte run of the first half and one of the second per load
-// instruction), then ONE bitonic merge step across the lane pair (l, l ^ 32) - element i against the partner's element
-// 127 - i, the low lane keeping the minima - leaves the 128 smallest scores of the cell in the low lane and the 128
-// largest in the high lane, each a bitonic sequence that seven more in-register stages sort.  Rank k is then element
-// k & 127 of lane (cell + 32 (k >> 7)).  The radix form needs ~1500 instructions of per-tile set-up per thread and
-// several barriers for the same tile: 0.9 - 1.45 TB/s at n = 130 .. 256 against 2.7 at n = 128.  (N = 64 with two lanes
-// per cell for 64 < n <= 128 was measured as well: 13 - 20 % slower than one lane with N = 128.)
-template <int N>
-__global__ void __launch_bounds__(256) kth_pair_kernel(const float *__restrict__ s, int n, long long M, const KAList kl,
-                                                       float *__restrict__ out)
-{
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int cell = lane & 31, half = lane >> 5;
-    const long long c0 = ((long long)blockIdx.x * 4 + wave) * 32, c = c0 + cell;
-    if (c0 >= M) return;                   // whole wave beyond the last tile
-    const bool cok = c < M;
-    // row i of the first half through a descriptor whose base advances by one row per load; the second half adds
-    // 128 rows to the lane offset (host: 128 M 4 < 2^32).  The descriptor ends where the tensor does (or 4 GiB on), so
-    // rows >= n read 0 - they are replaced by the padding key - and nothing past the allocation is touched.
-    const unsigned int voff = (unsigned)cell * 4u + (half ? (unsigned)(N * M * 4) : 0u);
-    const float *p = s + c0;
-    long long left = ((long long)n * M - c0) * 4;              // bytes from the row base to the end of the tensor
-    float raw[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const unsigned int rec = left > 0xffffffffLL ? 0xffffffffu : (left > 0 ? (unsigned)left : 0u);
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, rec, 0x00020000);
-        raw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
-        p += M;
-        left -= M * 4;
-    }
-    unsigned int v[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = (half * N + i < n) ? f2key(raw[i]) : 0xffffffffu;
-    ks_sort<N, 2>(v);
-    // the cross-lane merge step, pairs (i, 127 - i) together so that both exchanges read the sorted values
-#pragma unroll
-    for (int i = 0; i < N / 2; ++i) {
-        const unsigned int a = v[i], b = v[N - 1 - i];
-        const unsigned int xa = (unsigned int)__shfl_xor((int)b, 32);      // the partner's element 127 - i
-        const unsigned int xb = (unsigned int)__shfl_xor((int)a, 32);      // the partner's element i
-        v[i] = half ? max(a, xa) : min(a, xa);
-        v[N - 1 - i] = half ? max(b, xb) : min(b, xb);
-    }
-    ks_merge<N, 2 * N, N / 2>(v);          // (K = 2N: every run ascending)
-    // np.quantile: a NaN in the column makes every quantile of the cell NaN (positive NaNs sort above +inf at the top
-    // of the n real entries, negative ones below -inf at the bottom)
-    const unsigned int top = ks_take<N>(v, (n - 1) & (N - 1));
-    const unsigned int top_g = (unsigned int)__shfl((int)top, cell + 32 * ((n - 1) / N));
-    const unsigned int bot_g = (unsigned int)__shfl((int)v[0], cell);
-    const bool nan = top_g > 0xff800000u || bot_g < 0x007fffffu;
-#pragma unroll
-    for (int j = 0; j < KA_MAXK; ++j) {
-        if (j >= kl.nk) break;                                    // wave-uniform
-        const unsigned int e = ks_take<N>(v, kl.k[j] & (N - 1));
-        const unsigned int r = (unsigned int)__shfl((int)e, cell + 32 * (kl.k[j] / N));
-        if (cok && half == 0) out[(long long)kl.o[j] * M + c] = nan ? __uint_as_float(0x7fc00000u) : key2f(r);
-    }
-}
-
-template <int N>
-int launch_kth_pair(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
-{
-    const long long blocks = ((M + 31) / 32 + 3) / 4;
-    if (blocks > 0x7fffffffLL) return PRE_E_SHAPE;
-    for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
-        KAList kl;
-        kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
-        for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
-        hipLaunchKernelGGL(kth_pair_kernel<N>, dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, kl, out);
-        PRE_LAUNCH_CHECK();
-    }
-    return PRE_OK;
-}
-
 template <int N>
 int launch_kth_small(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
 {
@@ -1251,7 +1187,8 @@ extern "C" int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, cons
     hipStream_t st = as_stream(stream);
     if (n <= 64) return launch_kth_small<64>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     if (n <= 128) return launch_kth_small<128>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
-    if (n <= 256 && 128 * M * 4 < 0xffffffffLL) return launch_kth_pair<128>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    // 128 < n <= 1024: the tile in registers, read once (16, 32 rows per thread: two workgroups per CU; 64: one)
+    if (n <= 256) return launch_kth_tile<8, 16, 2>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     // 16-bit counters hold n < 65536; 1024 first-digit buckets (one workgroup per CU) pay off once 512 buckets
     // would leave more than CAP elements per bucket (n above ~2000)
     if (n <= 512) return launch_kth_tile<8, 32, 2>(scores, (int)n, (long long)M, ks, rows, nk, out, st);

@@ -596,11 +596,11 @@ def test_marginal_qhat_window_and_fallback_paths(gpu, n):
         assert np.isnan(np.quantile(col, 0.5, method="higher")) and np.isnan(icp.kth_axis0(s, [n // 2])[0, 109].item())
 
 
-@pytest.mark.parametrize("n", [257, 300, 511, 512, 513, 640, 777, 1000, 1023, 1024])
+@pytest.mark.parametrize("n", [129, 200, 256, 257, 300, 511, 512, 513, 640, 777, 1000, 1023, 1024])
 def test_marginal_qhat_register_resident_tiles(gpu, n):
-    """256 < n <= 1024 (kth_tile_kernel: one persistent workgroup per CU holds a 64-cell tile in registers, exact
-    [min, max] window, next tile prefetched into the same registers; tiles its fast form cannot finish are marked and
-    redone by the streaming kernel): ragged cell counts (fewer tiles than CUs, several tiles per workgroup, a partial
+    """128 < n <= 1024 (kth_tile_kernel: a persistent workgroup holds a 64-cell tile in registers - 16 / 32 rows per
+    thread with two workgroups per CU, 64 with one -, exact [min, max] window, next tile prefetched into the same
+    registers; tiles its fast form cannot finish are marked and redone by the streaming form once its loop is done): ragged cell counts (fewer tiles than CUs, several tiles per workgroup, a partial
     last tile), one rank / ten / more than ten, both extremes, and every column kind that decides a path - constant,
     two-valued, heavy ties, one huge outlier (stretched window -> marked tile), infinities of either sign, NaNs,
     denormals, sorted columns, mixed signs - against torch.sort, bit for bit."""
@@ -643,10 +643,10 @@ def test_marginal_qhat_register_resident_tiles(gpu, n):
 
 
 @pytest.mark.parametrize("n", [129, 131, 192, 250, 256])
-def test_marginal_qhat_two_lanes_per_cell_form(gpu, n):
-    """128 < n <= 256 (register sort with two lanes per cell, kth_pair_kernel): cell counts around the 32-cell wave
-    tiles and the 4-wave blocks, one rank and more than ten, both extremes, the ranks on either side of the lane split
-    (127, 128), ties across the split, a NaN / an infinity in either half - against torch.sort, bit for bit."""
+def test_marginal_qhat_register_tiles_16_rows(gpu, n):
+    """128 < n <= 256 (kth_tile_kernel with 16 rows per thread, two workgroups per CU; round 2's two-lanes-per-cell
+    register sort, which this replaced, drew these cases): cell counts around the tile sizes, one rank and more than
+    ten, both extremes, ranks 127 / 128, ties, a NaN / an infinity in either half - against torch.sort, bit for bit."""
     from cp_pre_amd import inductive_cp as icp
     g = torch.Generator(device=gpu).manual_seed(n)
     for M in (1, 31, 32, 33, 127, 128, 129, 1000, 100003):
