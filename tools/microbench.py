@@ -103,11 +103,11 @@ def bench_calib():
 
 def bench_select():
     alphas = [float(a) for a in icp.ALPHA_LEVELS]
-    for (n, M) in [(256, 10 * 512 * 512), (1024, 10 * 512 * 512), (4096, 2 * 512 * 512), (512, 32 * 256 * 256), (8192, 254 * 254)]:
+    for (n, M) in [(256, 10 * 512 * 512), (512, 32 * 256 * 256), (1000, 4 * 512 * 512), (1024, 10 * 512 * 512), (2048, 2 * 512 * 512), (4096, 2 * 512 * 512), (8192, 254 * 254)]:
         s = torch.randn(n, M, device=dev).abs_()
         ks = [icp.kth_index(n, n, a) for a in alphas]
         ms = timeit(lambda: icp.kth_axis0(s, ks), reps=3, warm=1)
-        report(f"kth_axis0 10 ranks [{n},{M}] 5 passes=20B", ms, 20 * n * M)
+        report(f"kth_axis0 10 ranks [{n},{M}] one read of the scores = 4B", ms, 4 * n * M)
         del s
     s = torch.randn(65536 * 8, device=dev)
     report("kth scalar 10 ranks N=524288", timeit(lambda: icp.kth_axis0(s, [icp.kth_index(s.numel(), s.numel(), a) for a in alphas])), 4 * s.numel())
