@@ -44,7 +44,8 @@ SIGNATURES = {
     "pre_residual_ns_momentum_f32": [_fld, _fld, _fld, _fld] + [POINTER(c_float)] * 4 + [c_float] * 4 + [c_int64] * 4 + [c_int, c_void_p],
     "pre_moments_segmax_f64": [_fp, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, _fp, _fp, _fp, c_void_p],
     "pre_segmin_mod_f32": [_fp, c_int64, c_int64, c_int64, c_int, c_int, _fp, c_void_p],
-    "pre_joint_score_pruned_f32": [_fp, c_int64, _fp, _fp, _fp, c_int64, c_int64, c_int64, c_int64, c_int, c_int, _fp, c_void_p],
+    "pre_joint_score_pruned_f32": [_fp, c_int64, _fp, _fp, _fp, c_int64, c_int64, c_int64, c_int64, c_int, c_int, _fp, _fp, _fp, c_void_p],
+    "pre_joint_score_flagged_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, _fp, _fp, c_void_p],
     "pre_residual_linear2_f32": [_fld, _fld, _fld, POINTER(c_float), POINTER(c_float), c_float] + [c_int64] * 4 + [c_int, c_void_p],
     "pre_residual_burgers_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_int64)] + [POINTER(c_float)] * 3 + [c_float] * 4 + [c_int64] * 3 + [c_int, c_void_p],
     "pre_residual_mhd_f32": [c_int, POINTER(PreField), _fld] + [POINTER(c_float)] * 3 + [c_double] + [c_int64] * 4 + [c_int, c_void_p],

@@ -270,7 +270,9 @@ constexpr int JS_RB = 32;
 // the sample's score becomes NaN.
 __device__ __forceinline__ void js_update(float av, float sv, float &m, float &thr, bool &nan)
 {
-    if (!(av <= thr * sv) || sv == 0.f) {
+    // (sv below the smallest normal number: thr * sv is then rounded with an ABSOLUTE error, and "a quotient that rounds
+    // above m always passes" no longer follows - such cells, and sv == 0, always take the divide)
+    if (!(av <= thr * sv) || sv < 1.17549435e-38f) {
         const float q = av / sv;
         if (q != q) nan = true;
         else if (q > m) { m = q; thr = m * 0.99999905f; }
@@ -280,7 +282,7 @@ __device__ __forceinline__ void js_update(float av, float sv, float &m, float &t
 __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                           const float *__restrict__ mod, int T, int X, int Y,
                                                           int ct, int cx, int cy, int groups, int smp_fastest,
-                                                          float *__restrict__ scores)
+                                                          const unsigned int *__restrict__ only, float *__restrict__ scores)
 {
     const long long plane = (long long)X * Y, vol = plane * T;
     // smp_fastest: consecutive workgroups take the SAME rows of consecutive samples, so the modulation rows they
@@ -288,6 +290,7 @@ __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restric
     // (Tried on top and dropped: four load pairs in flight per thread - 74 VGPRs, 15 % slower.)
     const int smp = smp_fastest ? blockIdx.x : blockIdx.y;
     const unsigned int cblk = smp_fastest ? blockIdx.y : blockIdx.x;
+    if (only && !only[smp]) return;                           // (block-uniform) the pass over the flagged samples only
     const float *pa = a + smp * vol, *pb = b ? b + smp * vol : nullptr;
     const long long nrows = (long long)T * X;
     const bool vec = (Y % 4 == 0) && !(((uintptr_t)a | (uintptr_t)mod | (uintptr_t)(b ? b : a)) & 15);
@@ -372,10 +375,12 @@ __global__ void __launch_bounds__(256) joint_score_kernel(const float *__restric
 constexpr int JSF_CELLS = 8192;
 __global__ void __launch_bounds__(256) joint_score_flat_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                                const float *__restrict__ mod, int T, int X, int Y, int ct,
-                                                               int cx, int cy, float *__restrict__ scores)
+                                                               int cx, int cy, const unsigned int *__restrict__ only,
+                                                               float *__restrict__ scores)
 {
     const long long vol = (long long)T * X * Y;
     const int smp = blockIdx.x;
+    if (only && !only[smp]) return;
     const float4 *pa = reinterpret_cast<const float4 *>(a + smp * vol);
     const float4 *pb = b ? reinterpret_cast<const float4 *>(b + smp * vol) : nullptr;
     const float4 *pm = reinterpret_cast<const float4 *>(mod);
@@ -454,7 +459,9 @@ __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *_
                                                                   const float *__restrict__ mod,
                                                                   const unsigned int *__restrict__ segmax,
                                                                   const float *__restrict__ segmin, int T, int X, int Y, int cx,
-                                                                  int cy, int per_chunk, int total, float *__restrict__ scores)
+                                                                  int cy, int per_chunk, int total, float *__restrict__ scores,
+                                                                  unsigned int *__restrict__ flags,
+                                                                  unsigned long long *__restrict__ stats)
 {
     extern __shared__ unsigned int work[];                        // `total` = TC * X * nseg segment ids
     __shared__ unsigned int red[16], redi[16], nwork, sbest;
@@ -491,8 +498,9 @@ __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *_
             }
 #pragma unroll
             for (int t = 0; t < MS_TMAX; ++t) {
+                // (a quotient <= 0 - a negative modulation - never raises the full pass's maximum either: js_update)
                 const float q = fabsf(rv[t]) / mv[t];
-                m = max(m, q != q ? NANBITS : __float_as_uint(q));
+                m = max(m, q != q ? NANBITS : (q > 0.f ? __float_as_uint(q) : 0u));
             }
         }
 #pragma unroll
@@ -518,7 +526,11 @@ __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *_
     for (int w = 1; w < nwaves; ++w)
         if (red[w] > bb || (red[w] == bb && redi[w] < bj)) { bb = red[w]; bj = redi[w]; }
     unsigned int best = __float_as_uint(scores[smp]);            // earlier slabs (non-negative or NaN: orders as uint)
-    if (bb == 0u) return;                                         // nothing scored in this slab (block-uniform)
+    if (bb == 0u) {                                               // nothing scored in this slab (block-uniform)
+        if (stats && tid == 0) atomicAdd(&stats[1], (unsigned long long)total);
+        if (flags && tid == 0) flags[smp] = 0u;
+        return;
+    }
     if (bb > best) best = max(best, evaluate((int)bj));          // (every wave evaluates it: no exchange needed)
     // (2) every other segment that can still beat it
     for (int j = tid; j < total; j += blockDim.x)
@@ -528,6 +540,23 @@ __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *_
     // the waves share the list; the best score so far is shared through LDS (it only grows, and skipping a segment
     // whose bound does not exceed ANY score already seen is always safe)
     const unsigned int nw = nwork;
+    if (stats && tid == 0) {                                      // [0] += segments read, [1] += segments, [2] += samples swept whole
+        const bool giveup = flags && 4u * nw > (unsigned)total;
+        atomicAdd(&stats[0], (unsigned long long)(giveup ? (unsigned)total : nw + 1u));
+        atomicAdd(&stats[1], (unsigned long long)total);
+        if (giveup) atomicAdd(&stats[2], 1ull);
+    }
+    if (flags) {
+        // The bounds do not prune this sample when more than a quarter of its segments would be read, 8 KB at a time (a
+        // modulation that jumps between neighbouring cells: max |r| / min mod says little): it is FLAGGED for the full
+        // pass over the flagged samples that the driver launches behind this kernel (pre_joint_score_flagged_f32).
+        const bool giveup = 4u * nw > (unsigned)total;
+        if (tid == 0) flags[smp] = giveup ? 1u : 0u;
+        if (giveup) {
+            if (tid == 0) atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, best);
+            return;
+        }
+    }
     for (unsigned int i = wave; i < nw; i += nwaves) {
         const int j = (int)work[i];
         best = max(best, *(volatile unsigned int *)&sbest);
@@ -816,8 +845,8 @@ int pre_std_from_moments_f32(const double *sum, const double *sumsq, int64_t n_t
     return PRE_OK;
 }
 
-int pre_joint_score_f32(const float *a, const float *b, const float *mod, int64_t n, int64_t T, int64_t X, int64_t Y,
-                        int crop_t, int crop_x, int crop_y, float *scores, void *stream)
+static int joint_score_launch(const float *a, const float *b, const float *mod, int64_t n, int64_t T, int64_t X, int64_t Y,
+                              int crop_t, int crop_x, int crop_y, const uint32_t *only, float *scores, void *stream)
 {
     if (!a || !mod || !scores || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
     if (crop_t < 0 || crop_x < 0 || crop_y < 0) return PRE_E_RANGE;
@@ -828,7 +857,7 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod, int64_
         if (Y < 64 && vol % 4 == 0 && vol < 0x7fffffffLL && nblk <= 65535 && n <= 0x7fffffff &&
             !(((uintptr_t)a | (uintptr_t)mod | (uintptr_t)(b ? b : a)) & 15)) {
             hipLaunchKernelGGL(joint_score_flat_kernel, dim3((unsigned)n, (unsigned)nblk), dim3(256), 0, as_stream(stream), a, b, mod,
-                               (int)T, (int)X, (int)Y, crop_t, crop_x, crop_y, scores);
+                               (int)T, (int)X, (int)Y, crop_t, crop_x, crop_y, only, scores);
             PRE_LAUNCH_CHECK();
             return PRE_OK;
         }
@@ -846,10 +875,23 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod, int64_
         const int swap = chunks <= 65535;
         hipLaunchKernelGGL(joint_score_kernel, swap ? dim3((unsigned)ns, (unsigned)chunks) : dim3((unsigned)chunks, (unsigned)ns),
                            dim3(256), 0, as_stream(stream), a + s0 * vol, b ? b + s0 * vol : nullptr, mod, (int)T, (int)X, (int)Y,
-                           crop_t, crop_x, crop_y, (int)groups, swap, scores + s0);
+                           crop_t, crop_x, crop_y, (int)groups, swap, only ? only + s0 : nullptr, scores + s0);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
+}
+
+int pre_joint_score_f32(const float *a, const float *b, const float *mod, int64_t n, int64_t T, int64_t X, int64_t Y,
+                        int crop_t, int crop_x, int crop_y, float *scores, void *stream)
+{
+    return joint_score_launch(a, b, mod, n, T, X, Y, crop_t, crop_x, crop_y, nullptr, scores, stream);
+}
+
+int pre_joint_score_flagged_f32(const float *a, const float *b, const float *mod, int64_t n, int64_t T, int64_t X, int64_t Y,
+                                int crop_t, int crop_x, int crop_y, const uint32_t *flags, float *scores, void *stream)
+{
+    if (!flags) return PRE_E_NULL;
+    return joint_score_launch(a, b, mod, n, T, X, Y, crop_t, crop_x, crop_y, flags, scores, stream);
 }
 
 int pre_segmin_mod_f32(const float *mod, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y, float *segmin, void *stream)
@@ -865,18 +907,21 @@ int pre_segmin_mod_f32(const float *mod, int64_t T, int64_t X, int64_t Y, int cr
 }
 
 int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float *mod, const uint32_t *segmax, const float *segmin,
-                               int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y, float *scores, void *stream)
+                               int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y, float *scores,
+                               uint32_t *flags, unsigned long long *stats, void *stream)
 {
     if (!res || !mod || !segmax || !segmin || !scores || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
     if (crop_x < 0 || crop_y < 0 || row_stride < T * X * Y) return PRE_E_RANGE;
     const long long nseg = (X * Y + JP_SEG - 1) / JP_SEG, TC = (T + MS_TMAX - 1) / MS_TMAX, total = TC * nseg;
     if (n > 0x7fffffff || T > 0x7fffffff || X > 0x7fffffff || Y > 0x7fffffff) return PRE_E_SHAPE;
-    if (total * 4 > 64 * 1024) return PRE_E_UNSUPPORTED;                                  // the work list lives in LDS
+    // the work list lives in LDS, next to 136 bytes of static state: 64 KiB in all, the limit of a workgroup on every
+    // CDNA part (gfx950 itself would allow 160 KiB)
+    if (total * 4 + 256 > 64 * 1024) return PRE_E_UNSUPPORTED;
     // a block per sample: few samples get more waves each to work through their lists
     const int threads = n >= 2048 ? 256 : n >= 512 ? 512 : 1024;
     hipLaunchKernelGGL(joint_score_pruned_kernel, dim3((unsigned)n), dim3(threads), (size_t)total * 4, as_stream(stream), res,
                        (long long)row_stride, mod, segmax, segmin, (int)T, (int)X, (int)Y, crop_x, crop_y, (int)nseg, (int)total,
-                       scores);
+                       scores, flags, stats);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }

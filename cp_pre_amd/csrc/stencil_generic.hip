@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) wgrad27_kernel(const float *__restrict__ 
 
 extern "C" {
 
-int pre_abi_version(void) { return 5; }
+int pre_abi_version(void) { return 6; }
 
 int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *tap_w, const int32_t *tap_off, int ntaps,
                       int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)

@@ -105,7 +105,7 @@ class HipOps:
         cropc = tuple(crop) if order is None else tuple(crop[o - 1] for o in order)
         A0, A1, A2 = resc.shape[1:]
         planes = A0 - 2 * cropc[0]
-        if planes < 1 or ((planes + 15) // 16) * ((A1 * A2 + 63) // 64) > 16384:
+        if planes < 1 or ((planes + 15) // 16) * ((A1 * A2 + 63) // 64) > 16320:    # (pre_joint_score_pruned_f32's LDS list)
             return None
         return resc, cropc
 
@@ -128,19 +128,31 @@ class HipOps:
         return segmax
 
     @staticmethod
-    def max_scores_pruned(res, mod, segmax, crop, scores):
-        """Branch-and-bound form of ``max_scores`` for the tensor ``add_moments_segmax`` just read: same scores, bit for
-        bit, but only the segments whose bound (max |res| / min mod) exceeds a sample's best score so far are read."""
+    def zeros_prune_stats(device):
+        """[segments read, segments, samples swept whole], accumulated on the device by ``max_scores_pruned``."""
+        return torch.zeros(3, dtype=torch.int64, device=device)
+
+    @staticmethod
+    def max_scores_pruned(res, mod, segmax, crop, scores, stats=None):
+        """Branch-and-bound form of ``max_scores`` for the tensor ``add_moments_segmax`` just read: the same scores for
+        the same modulation, bit for bit, but only the segments whose bound (max |res| / min mod) exceeds a sample's
+        best score so far are read; a sample whose bounds leave more than a quarter of its segments is flagged instead
+        and takes the full pass (``pre_joint_score_flagged_f32``: the other samples' workgroups leave at once)."""
         n, (T, X, Y) = res.shape[0], res.shape[1:]
         planes, mod_in = T - 2 * crop[0], mod[crop[0]:]
         segmin = torch.empty(segmax.shape[1:], dtype=torch.float32, device=res.device)
+        flags = torch.empty(n, dtype=torch.int32, device=res.device)
         lib = _lib.load()
         with torch.cuda.device(res.device):
             _lib.check(lib.pre_segmin_mod_f32(_lib.ptr(mod_in), planes, X, Y, crop[1], crop[2], _lib.ptr(segmin), _lib.stream()),
                        "pre_segmin_mod_f32")
             _lib.check(lib.pre_joint_score_pruned_f32(_lib.ptr(res[:, crop[0]:]), res.stride(0), _lib.ptr(mod_in), _lib.ptr(segmax),
                                                       _lib.ptr(segmin), n, planes, X, Y, crop[1], crop[2], _lib.ptr(scores),
+                                                      _lib.ptr(flags), _lib.ptr(stats) if stats is not None else None,
                                                       _lib.stream()), "pre_joint_score_pruned_f32")
+            _lib.check(lib.pre_joint_score_flagged_f32(_lib.ptr(res), None, _lib.ptr(mod), n, T, X, Y, crop[0], crop[1], crop[2],
+                                                       _lib.ptr(flags), _lib.ptr(scores), _lib.stream()),
+                       "pre_joint_score_flagged_f32")
 
     @staticmethod
     def kth(scores, ks):
@@ -161,9 +173,15 @@ class JointCalibration:
     per-sample max composes across slabs, so one sweep over the data suffices.
     """
 
+    # the bounds are dropped for the rest of the stream when the first pruned slab had to read more than this share
+    # of its segments (measured, profiles/r03/prune_ab.txt: beyond it the segment maxima cost more than they save)
+    PRUNE_GIVE_UP = 0.25
+
     def __init__(self, n_local, device, eps=0.0, group=None, ops=None, prune=True):
         self.ops = ops or HipOps
         self.prune = prune
+        self.prune_stats = None        # device [segments read, segments, samples swept whole] over the pruned slabs
+        self.prune_checked = False
         self.group, self.eps, self.n_local, self.device = group, eps, n_local, device
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
         self.n_total = n_local * self.world
@@ -176,7 +194,9 @@ class JointCalibration:
         (``PRE_FLAG_INTERIOR_T``): they are neither reduced nor scored.
         When the slab allows it (``HipOps.prune_view``: dense, large enough, ...) the moments pass also delivers
         per-segment maxima of |res| and the score pass reads only the segments that can still raise a sample's
-        score - the same scores bit for bit (``prune=False`` forces the full pass)."""
+        score - the same scores for the same modulation, bit for bit (``prune=False`` forces the full pass).  The
+        route adapts to the data: a sample whose bounds prune little is swept whole inside the kernel, and a stream
+        whose first pruned slab read more than ``PRUNE_GIVE_UP`` of its segments takes the plain passes from then on."""
         ops = self.ops
         M = res[0].numel() if hasattr(res[0], "numel") else res[0].size
         view = ops.prune_view(res, crop) if self.prune and getattr(ops, "prune_view", None) else None
@@ -196,11 +216,28 @@ class JointCalibration:
             torch.distributed.all_reduce(mom, group=self.group)          # RCCL: sum of (sum, sumsq) per cell
         mod = ops.std_from_moments(mom, self.n_total, tuple(res.shape[1:]), self.eps, like=res, **kw)
         if view is not None:
-            ops.max_scores_pruned(resc, icp.canon_cells(mod, icp.canon(res)[1]), segmax, cropc, self.scores)
+            if self.prune_stats is None and getattr(ops, "zeros_prune_stats", None):
+                self.prune_stats = ops.zeros_prune_stats(self.device)
+            kw2 = {"stats": self.prune_stats} if self.prune_stats is not None else {}
+            ops.max_scores_pruned(resc, icp.canon_cells(mod, icp.canon(res)[1]), segmax, cropc, self.scores, **kw2)
+            if self.prune_stats is not None and not self.prune_checked:
+                # ONE host read per stream, after its first pruned slab: were the bounds worth their segment maxima?
+                # (every rank reads its own counters; the decision only changes which LOCAL kernels run)
+                self.prune_checked = True
+                read, total, _ = (int(v) for v in self.prune_stats.tolist())
+                if total and read > self.PRUNE_GIVE_UP * total:
+                    self.prune = False
         else:
             ops.max_scores(res, mod, crop, self.scores)
         self.modulation.append(mod)
         return mod
+
+    def score_pass_read_frac(self):
+        """Share of the residual's segments the pruned score passes of this stream read (None: no pruned slab)."""
+        if self.prune_stats is None:
+            return None
+        read, total, _ = (int(v) for v in self.prune_stats.tolist())
+        return read / total if total else None
 
     def finish(self, alphas):
         scores = self.scores

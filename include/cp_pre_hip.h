@@ -57,7 +57,7 @@ typedef struct {
     int64_t sB, sT, sX, sY;
 } pre_out_t;
 
-int pre_abi_version(void);     /* 5 */
+int pre_abi_version(void);     /* 6 */
 
 /* ---- a4/a5/a6: ConvOperator.convolution ---------------------------------------------
  * Utils/ConvOps_2d.py:135-150  F.conv3d(field[:,None], K[None,None], padding=k//2)
@@ -183,8 +183,13 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod,
  *     additions may differ).
  *   pre_segmin_mod_f32: segmin[tc][s] = min of mod[T,X,Y] over the segment's uncropped cells; +inf if there is none,
  *     0 if the segment holds a NaN or a non-positive modulation (-> always read).
- *   pre_joint_score_pruned_f32: scores as pre_joint_score_f32 with crop_t = 0 over the same planes; TC*NS <= 16384
- *     (the work list lives in LDS; else PRE_E_UNSUPPORTED).
+ *   pre_joint_score_pruned_f32: scores as pre_joint_score_f32 with crop_t = 0 over the same planes; TC*NS <= 16320
+ *     (the work list lives in LDS; else PRE_E_UNSUPPORTED).  flags (device uint32 [n], may be NULL; ABI v6): a sample
+ *     whose bounds leave more than a quarter of its segments to read (a modulation that jumps between neighbouring
+ *     cells) is not read segment by segment but flagged, flags[i] = 1 (else 0), for pre_joint_score_flagged_f32 - the
+ *     full pass at its full speed over those samples.  stats (device, 3 x uint64, may be NULL): [0] += segments read
+ *     (all of a flagged sample's), [1] += segments, [2] += samples flagged - what a streaming driver needs to drop the
+ *     bounds for the slabs that follow, and a benchmark to say what fraction of the pass its data let it skip.
  * A t crop is applied by handing in the interior planes: a + crop_t*X*Y with T - 2*crop_t planes, row_stride unchanged. */
 int pre_moments_segmax_f64(const float *a, int64_t row_stride, int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x,
                            int crop_y, double *sum, double *sumsq, uint32_t *segmax, void *stream);
@@ -192,7 +197,12 @@ int pre_segmin_mod_f32(const float *mod, int64_t T, int64_t X, int64_t Y, int cr
                        void *stream);
 int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float *mod, const uint32_t *segmax,
                                const float *segmin, int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y,
-                               float *scores, void *stream);
+                               float *scores, uint32_t *flags, unsigned long long *stats, void *stream);
+/* pre_joint_score_f32 over the samples i with flags[i] != 0 only (the others' workgroups leave at once): the pass a
+ * driver launches behind pre_joint_score_pruned_f32 for the samples it flagged (ABI v6). */
+int pre_joint_score_flagged_f32(const float *a, const float *b, const float *mod,
+                                int64_t n, int64_t T, int64_t X, int64_t Y,
+                                int crop_t, int crop_x, int crop_y, const uint32_t *flags, float *scores, void *stream);
 
 /* ---- a11: calibrate(scores, n, alpha) ---------------------------------------------------
  * (Neural_PDE.UQ.inductive_cp, absent; call sites Marginal/Wave_Residuals_CP.py:288,

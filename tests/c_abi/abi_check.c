@@ -47,7 +47,7 @@ static int cmp_float(const void *a, const void *b) { const float x = *(const flo
 int main(void)
 {
     int failures = 0;
-    EXPECT(pre_abi_version() == 5, "pre_abi_version() == 5");
+    EXPECT(pre_abi_version() == 6, "pre_abi_version() == 6");
 
     /* ---- the reference's kernels: kernel_3d(stencil, axis) with the stencil on slab 1 (Utils/ConvOps_2d.py:67-79) */
     float Kt[27] = {0}, Kx[27] = {0}, Ky[27] = {0}, Kl[27] = {0};

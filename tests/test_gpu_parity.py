@@ -834,6 +834,65 @@ def test_pruned_joint_score_equals_full_pass(gpu, shape, crop, monkeypatch):
     assert not ops.can_prune(res, crop)
 
 
+@pytest.mark.parametrize("shape", [(300, 16, 64, 256), (64, 5, 24, 128)])
+def test_pruned_joint_score_adapts_to_wild_modulation(gpu, shape, monkeypatch):
+    """The adaptive route of the branch-and-bound score (round 3).  A per-cell scale that jumps by orders of magnitude
+    between neighbouring cells makes max |r| / min mod a useless bound: the kernel then flags such a sample for the full
+    pass over the flagged samples (stats[2] counts them), the driver reads the counters once after its first pruned slab and takes the plain passes
+    from then on - and the scores, the modulation and q-hat stay those of the full pass.  Also: a negative and a
+    subnormal modulation (eps < 0 / scores of ~1e-40 scale) go through both passes alike."""
+    from cp_pre_amd import pipeline
+    B, T, X, Y = shape
+    ops = pipeline.HipOps
+    monkeypatch.setattr(ops, "PRUNE_MIN_CELLS", 0)
+    monkeypatch.setattr(ops, "PRUNE_MIN_SAMPLES", 0)
+    g = torch.Generator().manual_seed(B + T)
+    crop = (0, 1, 1)
+    alphas = [0.1, 0.5, 0.9]
+    scale = torch.exp(3.0 * torch.randn(T, X, Y, generator=g)).to(gpu)
+    full_jc, ad_jc = pipeline.JointCalibration(B, gpu, prune=False), pipeline.JointCalibration(B, gpu)
+    for slab in range(3):
+        res = torch.randn(B, T, X, Y, generator=g).to(gpu) * scale
+        assert ops.can_prune(res, crop)
+        m1, m2 = full_jc.add_slab(res, crop=crop), ad_jc.add_slab(res, crop=crop)
+        assert torch.allclose(m1, m2, rtol=1e-6, atol=0.0)
+        assert torch.allclose(full_jc.scores, ad_jc.scores, rtol=1e-5, atol=0.0)
+        if slab == 0:
+            read, total, swept = (int(v) for v in ad_jc.prune_stats.tolist())
+            assert total == B * ((T + 15) // 16) * ((X * Y + 63) // 64) and swept > B // 2 and read > 0.25 * total
+            assert ad_jc.prune is False                                    # the stream gave the bounds up
+    assert ad_jc.score_pass_read_frac() > 0.25
+    assert torch.allclose(full_jc.finish(alphas), ad_jc.finish(alphas), rtol=1e-5, atol=0.0)
+    # smooth data keeps them (at a few hundred samples sigma-hat is noisy enough for the odd sample to be swept whole)
+    sm_jc = pipeline.JointCalibration(B, gpu)
+    res = torch.randn(B, T, X, Y, generator=g).to(gpu)
+    sm_jc.add_slab(res, crop=crop)
+    if B >= 256:                         # (with a few dozen samples the bounds are loose on any data)
+        assert sm_jc.prune is True and int(sm_jc.prune_stats[2]) < B // 4 and sm_jc.score_pass_read_frac() < 0.25
+    # same modulation -> same scores, with a negative modulation cell (full pass: a quotient <= 0 never raises the
+    # maximum) and subnormal modulations (the skip-the-divide test of js_update is not valid there: always divided)
+    for kind in ("negative", "subnormal"):
+        res = torch.randn(B, T, X, Y, generator=g).to(gpu)
+        mom = ops.zeros_moments(T * X * Y, gpu)
+        segmax = ops.add_moments_segmax(res, mom, crop)
+        mod = ops.std_from_moments(mom, B, (T, X, Y), 0.0, like=res)
+        if kind == "negative":
+            mod[T // 2, X // 2, 5::7] = -0.5
+        else:
+            res = res * 1e-40
+            mom = ops.zeros_moments(T * X * Y, gpu)
+            segmax = ops.add_moments_segmax(res, mom, crop)
+            mod = (torch.rand(T, X, Y, generator=g) * 3e-40 + 1e-41).to(gpu)
+            assert float(mod.max()) < 1.2e-38
+        s_full, s_pr = ops.zeros_scores(B, gpu), ops.zeros_scores(B, gpu)
+        ops.max_scores(res, mod, crop, s_full)
+        ops.max_scores_pruned(res, mod, segmax, crop, s_pr)
+        assert torch.equal(s_full, s_pr), kind
+        if kind == "subnormal":          # ... and both are the exactly rounded quotients (numpy divides the same way)
+            want = (res.abs() / mod)[:, :, 1:-1, 1:-1].amax(dim=(1, 2, 3))
+            assert torch.equal(s_full, want)
+
+
 @pytest.mark.parametrize("order", [(2, 3, 1), (3, 1, 2), (1, 3, 2)])
 def test_pruned_joint_score_on_permuted_layouts(gpu, order, monkeypatch):
     """The branch-and-bound score pass on residuals whose cell axes are permuted in memory (``order`` = the logical axes
