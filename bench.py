@@ -428,11 +428,14 @@ def main():
     res_of = {sl: res_buf[:B * sl * X * Y].view(B, sl, X, Y) for sl in set(slabs)}
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(n_slabs * (args.steps + args.warmup))]
+          for _ in range(n_slabs * (args.steps + args.warmup + 2))]          # (+2: the full-score-pass steps after the timed loop)
     ev_used = []
 
-    def step(k):
-        jc = pipeline.JointCalibration(B, dev, group=group, prune=not args.no_prune) if args.mode == "joint" else None
+    last_jc = [None]
+
+    def step(k, prune=not args.no_prune):
+        jc = pipeline.JointCalibration(B, dev, group=group, prune=prune) if args.mode == "joint" else None
+        last_jc[0] = jc
         q = None
         for s, sl in enumerate(slabs):
             res = res_of[sl]
@@ -470,8 +473,25 @@ def main():
     cells_per_step = B * sum(slabs) * X * Y * world                   # whole job, all ranks
     value = cells_per_step * args.steps / elapsed
 
+    # The branch-and-bound score pass makes `value` depend on the data (how much of the residual the bounds let it
+    # skip).  Say by how much: the share of the pass that was read, and the same step with the full pass - one more
+    # step, timed apart, not part of `value`.
+    read_frac = ms_full = None
+    if args.mode == "joint" and not args.no_prune:
+        read_frac = last_jc[0].score_pass_read_frac()
+        step(args.warmup + args.steps, prune=False)                   # (untimed: first use of the full-pass kernels)
+        sync()
+        t1 = time.perf_counter()
+        step(args.warmup + args.steps + 1, prune=False)
+        sync()
+        ms_full = 1e3 * (time.perf_counter() - t1)
+        if group is not None:
+            tt = torch.tensor([ms_full], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            ms_full = float(tt.item())
+
     if rank == 0:
-        timed = [(sl, e0.elapsed_time(e1)) for (k, sl, e0, e1) in ev_used if k >= args.warmup]     # ms, this rank
+        timed = [(sl, e0.elapsed_time(e1)) for (k, sl, e0, e1) in ev_used if args.warmup <= k < args.warmup + args.steps]     # ms, this rank
         kms = sum(d for _, d in timed) / len(timed)
         # 3 fields read + 1 residual written = 16 B per cell the launch COMPUTES (its interior
         # planes); the two halo planes each slab re-reads are overhead, reported apart
@@ -492,9 +512,13 @@ def main():
                        # `value` is measured with the fields resident in HBM (contract); if the 3 fields came from host
                        # memory instead, PCIe Gen5 x16 (63 GB/s spec) would bound the job at 63e9 / 12 B per cell
                        "inputs": "resident in HBM", "host_fed_bound_cells_per_s": 63e9 / 12.0,
-                       **({"score_pass": "branch-and-bound (bit-identical scores)"
+                       **({"score_pass": "branch-and-bound (same scores as the full pass for the same modulation; adaptive: "
+                                         "flagged samples and wasteful streams take the full pass)"
                            if not args.no_prune and pipeline.HipOps.can_prune(res_of[slabs[0]], (0, 1, 1)) else "full"}
                           if args.mode == "joint" else {})},
+            # data dependence of `value`: share of the score pass's segments that were read (the synthetic residuals are
+            # noise-like: tight bounds), and the same step with the full score pass (--no-prune)
+            "score_pass_read_frac": read_frac, "ms_per_step_full_score_pass": ms_full,
             "roofline": {"bound": "hbm", "kernel": "march_kernel<NSMomentum<0>,8,64>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
