@@ -387,7 +387,9 @@ def main():
         # fewer, thicker slabs re-read fewer halo planes (64 planes: 16 -> 4 slabs, 13 -> 5, 8 -> 8); the resident
         # set of S = 16 at the full batch is 301 GB of the 309 GB the device reports, so it is taken only if it fits.
         # Smaller per-rank batches (--scaling strong, --batch) afford thicker slabs, up to the whole T axis (no halo).
-        extra = 4 * (4 << 30) if (args.mode == "marginal" and group is not None) else 0   # the exchange's staging buffers
+        # sharded marginal CP: the exchange receives ONE plane of all ranks' samples at a time (no send staging: the
+        # residual is written time-major, pipeline.time_major)
+        extra = 4 * world * B * X * Y if (args.mode == "marginal" and world > 1) else 0
         extra += (1 << 30) if group is not None else 0                 # headroom for RCCL's own scratch beyond the warm-up collective
         cands = [c for c in (args.nt, (args.nt + 1) // 2, (args.nt + 2) // 3, 16, 13, 8) if 0 < c <= args.nt]
         idx = next((i for i, c in enumerate(cands) if resident_bytes(B, args.nt, c, X, Y) + extra <= free - (4 << 30)),
@@ -425,7 +427,12 @@ def main():
     # residual buffer: the slab's INTERIOR planes only (the slab's first and last plane are halo planes that every
     # consumer would crop: they are neither computed nor stored, PRE_FLAG_OUT_INTERIOR_T)
     res_buf = torch.empty(B * S * X * Y, dtype=torch.float32, device=dev)
-    res_of = {sl: res_buf[:B * sl * X * Y].view(B, sl, X, Y) for sl in set(slabs)}
+    if args.mode == "marginal" and group is not None:
+        # time-major [sl][B][X][Y] seen as [B,sl,X,Y]: plane t of all local samples is one contiguous block, the send
+        # block of the all-to-all that hands plane t to rank t % world (pipeline.marginal_qhat: no pack copy)
+        res_of = {sl: res_buf[:B * sl * X * Y].view(sl, B, X, Y).transpose(0, 1) for sl in set(slabs)}
+    else:
+        res_of = {sl: res_buf[:B * sl * X * Y].view(B, sl, X, Y) for sl in set(slabs)}
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(n_slabs * (args.steps + args.warmup + 2))]          # (+2: the full-score-pass steps after the timed loop)

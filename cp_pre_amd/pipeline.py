@@ -249,22 +249,107 @@ class JointCalibration:
         return self.ops.kth(scores, _ranks(self.n_total, alphas))
 
 
-def marginal_qhat(scores, alphas, group=None, ops=None, stage_bytes=4 << 30, overlap=True):
+def time_major(n_local, cells, dtype=torch.float32, device=None):
+    """A score / residual buffer for ``marginal_qhat``'s zero-copy exchange: memory [T][n_local][*rest] (time-major),
+    returned as its logical [n_local, T, *rest] view.  Plane t of every local sample is then one contiguous block -
+    the send block of the all-to-all that gives plane t to rank t % world - so a residual kernel that writes through
+    this view (``NavierStokes.residual_momentum(out=...)``: any batch / time strides over dense planes) has already
+    packed the exchange."""
+    T, rest = cells[0], tuple(cells[1:])
+    return torch.empty((T, n_local) + rest, dtype=dtype, device=device).transpose(0, 1)
+
+
+def _is_time_major(scores):
+    """[n, T, ...] whose memory is [T][n][...] dense (see :func:`time_major`)."""
+    if scores.dim() < 3 or scores.shape[1] < 1:
+        return False
+    return scores.transpose(0, 1).is_contiguous() and (scores.shape[0] > 1 and scores.shape[1] > 1 or scores.is_contiguous())
+
+
+def _marginal_planes(scores, alphas, group, ops, overlap):
+    """Sharded per-cell q-hat of a TIME-MAJOR score tensor [n_local, T, *rest]: no pack copy, one all-to-all per run of
+    ``world`` planes (plane t goes to rank t % world, which selects over all n_local * world samples of it), one
+    all-gather of the q-hat planes at the end.  Bytes on the wire per rank: (world-1)/world of its scores once
+    (4 B x n_local x cells), + nk/n_local of that for the q-hats.  Staging: ONE received plane of all samples
+    (4 B x n_local x world x cells per plane), twice with ``overlap``."""
+    dist = torch.distributed
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_local, T = scores.shape[0], scores.shape[1]
+    rest = tuple(scores.shape[2:])
+    per = 1
+    for d in rest:
+        per *= d
+    ks = _ranks(n_local * world, alphas)          # raises before any collective if a level exceeds 1
+    nk = len(alphas)
+    tm = scores.transpose(0, 1).reshape(T, n_local * per)       # the memory as it lies: [T][n_local * per], no copy
+    runs = (T + world - 1) // world
+    nbuf = 2 if (overlap and runs > 1) else 1
+    recv = [tm.new_empty(world * n_local * per) for _ in range(nbuf)]
+    q_own = tm.new_zeros(runs, nk, per)           # the q-hat planes this rank owns (plane k * world + rank), run by run
+    work = [None] * nbuf
+
+    def exchange(k, b):
+        t0 = k * world
+        pr = min(world, T - t0)                   # planes in this run: ranks >= pr receive nothing
+        send = tm[t0:t0 + pr].reshape(-1)         # contiguous: [pr][n_local * per]
+        in_split = [n_local * per if r < pr else 0 for r in range(world)]
+        out_split = [n_local * per if rank < pr else 0] * world
+        out = recv[b] if rank < pr else recv[b][:0]
+        return dist.all_to_all_single(out, send, out_split, in_split, group=group, async_op=nbuf > 1)
+
+    def select(k):
+        b = k % nbuf
+        if work[b] is not None:
+            work[b].wait()                        # the compute stream waits for run k's exchange
+            work[b] = None
+        if k * world + rank < T:
+            q_own[k] = ops.kth(recv[b].reshape(world * n_local, per), ks).reshape(nk, per)
+
+    for k in range(runs):
+        b = k % nbuf
+        work[b] = exchange(k, b)
+        if nbuf > 1 and k > 0:
+            select(k - 1)
+        elif nbuf == 1:
+            select(k)
+    if nbuf > 1:
+        select(runs - 1)
+    parts = [torch.empty_like(q_own) for _ in range(world)]
+    dist.all_gather(parts, q_own, group=group)                   # nk * (planes owned) * per floats per rank
+    # parts[r][k, j] is q-hat j of plane k * world + r
+    q = torch.stack(parts, dim=1).reshape(runs * world, nk, per)[:T]          # [T, nk, per]
+    return q.transpose(0, 1).reshape((nk, T) + rest)
+
+
+def marginal_qhat(scores, alphas, group=None, ops=None, stage_bytes=4 << 30, overlap=False):
     """Per-cell q-hat [len(alphas), *cells] of |residual| scores [n_local, *cells].
 
-    Single rank: one multi-rank radix select.  Sharded: all-to-all (batch-sharded -> cell-sharded), local select
-    over all ``n_local * world`` samples, ONE all-gather of the result at the end.
+    Single rank (no group, or a group of one: the exchange is the identity): one multi-rank select per tensor, or per
+    plane of a time-major one.  Sharded: all-to-all (batch-sharded -> cell-sharded), local select over all
+    ``n_local * world`` samples, ONE all-gather of the result at the end.
+
+    A TIME-MAJOR tensor (:func:`time_major`: what a t-slab driver lets its residual kernel write) is exchanged where it
+    lies, plane by plane (``_marginal_planes``): no pack copy, no send staging.  Any other layout takes the cell-run
+    form below, which packs each run into a [world, n_local, cells-per-rank] send buffer first.
 
     The exchange runs over runs of cells sized so that one send and one receive staging buffer hold at most
     ``stage_bytes`` each (a C3 slab of scores is 56 GB; staging it whole next to the fields would not fit in HBM).
     ``overlap``: the staging buffers are double-buffered and the all-to-all of run k is issued asynchronously
     (RCCL runs it on its own stream) before the select of run k-1 is enqueued, so the xGMI transfer of one run hides
-    behind the select of the previous one; nothing else is ordered differently, the result is identical."""
+    behind the select of the previous one; nothing else is ordered differently, the result is identical.  Off by
+    default: the stream ordering it relies on (RCCL's stream against the compute stream, reuse of the staging
+    buffers) has only ever run under gloo, whose collectives block the host."""
     ops = ops or HipOps
     n_local, cells = scores.shape[0], tuple(scores.shape[1:])
-    if group is None:
-        return ops.kth(scores, _ranks(n_local, alphas))
-    world = torch.distributed.get_world_size(group)
+    world = torch.distributed.get_world_size(group) if group is not None else 1
+    tmajor = _is_time_major(scores) and not scores.is_contiguous()
+    if world == 1:
+        ks = _ranks(n_local, alphas)
+        if tmajor:                                # plane by plane: each [n_local, *rest] is contiguous
+            return torch.stack([ops.kth(scores[:, t], ks) for t in range(cells[0])], dim=1)
+        return ops.kth(scores, ks)
+    if tmajor:
+        return _marginal_planes(scores, alphas, group, ops, overlap)
     if n_local * world > 0x7fffffff:
         raise ValueError(f"{n_local} x {world} calibration samples exceed the select's 32-bit sample count")
     flat = scores.reshape(n_local, -1)

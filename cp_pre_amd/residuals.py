@@ -127,7 +127,8 @@ class NavierStokes(_Residual2D):
         (fused route only; lets a streaming driver reuse one buffer).  ``skip_t_rim``: the caller
         crops the first and last time plane anyway, so they need not be computed or stored
         (``PRE_FLAG_INTERIOR_T``; their content is then unspecified).  With ``skip_t_rim`` ``out`` may
-        also be a contiguous [BS,Nt-2,Nx,Ny] tensor: it then receives the interior planes only
+        also be a [BS,Nt-2,Nx,Ny] tensor (contiguous, or any batch / time strides over dense planes): it then receives
+        the interior planes only
         (``PRE_FLAG_OUT_INTERIOR_T``; what a t-slab driver that feeds slabs with their two halo planes
         wants) and the result is that tensor, cropped in x and y unless ``boundary``."""
         u, v, p = vars[:, 0], vars[:, 1], vars[:, 2]
@@ -149,8 +150,12 @@ class NavierStokes(_Residual2D):
                 if not (out.is_cuda and out.dtype == torch.float32 and (out.shape == du.shape or interior)):
                     raise ValueError("out must be an fp32 device tensor of the field shape "
                                      "(or, with skip_t_rim, of its interior planes [BS,Nt-2,Nx,Ny])")
-                if interior and not (out.is_contiguous() and origin is None and not _dispatch.needs_grad(u, v, p)):
-                    raise ValueError("an interior-plane out needs device-resident fields, a contiguous out and no autograd")
+                # (the planes of an interior out must be dense, its batch and time strides are free: a t-slab driver that
+                # shards the marginal calibration hands in a TIME-MAJOR buffer [Nt-2][BS][Nx][Ny] seen as [BS,Nt-2,Nx,Ny],
+                # whose planes then are the contiguous send blocks of its all-to-all - pipeline.marginal_qhat)
+                dense_planes = out.dim() == 4 and out.stride(3) == 1 and out.stride(2) == out.shape[3]
+                if interior and not (dense_planes and origin is None and not _dispatch.needs_grad(u, v, p)):
+                    raise ValueError("an interior-plane out needs device-resident fields, dense [Nx,Ny] planes and no autograd")
                 flags = (_lib.PRE_FLAG_ABS if absolute else 0) | (_lib.PRE_FLAG_INTERIOR_T if skip_t_rim else 0) | \
                         (_lib.PRE_FLAG_OUT_INTERIOR_T if interior else 0)
                 fu, fv, fp, fo = _lib.field(du), _lib.field(dv), _lib.field(dp), _lib.field(out)

@@ -76,12 +76,23 @@ def _worker(rank, world, port, n_local, shape, slabs, out_dir):
         qm_runs = pipeline.marginal_qhat(mine.abs().contiguous(), ALPHAS, group=dist.group.WORLD, ops=CpuOps,
                                          stage_bytes=4 * n_local * world * 100)
         assert torch.equal(qm_runs, qm)
-        # the double-buffered asynchronous exchange (default) against the blocking one, 1 / 4 / 8 runs
+        # the double-buffered asynchronous exchange against the blocking one (the default), 1 / 4 / 8 runs
         for cells_per_rank in (400, 100, 50):
             kw = dict(group=dist.group.WORLD, ops=CpuOps, stage_bytes=4 * n_local * world * cells_per_rank)
             a = pipeline.marginal_qhat(mine.abs().contiguous(), ALPHAS, overlap=True, **kw)
             b = pipeline.marginal_qhat(mine.abs().contiguous(), ALPHAS, overlap=False, **kw)
             assert torch.equal(a, b) and torch.equal(a, qm)
+        # a TIME-MAJOR score buffer (what the t-slab driver lets the residual kernel write) is exchanged where it lies,
+        # plane t to rank t % world, no pack: 10 planes over 2 / 3 ranks = 5 runs / 3 runs and a ragged one
+        tm = pipeline.time_major(n_local, mine.shape[1:])
+        tm.copy_(mine.abs())
+        assert not tm.is_contiguous() and pipeline._is_time_major(tm)
+        for ov in (False, True):
+            q_tm = pipeline.marginal_qhat(tm, ALPHAS, group=dist.group.WORLD, ops=CpuOps, overlap=ov)
+            assert q_tm.shape == qm.shape and torch.equal(q_tm, qm), ov
+        one = pipeline.time_major(n_local, (1,) + tuple(mine.shape[2:]))       # a single plane: rank 0 owns it, the others idle
+        one.copy_(mine.abs()[:, 3:4])
+        assert torch.equal(pipeline.marginal_qhat(one, ALPHAS, group=dist.group.WORLD, ops=CpuOps), qm[:, 3:4])
         with pytest.raises(ValueError):                       # a level above 1 is refused before any collective
             pipeline.marginal_qhat(mine.abs().contiguous(), [1e-6], group=dist.group.WORLD, ops=CpuOps)
         np.save(os.path.join(out_dir, f"q_{rank}.npy"), q.numpy())
@@ -137,3 +148,6 @@ def test_single_rank_pipeline_equals_whole_tensor_oracle():
         assert abs(q[j] - oc.calibrate(sc, 12, a)) <= 1e-6 * abs(q[j])
     qm = pipeline.marginal_qhat(t.abs(), ALPHAS, ops=CpuOps).numpy()
     assert np.array_equal(qm[2], oc.calibrate(np.abs(res), 12, 0.5))
+    tm = pipeline.time_major(12, t.shape[1:])                 # time-major buffer, no group: plane by plane, same result
+    tm.copy_(t.abs())
+    assert np.array_equal(pipeline.marginal_qhat(tm, ALPHAS, ops=CpuOps).numpy(), qm)

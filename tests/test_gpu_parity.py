@@ -1743,10 +1743,36 @@ def _sharded_worker(rank, world, port, n_local, shape, out_dir):
             jc.add_slab(mine[:, s * (T - 2) // 2:s * (T - 2) // 2 + (T - 2) // 2 + 2].contiguous(), crop=(1, 1, 1))
         q = jc.finish(alphas)
         qm = pipeline.marginal_qhat(mine.abs().contiguous(), alphas, group=dist.group.WORLD, stage_bytes=4 * n_local * world * 1000)
+        # the zero-copy exchange of a time-major score buffer (round 3): plane t to rank t % world, no pack
+        tm = pipeline.time_major(n_local, shape, device=dev)
+        tm.copy_(mine.abs())
+        for ov in (False, True):
+            assert torch.equal(pipeline.marginal_qhat(tm, alphas, group=dist.group.WORLD, overlap=ov), qm), ov
         np.save(os.path.join(out_dir, f"q_{rank}.npy"), q.cpu().numpy())
         np.save(os.path.join(out_dir, f"qm_{rank}.npy"), qm.cpu().numpy())
     finally:
         dist.destroy_process_group()
+
+
+def test_time_major_residual_buffer_and_planewise_qhat(gpu):
+    """The t-slab driver's residual buffer for sharded marginal CP: memory [T][B][X][Y] handed to the fused kernel as
+    an interior-plane ``out`` view [B,T-2,X,Y] (any batch / time strides over dense planes).  Same numbers as the
+    contiguous buffer, bit for bit; q-hat of the time-major view (plane by plane, no copy) == q-hat of a copy."""
+    from cp_pre_amd import pipeline
+    from cp_pre_amd.residuals import NavierStokes
+    B, T, X, Y = 37, 9, 24, 256
+    g = torch.Generator().manual_seed(77)
+    v = (torch.rand(B, 3, T, X, Y, generator=g) + 0.5).to(gpu)
+    ns = NavierStokes(1e-2, 1.0 / X, 1.0 / Y, nu=1e-3)
+    ref = torch.empty(B, T - 2, X, Y, device=gpu)
+    ns.residual_momentum(v, boundary=True, absolute=True, out=ref, skip_t_rim=True)
+    tm = pipeline.time_major(B, (T - 2, X, Y), device=gpu)
+    tm.fill_(float("nan"))
+    got = ns.residual_momentum(v, boundary=True, absolute=True, out=tm, skip_t_rim=True)
+    assert got.data_ptr() == tm.data_ptr() and not tm.is_contiguous() and tm.transpose(0, 1).is_contiguous()
+    assert torch.equal(tm, ref)
+    alphas = [0.1, 0.5, 0.9]
+    assert torch.equal(pipeline.marginal_qhat(tm, alphas), pipeline.marginal_qhat(ref, alphas))
 
 
 @pytest.mark.timeout(300)
