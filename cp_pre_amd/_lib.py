@@ -49,6 +49,7 @@ SIGNATURES = {
     "pre_residual_linear2_f32": [_fld, _fld, _fld, POINTER(c_float), POINTER(c_float), c_float] + [c_int64] * 4 + [c_int, c_void_p],
     "pre_residual_burgers_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_int64)] + [POINTER(c_float)] * 3 + [c_float] * 4 + [c_int64] * 3 + [c_int, c_void_p],
     "pre_residual_mhd_f32": [c_int, POINTER(PreField), _fld] + [POINTER(c_float)] * 3 + [c_double] + [c_int64] * 4 + [c_int, c_void_p],
+    "pre_residual_jorek_f32": [c_int, POINTER(PreField), _fld, _fld] + [POINTER(c_float)] * 6 + [c_int64] * 4 + [c_int, c_void_p],
     "pre_spatial2d_bc_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_int64), POINTER(c_float), POINTER(PreBC), c_int64, c_int64, c_int64, c_int, c_void_p],
     "pre_spatial2d_linear2_bc_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_int64), _fp, POINTER(c_int64), POINTER(c_float), POINTER(c_float),
                                      c_float, POINTER(PreBC), c_int64, c_int64, c_int64, c_int, c_void_p],

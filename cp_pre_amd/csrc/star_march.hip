@@ -218,6 +218,61 @@ struct MHDInduction {  // Marginal/MHD_Residuals_CP.py:259-268   fields u,v,Bx,B
     }
 };
 
+// Reduced MHD (JOREK), Marginal/JOREK_residuals_CP.py:207-243 (twin: Joint/JOREK_residuals_CP.py).  Fields rho, phi, T
+// and the radius R - in the script a 1-D grid tensor broadcast along the LAST axis of the [BS,Nt,Nx,Ny] fields, here one
+// more "field" whose view repeats that row (zero strides on the other axes): only its centre value is used.  D_R / D_RR
+// share the tap structure of D_x, D_Z / D_ZZ that of D_y (the reference's 'y' operators have their taps along Nt,
+// SURVEY 0.5 - inherited through the dense kernels like everywhere else).  Evaluation order = the script's.
+//   continuity:  res = a0*D_t(rho) - (a1*R)*X(rho) - (a2*rho)*D_Z(phi) - a3*Y(rho)
+//                X(f) = D_R(f)*D_Z(phi) - D_R(phi)*D_Z(f),  Y(f) = (D_RR(f) + (1/R)*D_R(f)) + D_ZZ(f)
+//                norms=False: a = (1, 1, 2, D);  norms=True: the script's folded scalars (host, fp32, same order)
+//   temperature: res = T*D_t(rho) + rho*D_t(T) - (rho*R)*X(T) + (T*R)*X(rho) + ((a0*rho)*T)*D_Z(phi) + a3*Y(T),
+//                a0 = 2*gamma, a3 = K
+struct JorekParams { Star Dt, DR, DZ, DRR, DZZ; float a0, a1, a2, a3; };
+
+template <int MODE>
+struct JorekContinuity {
+    static constexpr int F = 3;        // rho, phi, R
+    using Params = JorekParams;
+    static __device__ __forceinline__ float4 eval(const Nbr (&n)[3], const Params &p)
+    {
+        using K = OpKinds<MODE>;
+        const Nbr &rho = n[0], &phi = n[1];
+        const float4 R = n[2].c;
+        const float4 dRrho = apply<K::DX>(p.DR, rho), dZphi = apply<K::DY>(p.DZ, phi);
+        const float4 X = dRrho * dZphi - apply<K::DX>(p.DR, phi) * apply<K::DY>(p.DZ, rho);
+        const float4 Y = (apply<K::DX>(p.DRR, rho) + (f4(1.0f) / R) * dRrho) + apply<K::DY>(p.DZZ, rho);
+        float4 r = p.a0 * apply<K::DT>(p.Dt, rho);
+        r = r - (p.a1 * R) * X;
+        r = r - (p.a2 * rho.c) * dZphi;
+        r = r - p.a3 * Y;
+        return r;
+    }
+};
+
+template <int MODE>
+struct JorekTemperature {
+    static constexpr int F = 4;        // rho, phi, T, R
+    using Params = JorekParams;
+    static __device__ __forceinline__ float4 eval(const Nbr (&n)[4], const Params &p)
+    {
+        using K = OpKinds<MODE>;
+        const Nbr &rho = n[0], &phi = n[1], &T = n[2];
+        const float4 R = n[3].c;
+        const float4 dZphi = apply<K::DY>(p.DZ, phi), dRphi = apply<K::DX>(p.DR, phi);
+        const float4 dRT = apply<K::DX>(p.DR, T);
+        const float4 XT = dRT * dZphi - dRphi * apply<K::DY>(p.DZ, T);
+        const float4 Xr = apply<K::DX>(p.DR, rho) * dZphi - dRphi * apply<K::DY>(p.DZ, rho);
+        const float4 YT = (apply<K::DX>(p.DRR, T) + (f4(1.0f) / R) * dRT) + apply<K::DY>(p.DZZ, T);
+        float4 r = T.c * apply<K::DT>(p.Dt, rho) + rho.c * apply<K::DT>(p.Dt, T);
+        r = r - (rho.c * R) * XT;
+        r = r + (T.c * R) * Xr;
+        r = r + ((p.a0 * rho.c) * T.c) * dZphi;
+        r = r + p.a3 * YT;
+        return r;
+    }
+};
+
 // ------------------------------------------------------------------ the marching kernel
 // Global float4 accesses are declared 4-byte aligned: gfx950 runs with unaligned access enabled and
 // the compiler still emits one global_load/store_dwordx4, so views whose base or row pitch is not a
@@ -841,6 +896,40 @@ int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], const pre_out_t *o
     if (rc) return rc;
     if (eq == 1) return launch_mode<MHDMomentum>(relabeled_mode(mode, rel), g, prm, st);
     return launch_mode<MHDEnergy>(relabeled_mode(mode, rel), g, prm, st);
+}
+
+int pre_residual_jorek_f32(int eq, const pre_field_t fields[3], const pre_field_t *Rb, const pre_out_t *out,
+                           const float *K_t, const float *K_R, const float *K_Z, const float *K_RR, const float *K_ZZ,
+                           const float coef[4], int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)
+{
+    if (!fields || !Rb || !K_t || !K_R || !K_Z || !K_RR || !K_ZZ || !coef) return PRE_E_NULL;
+    if (eq < 0 || eq > 1) return PRE_E_RANGE;
+    JorekParams prm;
+    if (!star_from_dense27(K_t, &prm.Dt) || !star_from_dense27(K_R, &prm.DR) || !star_from_dense27(K_Z, &prm.DZ) ||
+        !star_from_dense27(K_RR, &prm.DRR) || !star_from_dense27(K_ZZ, &prm.DZZ))
+        return PRE_E_UNSUPPORTED;
+    prm.a0 = coef[0]; prm.a1 = coef[1]; prm.a2 = coef[2]; prm.a3 = coef[3];
+    // D_RR must fit D_R's compiled tap structure and D_ZZ that of D_Z, else every operator is a general star
+    int mode = pick_mode(prm.Dt, prm.DR, prm.DZ, nullptr);
+    {
+        const Shape rr = shape_of(prm.DRR), zz = shape_of(prm.DZZ);
+        const bool rr_ok = !rr.t && !rr.y, zz_ok = mode == 0 ? (!zz.x && !zz.y) : (!zz.x && !zz.t);
+        if (mode != 2 && !(rr_ok && zz_ok)) mode = 2;
+    }
+    Star *stars[5] = {&prm.Dt, &prm.DR, &prm.DZ, &prm.DRR, &prm.DZZ};
+    Geom g;
+    int rel;
+    hipStream_t st = as_stream(stream);
+    if (eq == 0) {
+        const pre_field_t *fs[3] = {&fields[0], &fields[1], Rb};
+        int rc = prepare(g, rel, fs, 3, out, B, T, X, Y, flags, stars, 5);
+        if (rc) return rc;
+        return launch_mode<JorekContinuity>(relabeled_mode(mode, rel), g, prm, st);
+    }
+    const pre_field_t *fs[4] = {&fields[0], &fields[1], &fields[2], Rb};
+    int rc = prepare(g, rel, fs, 4, out, B, T, X, Y, flags, stars, 5);
+    if (rc) return rc;
+    return launch_mode<JorekTemperature>(relabeled_mode(mode, rel), g, prm, st);
 }
 
 // ---- 2-D spatial operators with boundary conditions ----------------------------

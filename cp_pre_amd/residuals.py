@@ -280,6 +280,122 @@ class MHD(_Residual2D):
         return _finish(res, boundary, _CROP3, absolute, done_abs)
 
 
+# ======================================================================= reduced MHD (JOREK)
+class JOREK:
+    """``Marginal/JOREK_residuals_CP.py:188-243`` (twin ``Joint/JOREK_residuals_CP.py``): continuity and temperature
+    residuals of the reduced-MHD fields (rho, phi, T) on an (R, Z) grid.
+
+    ``vars`` is what the script holds, [BS, F, Nx, Ny, Nt] (the surrogate's layout); like its ``unstack_fields``
+    (:84-95) every field is taken as the [BS, Nt, Nx, Ny] permuted view, zero-copy.  ``R`` is the 1-D radius grid
+    tensor; the script's expressions broadcast it along the LAST axis of those views (its grid is square), and so
+    does this class - ``len(R)`` must equal Ny.  The five operators are built as the script builds them (:201-205):
+    ``D_t`` with ``scale=alpha``, ``D_R`` / ``D_Z`` with ``scale=beta`` and ``D_RR`` / ``D_ZZ`` with the value the
+    name ``gamma`` holds at that point of the script - already the adiabatic index (:199), hence the default
+    ``lap_scale=None`` -> ``gamma``.  ``domain='y'`` carries the reference's kernel (taps along Nt).  All five
+    ``.kernel`` tensors may be replaced by the caller; the fused route hands the current ones to the library."""
+
+    def __init__(self, R, D=3.4, K=2.25 * 1e-7, gamma=5 / 3, alpha=1, beta=1, lap_scale=None, dx=None, dy=None, dt=None,
+                 device='cpu', fused=True, y_axis_fix=False):
+        self.fused = fused
+        self.R = torch.as_tensor(R, dtype=torch.float32)
+        self.D, self.K, self.gamma = D, K, gamma
+        self.dx, self.dy, self.dt = dx, dy, dt
+        lap = torch.tensor(gamma, dtype=torch.float32) if lap_scale is None else lap_scale
+        self.D_t = ConvOperator2D(domain='t', order=1, scale=alpha, device=device)
+        self.D_R = ConvOperator2D(domain='x', order=1, scale=beta, device=device)
+        self.D_Z = ConvOperator2D(domain='y', order=1, scale=beta, device=device, y_axis_fix=y_axis_fix)
+        self.D_RR = ConvOperator2D(domain='x', order=2, scale=lap, device=device)
+        self.D_ZZ = ConvOperator2D(domain='y', order=2, scale=lap, device=device, y_axis_fix=y_axis_fix)
+
+    @staticmethod
+    def unstack_fields(vars):
+        """The script's ``unstack_fields(vars, axis=1, ...)``: [BS,F,Nx,Ny,Nt] -> F views [BS,Nt,Nx,Ny]."""
+        return [vars[:, i].permute(0, 3, 1, 2) for i in range(vars.shape[1])]
+
+    def _ops(self):
+        return (self.D_t, self.D_R, self.D_Z, self.D_RR, self.D_ZZ)
+
+    def _t32(self, x, like):
+        return torch.as_tensor(x, dtype=torch.float32).to(like.device)
+
+    def _fused(self, eq, fields, coef, absolute):
+        """One streaming pass (``pre_residual_jorek_f32``); None -> compose."""
+        if not self.fused or any(f.numel() == 0 for f in fields) or \
+                _dispatch.needs_grad(*[getattr(o, "kernel", None) for o in self._ops()]):
+            return None
+        ks = [_dispatch.dense27(o.kernel) for o in self._ops()]
+        if any(k is None for k in ks):
+            return None
+        with torch.no_grad():
+            devs, origin = _stage(fields)
+        f0 = devs[0]
+        if self.R.numel() != f0.shape[3]:
+            raise RuntimeError(f"R has {self.R.numel()} points, the fields' last axis {f0.shape[3]} (the reference "
+                               "broadcasts its 1-D R along the last axis)")
+        # R as one more field view that repeats the row: unit stride on the axis the fields are contiguous on
+        Rd = self.R.to(f0.device)
+        if f0.stride(3) == 1:
+            Rb = Rd.view(1, 1, 1, -1).expand(f0.shape)
+        elif f0.stride(1) == 1:                                           # Nt fastest (the surrogate's memory order)
+            Rb = Rd.view(-1, 1).expand(-1, f0.shape[1]).contiguous().as_strided(tuple(f0.shape), (0, 1, 0, f0.shape[1]))
+        else:
+            return None
+        out = _lib.empty_like_layout(f0)
+        arr = (_lib.PreField * 3)(*[_lib.field(devs[i] if i < len(devs) else devs[0]) for i in range(3)])
+        fo, fr = _lib.field(out), _lib.field(Rb)
+        with torch.cuda.device(out.device):
+            ok = _fused_call("pre_residual_jorek_f32", lambda: _lib.load().pre_residual_jorek_f32(
+                eq, arr, ctypes.byref(fr), ctypes.byref(fo), *ks, _lib.farr(coef), *out.shape,
+                _lib.PRE_FLAG_ABS if absolute else 0, _lib.stream()))
+        return _dispatch.from_device(out, origin) if ok else None
+
+    def residual_continuity(self, vars, boundary=False, norms=False, absolute=False):
+        """:207-221."""
+        D_t, D_R, D_Z, D_RR, D_ZZ = self._ops()
+        rho, phi, _ = self.unstack_fields(vars)
+        if norms and (self.dx is None or self.dy is None or self.dt is None):
+            raise ValueError("norms=True needs dx, dy, dt")
+
+        def composed(rho, phi):
+            R, D = self._t32(self.R, rho), self._t32(self.D, rho)
+            if norms:
+                dx, dy, dt = (self._t32(v, rho) for v in (self.dx, self.dy, self.dt))
+                return 2*dx*dy*D_t(rho) - (dt)*R*(D_R(rho)*D_Z(phi) - D_R(phi)*D_Z(rho)) - (2*dt*dy)*2*rho*D_Z(phi) \
+                    - (4*dt)*D*(D_RR(rho) + (1/R)*D_R(rho) + D_ZZ(rho))
+            return D_t(rho) - R*(D_R(rho)*D_Z(phi) - D_R(phi)*D_Z(rho)) - 2*rho*D_Z(phi) \
+                - D*(D_RR(rho) + (1/R)*D_R(rho) + D_ZZ(rho))
+        if norms:      # the script's scalars, folded in fp32 in its own order of operations
+            t = lambda v: torch.tensor(v, dtype=torch.float32)
+            dx, dy, dt, D = t(self.dx), t(self.dy), t(self.dt), t(self.D)
+            coef = [float(2*dx*dy), float(dt), float((2*dt*dy)*2), float((4*dt)*D)]
+        else:
+            coef = [1.0, 1.0, 2.0, float(torch.tensor(self.D, dtype=torch.float32))]
+        res = _attach(self._fused(0, (rho, phi), coef, absolute), (rho, phi), composed, absolute)
+        if res is None:
+            return _finish(_on_device((rho, phi), composed), boundary, _CROP3, absolute, False)
+        return _finish(res, boundary, _CROP3, absolute, True)
+
+    def residual_temperature(self, vars, boundary=False, norms=False, absolute=False):
+        """:224-243."""
+        if norms:
+            raise Exception("Norm not implemented yet")              # (as the reference, :230)
+        D_t, D_R, D_Z, D_RR, D_ZZ = self._ops()
+        rho, phi, T = self.unstack_fields(vars)
+
+        def composed(rho, phi, T):
+            R, K, gamma = self._t32(self.R, rho), self._t32(self.K, rho), self._t32(self.gamma, rho)
+            return T*D_t(rho) + rho*D_t(T) - rho*R*(D_R(T)*D_Z(phi) - D_R(phi)*D_Z(T)) + \
+                T*R*(D_R(rho)*D_Z(phi) - D_R(phi)*D_Z(rho)) + \
+                2*gamma*rho*T*D_Z(phi) + \
+                K * (D_RR(T) + (1/R)*D_R(T) + D_ZZ(T))
+        t = lambda v: torch.tensor(v, dtype=torch.float32)
+        coef = [float(2 * t(self.gamma)), 0.0, 0.0, float(t(self.K))]
+        res = _attach(self._fused(1, (rho, phi, T), coef, absolute), (rho, phi, T), composed, absolute)
+        if res is None:
+            return _finish(_on_device((rho, phi, T), composed), boundary, _CROP3, absolute, False)
+        return _finish(res, boundary, _CROP3, absolute, True)
+
+
 class PRE_MHD(MHD):
     """``Other_UQ/Evaluation/PRE_estimations.py:54-80``: the energy equation."""
 

@@ -113,6 +113,20 @@ int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], const pre_out_t *o
                          const float *K_t, const float *K_x, const float *K_y, double gamma,
                          int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream);
 
+/* Reduced MHD (JOREK), Marginal/JOREK_residuals_CP.py:207-243 (twin Joint/JOREK_residuals_CP.py:210-243); ABI v6.
+ * fields = {rho, phi, T}: the views the script's unstack_fields makes ([BS,Nt,Nx,Ny], Nt fastest in the surrogate's
+ * memory).  Rb: the radius grid as a view of the same logical shape that repeats R along the LAST axis (the script
+ * broadcasts its 1-D R tensor that way) - zero strides on the other axes, unit stride on the axis the fields are
+ * contiguous on.  K_*: the dense kernels of D_t, D_R, D_Z, D_RR, D_ZZ (:201-205).
+ *   eq 0 continuity:  a0*D_t(rho) - (a1*R)*X(rho) - (a2*rho)*D_Z(phi) - a3*((D_RR(rho) + (1/R)*D_R(rho)) + D_ZZ(rho)),
+ *                     X(f) = D_R(f)*D_Z(phi) - D_R(phi)*D_Z(f); coef = {a0,a1,a2,a3} = {1,1,2,D}, or the script's
+ *                     norms=True scalars {2*dx*dy, dt, (2*dt*dy)*2, (4*dt)*D} folded in fp32 in its order
+ *   eq 1 temperature: T*D_t(rho) + rho*D_t(T) - (rho*R)*X(T) + (T*R)*X(rho) + ((a0*rho)*T)*D_Z(phi)
+ *                     + a3*((D_RR(T) + (1/R)*D_R(T)) + D_ZZ(T));  coef = {2*gamma, -, -, K} */
+int pre_residual_jorek_f32(int eq, const pre_field_t fields[3], const pre_field_t *Rb, const pre_out_t *out,
+                           const float *K_t, const float *K_R, const float *K_Z, const float *K_RR, const float *K_ZZ,
+                           const float coef[4], int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream);
+
 /* ---- 8f rank 4: 2-D spatial operators with boundary conditions -------------------------------
  * Utils/ConvOps_Spatial.py:83-136 (F.conv2d, 'valid') applied to a field padded by
  * Utils/boundary_conditions.py:81-185 (BoundaryManager.pad_signal), as the Gradient / Laplace /

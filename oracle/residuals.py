@@ -151,6 +151,53 @@ def mhd_gauss(vars, boundary=False):
     return _crop(res, boundary)
 
 
+class OpsJorek:
+    """The five operators of ``Marginal/JOREK_residuals_CP.py:201-205`` with the scales the script's globals hold at
+    that point: alpha = beta = 1 (:192), and ``gamma`` already re-bound to the adiabatic index 5/3 (:199) - the
+    ``scale`` of D_RR and D_ZZ.  ``domain='y'`` carries the reference's kernel (taps along Nt)."""
+
+    def __init__(self, alpha=1, beta=1, lap_scale=None, gamma=5 / 3):
+        lap = torch.tensor(gamma, dtype=torch.float32) if lap_scale is None else lap_scale
+        self.D_t = ConvOperator2D("t", 1, scale=alpha)
+        self.D_R = ConvOperator2D("x", 1, scale=beta)
+        self.D_Z = ConvOperator2D("y", 1, scale=beta)
+        self.D_RR = ConvOperator2D("x", 2, scale=lap)
+        self.D_ZZ = ConvOperator2D("y", 2, scale=lap)
+
+
+def jorek_unstack(vars):
+    """``unstack_fields`` of the script (:84-95): vars [BS,F,Nx,Ny,Nt] -> F views [BS,Nt,Nx,Ny]."""
+    return [vars[:, i].permute(0, 3, 1, 2) for i in range(vars.shape[1])]
+
+
+def jorek_continuity(vars, R, D=3.4, boundary=False, norms=False, dx=None, dy=None, dt=None, ops=None):
+    """Marginal/JOREK_residuals_CP.py:207-221 (twin: Joint/JOREK_residuals_CP.py:210-221).  ``R`` is the 1-D radius
+    grid; the expression broadcasts it along the LAST axis of the [BS,Nt,Nx,Ny] fields."""
+    o = ops or OpsJorek()
+    D_t, D_R, D_Z, D_RR, D_ZZ = o.D_t, o.D_R, o.D_Z, o.D_RR, o.D_ZZ
+    rho, phi, T = jorek_unstack(vars)
+    D = torch.tensor(D, dtype=torch.float32)
+    if norms:
+        res = 2*dx*dy*D_t(rho) - (dt)*R*(D_R(rho)*D_Z(phi) - D_R(phi)*D_Z(rho)) - (2*dt*dy)*2*rho*D_Z(phi) - (4*dt)*D*(D_RR(rho) + (1/R)*D_R(rho) + D_ZZ(rho))
+    else:
+        res = D_t(rho) - R*(D_R(rho)*D_Z(phi) - D_R(phi)*D_Z(rho)) - 2*rho*D_Z(phi) - D*(D_RR(rho) + (1/R)*D_R(rho) + D_ZZ(rho))
+    return _crop(res, boundary)
+
+
+def jorek_temperature(vars, R, K=2.25 * 1e-7, gamma=5 / 3, boundary=False, ops=None):
+    """Marginal/JOREK_residuals_CP.py:224-243."""
+    o = ops or OpsJorek()
+    D_t, D_R, D_Z, D_RR, D_ZZ = o.D_t, o.D_R, o.D_Z, o.D_RR, o.D_ZZ
+    rho, phi, T = jorek_unstack(vars)
+    K = torch.tensor(K, dtype=torch.float32)
+    gamma = torch.tensor(gamma, dtype=torch.float32)
+    res = T*D_t(rho) + rho*D_t(T) - rho*R*(D_R(T)*D_Z(phi) - D_R(phi)*D_Z(T)) + \
+        T*R*(D_R(rho)*D_Z(phi) - D_R(phi)*D_Z(rho)) + \
+        2*gamma*rho*T*D_Z(phi) + \
+        K * (D_RR(T) + (1/R)*D_R(T) + D_ZZ(T))
+    return _crop(res, boundary)
+
+
 def periodic_bc_residual(u, dx, wall="right"):
     """Marginal/NS_Residuals_CP.py:468-478."""
     if wall == "top":

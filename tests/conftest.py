@@ -35,4 +35,4 @@ def rel_err(a, b):
 
 @pytest.fixture(scope="session")
 def golden():
-    return {n: load_golden(n + ".npz") for n in ("kernels", "apply", "residuals", "conformal")}
+    return {n: load_golden(n + ".npz") for n in ("kernels", "apply", "residuals", "conformal", "jorek")}

@@ -15,6 +15,9 @@ What is executed from the reference (nothing of it is copied into this repo):
     imported (top-level ``from Neural_PDE...``), so the defs are located with ``ast`` at
     generation time, compiled from the reference file itself and executed against the
     reference's own ConvOperator instances -> residuals.npz
+  * the reduced-MHD residuals of ``Marginal/JOREK_residuals_CP.py`` (:188-247): the operator constructions, the
+    coefficient tensors and the ``residual_continuity`` / ``residual_temperature`` defs, compiled from the file and
+    executed on seeded fields and a seeded R grid -> jorek.npz
   * ``filter_sims_joint`` (Joint/Burgers_Residuals_CP.py:298-300) and ``filter_sims_within_bounds``
     (Active_Learning/Advection_AL_Marginal.py:169-198) - defined inside the reference tree -
     compiled from it the same way -> filters.npz
@@ -194,6 +197,43 @@ def gen_residuals():
     np.savez_compressed(os.path.join(HERE, "residuals.npz"), **out)
 
 
+def gen_jorek():
+    """Reduced-MHD (JOREK) residuals, ``Marginal/JOREK_residuals_CP.py:188-247`` (twin: ``Joint/JOREK_residuals_CP.py``).
+    Executed from the reference file: the operator constructions ``D_t .. D_ZZ = ConvOperator(...)`` (:201-205, with
+    the globals they see at that point of the script: alpha = beta = 1 (:192) and gamma ALREADY re-bound to the
+    adiabatic index tensor 5/3 (:199), which is therefore the ``scale`` of D_RR / D_ZZ), the coefficient tensors D, K,
+    gamma (:196-199) and the defs ``unstack_fields``, ``residual_continuity``, ``residual_temperature`` - on seeded
+    fields and a seeded R grid.  R is a 1-D tensor (``x_grid``) that the expressions broadcast against [BS,Nt,Nx,Ny]
+    fields, i.e. along the LAST axis: the fixture grid is square like the reference's data."""
+    rel = "Marginal/JOREK_residuals_CP.py"
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    # vars as the script holds them: [BS, F, Nx, Ny, Nt] (the surrogate's layout); unstack_fields permutes every field
+    # to [BS, Nt, Nx, Ny] (:84-95), so the operators see Nt-fastest views
+    v3 = torch.rand(4, 3, 12, 12, 6, generator=g) + 0.5                     # rho, phi, T in U(0.5, 1.5)
+    R = torch.linspace(1.2, 2.3, 12) + 0.01 * torch.rand(12, generator=g)   # major radius grid, > 0
+    dx = torch.tensor(0.1, dtype=torch.float32)
+    dt = torch.tensor(0.02, dtype=torch.float32)
+    env = dict(ConvOperator=Ref2D, torch=torch, np=np, alpha=1, beta=1)
+    for name in ("D", "mu", "K", "gamma"):                                  # :196-199 (gamma: the LAST top-level binding)
+        path = os.path.join(REF, rel)
+        tree = ast.parse(open(path).read(), path)
+        val = [n for n in tree.body if isinstance(n, ast.Assign) and ast.unparse(n.targets[0]) == name][-1].value
+        env[name] = eval(compile(ast.Expression(val), path, "eval"), env)
+    for name in ("D_t", "D_R", "D_Z", "D_RR", "D_ZZ"):                      # :201-205
+        env[name] = eval(ref_assign_value(rel, name), env)
+        out[f"kernel|{name}"] = env[name].kernel.numpy()
+    env.update(R=R, dx=dx, dy=dx, dt=dt, field=["rho", "phi", "T"])
+    exec(ref_defs(rel, ["unstack_fields", "residual_continuity", "residual_temperature"]), env)
+    out["vars3"], out["R"] = v3.numpy(), R.numpy()
+    out["coef"] = np.array([float(dx), float(dx), float(dt), float(env["D"]), float(env["K"]), float(env["gamma"])], np.float64)
+    for b in (False, True):
+        out[f"continuity|{int(b)}"] = env["residual_continuity"](v3, boundary=b).contiguous().numpy()
+        out[f"continuity_norms|{int(b)}"] = env["residual_continuity"](v3, boundary=b, norms=True).contiguous().numpy()
+        out[f"temperature|{int(b)}"] = env["residual_temperature"](v3, boundary=b).contiguous().numpy()
+    np.savez_compressed(os.path.join(HERE, "jorek.npz"), **out)
+
+
 def gen_conformal():
     """BUILD-DEFINED vectors (numpy): not reference-derived."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
@@ -364,6 +404,9 @@ def gen_spectral():
 
 
 if __name__ == "__main__":
+    if "--jorek" in sys.argv:
+        gen_jorek()
+        sys.exit(0)
     if "spectral" in sys.argv[1:]:
         gen_spectral()
         sys.exit(0)
@@ -382,6 +425,7 @@ if __name__ == "__main__":
     ks = gen_kernels()
     gen_apply(ks)
     gen_residuals()
+    gen_jorek()
     gen_conformal()
     gen_conformal_ref()
     gen_filters()

@@ -395,6 +395,79 @@ def test_residuals_match_reference_golden(gpu, golden, fused):
             assert rel_err(got.cpu().numpy(), ref) <= RES_TOL, (name, b, fused)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_jorek_residuals_match_reference_golden(gpu, golden, fused, monkeypatch):
+    """Reduced-MHD residuals (Marginal/JOREK_residuals_CP.py:207-243): fused single pass and operator-by-operator
+    composition against vectors executed from the script's own operator constructions and defs
+    (tests/golden/jorek.npz) - continuity, continuity with norms=True, temperature, cropped and uncropped; the five
+    operator kernels bit for bit.  The fused route must really be the fused kernel (its entry point is counted)."""
+    from cp_pre_amd import _lib
+    from cp_pre_amd import residuals as R
+    g = golden["jorek"]
+    v3 = torch.from_numpy(g["vars3"]).to(gpu)                              # [BS, F, Nx, Ny, Nt]
+    dx, dy, dt, D, K, gamma = g["coef"].tolist()
+    jo = R.JOREK(torch.from_numpy(g["R"]), D=D, K=K, gamma=gamma, dx=dx, dy=dy, dt=dt, fused=fused)
+    for name in ("D_t", "D_R", "D_Z", "D_RR", "D_ZZ"):
+        assert np.array_equal(getattr(jo, name).kernel.cpu().numpy(), g[f"kernel|{name}"]), name
+    calls = []
+    real = _lib.load().pre_residual_jorek_f32
+    monkeypatch.setattr(_lib.load(), "pre_residual_jorek_f32", lambda *a: (calls.append(1), real(*a))[1])
+    for b in (0, 1):
+        cases = {"continuity": jo.residual_continuity(v3, boundary=bool(b)),
+                 "continuity_norms": jo.residual_continuity(v3, boundary=bool(b), norms=True),
+                 "temperature": jo.residual_temperature(v3, boundary=bool(b))}
+        for name, got in cases.items():
+            ref = g[f"{name}|{b}"]
+            assert got.is_cuda and tuple(got.shape) == ref.shape, (name, b)
+            assert rel_err(got.cpu().numpy(), ref) <= RES_TOL, (name, b, fused, rel_err(got.cpu().numpy(), ref))
+    assert len(calls) == (6 if fused else 0)
+    a = jo.residual_temperature(v3, boundary=True, absolute=True)
+    assert rel_err(a.cpu().numpy(), np.abs(g["temperature|1"])) <= RES_TOL and bool((a >= 0).all())
+
+
+def test_jorek_streaming_sizes_and_layouts_vs_oracle(gpu):
+    """The fused reduced-MHD kernels at sizes with several tiles: the surrogate's Nt-fastest layout (the script's,
+    through unstack_fields) with a short and a long Nt, a copy in the reference layout (Ny fastest), user-modified
+    operator kernels (general-star instantiation), y_axis_fix against its own composition; a wrong-length R raises."""
+    from cp_pre_amd import residuals as R
+    from oracle import residuals as orr
+    g = torch.Generator().manual_seed(23)
+    for (B, N, Nt) in ((3, 64, 10), (2, 128, 24), (2, 40, 100)):
+        v3 = torch.rand(B, 3, N, N, Nt, generator=g) + 0.5
+        Rg = torch.linspace(1.0, 2.0, N) + 0.01 * torch.rand(N, generator=g)
+        jo = R.JOREK(Rg, dx=0.1, dy=0.1, dt=0.02)
+        d3 = v3.to(gpu)
+        t = lambda x: torch.tensor(x, dtype=torch.float32)
+        pairs = {
+            "continuity": (jo.residual_continuity(d3, True), orr.jorek_continuity(v3, Rg, 3.4, boundary=True)),
+            "continuity_norms": (jo.residual_continuity(d3, True, norms=True),
+                                 orr.jorek_continuity(v3, Rg, 3.4, boundary=True, norms=True, dx=t(0.1), dy=t(0.1), dt=t(0.02))),
+            "temperature": (jo.residual_temperature(d3, True), orr.jorek_temperature(v3, Rg, boundary=True)),
+        }
+        for name, (got, ref) in pairs.items():
+            assert tuple(got.shape) == tuple(ref.shape) == (B, Nt, N, N)
+            assert rel_err(got.cpu().numpy(), ref.numpy()) <= RES_TOL, (name, B, N, Nt)
+        # the same fields laid out Ny-fastest (a [BS,F,Nt,Nx,Ny] tensor permuted into the script's axis order)
+        ref_layout = d3.permute(0, 1, 4, 2, 3).contiguous().permute(0, 1, 3, 4, 2)
+        assert ref_layout.stride(3) == 1 and torch.equal(ref_layout, d3)
+        got = jo.residual_temperature(ref_layout, True)
+        assert rel_err(got.cpu().numpy(), pairs["temperature"][1].numpy()) <= RES_TOL, ("ny-fastest", N, Nt)
+    # user-modified operators (taps on all three axes: the general-star instantiation) == their composition
+    jo2, jo2c = R.JOREK(Rg), R.JOREK(Rg, fused=False)
+    for o, oc_ in ((jo2.D_Z, jo2c.D_Z), (jo2.D_RR, jo2c.D_RR)):
+        k = o.kernel.clone()
+        k[1, 1, 0], k[1, 1, 2], k[0, 1, 1] = 0.3, -0.7, 0.2
+        o.kernel = k
+        oc_.kernel = k.clone()
+    assert rel_err(jo2.residual_temperature(d3, True).cpu().numpy(), jo2c.residual_temperature(d3, True).cpu().numpy()) <= RES_TOL
+    fix, fixc = R.JOREK(Rg, y_axis_fix=True), R.JOREK(Rg, y_axis_fix=True, fused=False)
+    a, b = fix.residual_continuity(d3, True), fixc.residual_continuity(d3, True)
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= RES_TOL
+    assert rel_err(a.cpu().numpy(), jo.residual_continuity(d3, True).cpu().numpy()) > 1e-3      # not the reference's D_Z
+    with pytest.raises(RuntimeError):
+        R.JOREK(Rg[:-1]).residual_continuity(d3, True)
+
+
 def test_fused_residuals_streaming_sizes_vs_oracle(gpu):
     """Same equations at sizes that take the fused streaming kernels (Y % 4 == 0, several tiles)."""
     from cp_pre_amd import residuals as R

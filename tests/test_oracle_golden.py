@@ -110,6 +110,26 @@ def test_residuals_match_reference(golden):
         assert rel_err(got, g[f"ns_periodic_bc|{wall}"]) <= TOL
 
 
+def test_jorek_residuals_match_reference(golden):
+    """Reduced-MHD residuals (Marginal/JOREK_residuals_CP.py:207-243) against the vectors executed from the script's own
+    operator constructions and defs (tests/golden/make_golden.py::gen_jorek); the operators' kernels bit for bit."""
+    g = golden["jorek"]
+    v3, R = torch.from_numpy(g["vars3"]), torch.from_numpy(g["R"])
+    dx, dy, dt, D, K, gamma = g["coef"].tolist()
+    t = lambda x: torch.tensor(x, dtype=torch.float32)
+    o = orr.OpsJorek()
+    for name in ("D_t", "D_R", "D_Z", "D_RR", "D_ZZ"):
+        assert np.array_equal(getattr(o, name).kernel.numpy(), g[f"kernel|{name}"]), name
+    for b in (0, 1):
+        cases = {"continuity": orr.jorek_continuity(v3, R, D, boundary=bool(b)),
+                 "continuity_norms": orr.jorek_continuity(v3, R, D, boundary=bool(b), norms=True, dx=t(dx), dy=t(dy), dt=t(dt)),
+                 "temperature": orr.jorek_temperature(v3, R, K, gamma, boundary=bool(b))}
+        for name, got in cases.items():
+            ref = g[f"{name}|{b}"]
+            assert tuple(got.shape) == ref.shape, (name, b)
+            assert rel_err(got.numpy(), ref) <= TOL, (name, b, rel_err(got.numpy(), ref))
+
+
 def test_conformal_build_defined_vectors(golden):
     """Oracle vs committed numpy vectors (BUILD-DEFINED: parity with the reference is unpinned)."""
     g = golden["conformal"]
