@@ -2,7 +2,8 @@
  * Shows what a maintainer binding the library from another language sees, and checks each call
  * against plain C loops written here (the reference's arithmetic: zero-padded cross-correlation,
  * Utils/ConvOps_2d.py:149; the NS momentum expression, Marginal/NS_Residuals_CP.py:231-240; an order
- * statistic per cell).  Built and run by tests/test_gpu_parity.py::test_c_abi_client.  Exit code 0 = all ok.
+ * statistic per cell; the streaming joint chain; MHD induction, JOREK continuity, Burgers and the 1-D stencil).
+ * Built and run by tests/test_gpu_parity.py::test_c_abi_client.  Exit code 0 = all ok.
  *
  *   hipcc -x c tests/c_abi/abi_check.c -Iinclude -Lcp_pre_amd -lcp_pre_hip -Wl,-rpath,$PWD/cp_pre_amd -o abi_check
  */
@@ -144,6 +145,148 @@ int main(void)
         EXPECT(pre_kth_axis0_f32(dout, n, M, bad, 2, dq, st) == PRE_E_RANGE, "rank >= n -> PRE_E_RANGE");
         EXPECT(pre_kth_axis0_f32(NULL, n, M, ks, 3, dq, st) == PRE_E_NULL, "null pointer -> PRE_E_NULL");
         CHECK_HIP(hipFree(dq));
+    }
+
+    /* ---- a12/a13/a11, the streaming joint chain (Joint/Burgers_Residuals_CP.py:272-285): segment maxima + moments in
+     * one read, modulation from the moments, segment minima, branch-and-bound score with its flagged full pass, scalar
+     * q-hat - against the plain recipe in C (std over samples, max |r|/mod over the cropped cells, qsort) */
+    {
+        enum { n = B, M = T * X * Y, NS = (X * Y + 63) / 64, TC = (T + 15) / 16 };
+        double *dsum, *dsq;
+        uint32_t *dsegmax, *dflags;
+        unsigned long long *dstats;
+        float *dmod, *dsegmin, *dsc, *dq;
+        static float hmod[M], hsc[n], hq[2], wmod[M], wsc[n];
+        unsigned long long hstats[3];
+        CHECK_HIP(hipMalloc((void **)&dsum, M * sizeof(double))); CHECK_HIP(hipMalloc((void **)&dsq, M * sizeof(double)));
+        CHECK_HIP(hipMalloc((void **)&dsegmax, n * TC * NS * 4)); CHECK_HIP(hipMalloc((void **)&dflags, n * 4));
+        CHECK_HIP(hipMalloc((void **)&dstats, 24)); CHECK_HIP(hipMalloc((void **)&dmod, M * 4));
+        CHECK_HIP(hipMalloc((void **)&dsegmin, TC * NS * 4)); CHECK_HIP(hipMalloc((void **)&dsc, n * 4));
+        CHECK_HIP(hipMalloc((void **)&dq, 8));
+        CHECK_HIP(hipMemsetAsync(dsum, 0, M * sizeof(double), st)); CHECK_HIP(hipMemsetAsync(dsq, 0, M * sizeof(double), st));
+        CHECK_HIP(hipMemsetAsync(dstats, 0, 24, st)); CHECK_HIP(hipMemsetAsync(dsc, 0, n * 4, st));
+        int rc = pre_moments_segmax_f64(du, M, n, T, X, Y, 1, 1, dsum, dsq, dsegmax, st);
+        int rc2 = pre_std_from_moments_f32(dsum, dsq, n, M, 0.f, dmod, st);
+        int rc3 = pre_segmin_mod_f32(dmod, T, X, Y, 1, 1, dsegmin, st);
+        int rc4 = pre_joint_score_pruned_f32(du, M, dmod, dsegmax, dsegmin, n, T, X, Y, 1, 1, dsc, dflags, dstats, st);
+        int rc5 = pre_joint_score_flagged_f32(du, NULL, dmod, n, T, X, Y, 0, 1, 1, dflags, dsc, st);
+        int64_t kq[2] = {0, n - 1};
+        int rc6 = pre_kth_f32(dsc, n, kq, 2, dq, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(hmod, dmod, sizeof hmod, hipMemcpyDeviceToHost)); CHECK_HIP(hipMemcpy(hsc, dsc, sizeof hsc, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(hq, dq, sizeof hq, hipMemcpyDeviceToHost)); CHECK_HIP(hipMemcpy(hstats, dstats, 24, hipMemcpyDeviceToHost));
+        for (int c = 0; c < M; ++c) {
+            double s1 = 0, s2 = 0;
+            for (int i = 0; i < n; ++i) { s1 += hu[i * M + c]; s2 += (double)hu[i * M + c] * hu[i * M + c]; }
+            const double mean = s1 / n, var = s2 / n - mean * mean;
+            wmod[c] = (float)sqrt(var > 0 ? var : 0);
+        }
+        for (int i = 0; i < n; ++i) {
+            float m = 0.f;
+            for (int t = 0; t < T; ++t) for (int x = 1; x < X - 1; ++x) for (int y = 1; y < Y - 1; ++y) {
+                const int c = (t * X + x) * Y + y;
+                const float q = fabsf(hu[i * M + c]) / hmod[c];               /* the device's own modulation: same quotients */
+                if (q > m) m = q;
+            }
+            wsc[i] = m;
+        }
+        int same = 1;
+        for (int i = 0; i < n; ++i) same &= (hsc[i] == wsc[i]);
+        float srt[n];
+        memcpy(srt, wsc, sizeof srt);
+        qsort(srt, n, sizeof(float), cmp_float);
+        EXPECT(rc == PRE_OK && rc2 == PRE_OK && rel_err(hmod, wmod, M) <= 1e-6, "pre_moments_segmax_f64 + pre_std_from_moments_f32 vs C std (<= 1e-6)");
+        EXPECT(rc3 == PRE_OK && rc4 == PRE_OK && rc5 == PRE_OK && same, "pre_segmin_mod_f32 + pre_joint_score_pruned_f32 + pre_joint_score_flagged_f32: scores bit-exact vs C max |r|/mod");
+        EXPECT(hstats[1] == (unsigned long long)n * TC * NS && hstats[0] <= hstats[1], "pruned score statistics: segments read <= segments");
+        EXPECT(rc6 == PRE_OK && hq[0] == srt[0] && hq[1] == srt[n - 1], "pre_kth_f32: scalar order statistics of the scores");
+        /* the un-pruned route through the plain entry points gives the same scores */
+        CHECK_HIP(hipMemsetAsync(dsc, 0, n * 4, st));
+        CHECK_HIP(hipMemsetAsync(dsum, 0, M * sizeof(double), st)); CHECK_HIP(hipMemsetAsync(dsq, 0, M * sizeof(double), st));
+        int rc7 = pre_moments_axis0_f64(du, NULL, n, M, M, dsum, dsq, st);
+        int rc8 = pre_joint_score_f32(du, NULL, dmod, n, T, X, Y, 0, 1, 1, dsc, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(hsc, dsc, sizeof hsc, hipMemcpyDeviceToHost));
+        same = 1;
+        for (int i = 0; i < n; ++i) same &= (hsc[i] == wsc[i]);
+        EXPECT(rc7 == PRE_OK && rc8 == PRE_OK && same, "pre_moments_axis0_f64 + pre_joint_score_f32: the same scores");
+        hipFree(dsum); hipFree(dsq); hipFree(dsegmax); hipFree(dflags); hipFree(dstats); hipFree(dmod); hipFree(dsegmin); hipFree(dsc); hipFree(dq);
+    }
+
+    /* ---- a9: MHD induction (Marginal/MHD_Residuals_CP.py:259-268), fields {rho,u,v,p,Bx,By} = {u,u,v,p,p,v} here */
+    {
+        const pre_field_t f6[6] = {fu, fu, fv, fp, fp, fv};
+        int rc = pre_residual_mhd_f32(3, f6, &fo, Kt, Kx, Ky, 5.0 / 3.0, B, T, X, Y, 0, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        const float *u = hu, *v = hv, *bx = hp, *by = hv;
+        xcorr27(bx, Kt, tmp[0]); xcorr27(u, Ky, tmp[1]); xcorr27(v, Ky, tmp[2]); xcorr27(bx, Ky, tmp[3]); xcorr27(by, Ky, tmp[4]);
+        xcorr27(by, Kt, tmp[5]); xcorr27(u, Kx, tmp[6]); xcorr27(v, Kx, tmp[7]); xcorr27(bx, Kx, tmp[8]); xcorr27(by, Kx, tmp[9]);
+        for (int i = 0; i < N; ++i) {
+            const float rx = tmp[0][i] - by[i] * tmp[1][i] + bx[i] * tmp[2][i] - v[i] * tmp[3][i] + u[i] * tmp[4][i];
+            const float ry = tmp[5][i] + by[i] * tmp[6][i] - bx[i] * tmp[7][i] - v[i] * tmp[8][i] + u[i] * tmp[9][i];
+            want[i] = rx + ry;
+        }
+        EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-5, "pre_residual_mhd_f32 (induction) vs operator-by-operator C loops (<= 1e-5)");
+    }
+
+    /* ---- a9: reduced MHD / JOREK continuity (Marginal/JOREK_residuals_CP.py:207-221), R broadcast along the last axis */
+    {
+        static float hR[Y];
+        float *dR;
+        float Krr[27] = {0}, Kzz[27] = {0};
+        const float D = 3.4f, g = 5.0f / 3.0f;
+        for (int y = 0; y < Y; ++y) hR[y] = 1.2f + 0.01f * y;
+        Krr[(1 * 3 + 0) * 3 + 1] = Krr[(1 * 3 + 2) * 3 + 1] = g; Krr[(1 * 3 + 1) * 3 + 1] = -2.f * g;       /* 'x', 2, scale gamma */
+        Kzz[(0 * 3 + 1) * 3 + 1] = Kzz[(2 * 3 + 1) * 3 + 1] = g; Kzz[(1 * 3 + 1) * 3 + 1] = -2.f * g;       /* 'y', 2: along Nt   */
+        CHECK_HIP(hipMalloc((void **)&dR, sizeof hR));
+        CHECK_HIP(hipMemcpy(dR, hR, sizeof hR, hipMemcpyHostToDevice));
+        const pre_field_t f3[3] = {fu, fv, fp}, fR = {dR, 0, 0, 0, 1};
+        const float coef[4] = {1.f, 1.f, 2.f, D};
+        int rc = pre_residual_jorek_f32(0, f3, &fR, &fo, Kt, Kx, Ky, Krr, Kzz, coef, B, T, X, Y, 0, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        const float *rho = hu, *phi = hv;
+        xcorr27(rho, Kt, tmp[0]); xcorr27(rho, Kx, tmp[1]); xcorr27(phi, Ky, tmp[2]); xcorr27(phi, Kx, tmp[3]); xcorr27(rho, Ky, tmp[4]);
+        xcorr27(rho, Krr, tmp[5]); xcorr27(rho, Kzz, tmp[6]);
+        for (int i = 0; i < N; ++i) {
+            const float R = hR[i % Y];
+            want[i] = tmp[0][i] - R * (tmp[1][i] * tmp[2][i] - tmp[3][i] * tmp[4][i]) - 2.f * rho[i] * tmp[2][i]
+                      - D * (tmp[5][i] + (1.f / R) * tmp[1][i] + tmp[6][i]);
+        }
+        EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-5, "pre_residual_jorek_f32 (continuity) vs operator-by-operator C loops (<= 1e-5)");
+        hipFree(dR);
+    }
+
+    /* ---- a5/a9 1-D: pre_stencil2d_f32 and the Burgers residual (Joint/Burgers_Residuals_CP.py:182-187) on [B*T, X, Y]
+     * read as a 1-D problem [BS, Nt, Nx] = [B*T, X, Y]; 3x3 kernels, axes (Nt, Nx) */
+    {
+        enum { BS = B * T };
+        const int64_t st3[3] = {(int64_t)X * Y, Y, 1};
+        float k_t[9] = {0, -1, 0, 0, 0, 0, 0, 1, 0}, k_x[9] = {0, 0, 0, -1, 0, 1, 0, 0, 0}, k_xx[9] = {0, 0, 0, 1, -2, 1, 0, 0, 0};
+        float w[3] = {1.f, -2.f, 1.f};
+        int32_t off[6] = {0, -1, 0, 0, 0, 1};
+        int rc = pre_stencil2d_f32(du, st3, dout, st3, w, off, 3, BS, X, Y, 0, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        /* D_xx(u)[b,t,x] = u[x-1] - 2u[x] + u[x+1] along the last axis, zero padded */
+        for (int r = 0; r < BS * X; ++r) for (int y = 0; y < Y; ++y) {
+            const float *row = hu + r * Y;
+            want[r * Y + y] = (y > 0 ? row[y - 1] : 0.f) - 2.f * row[y] + (y < Y - 1 ? row[y + 1] : 0.f);
+        }
+        EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-5, "pre_stencil2d_f32: D_xx tap list vs C loops (<= 1e-5)");
+        const float dx = 2.f / 64, dt = 1.25f / 10, nu = 0.002f, c3 = 2.f * dt / dx;
+        rc = pre_residual_burgers_f32(du, st3, dout, st3, k_t, k_x, k_xx, dx, dt, nu, c3, BS, X, Y, 0, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        for (int b = 0; b < BS; ++b) for (int t = 0; t < X; ++t) for (int x = 0; x < Y; ++x) {
+            const float *u = hu + (size_t)b * X * Y;
+            const float c = u[t * Y + x];
+            const float Dt = (t < X - 1 ? u[(t + 1) * Y + x] : 0.f) - (t > 0 ? u[(t - 1) * Y + x] : 0.f);
+            const float Dx = (x < Y - 1 ? u[t * Y + x + 1] : 0.f) - (x > 0 ? u[t * Y + x - 1] : 0.f);
+            const float Dxx = (x > 0 ? u[t * Y + x - 1] : 0.f) - 2.f * c + (x < Y - 1 ? u[t * Y + x + 1] : 0.f);
+            want[((size_t)b * X + t) * Y + x] = dx * Dt + dt * c * Dx - nu * Dxx * c3;
+        }
+        EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-5, "pre_residual_burgers_f32 vs C loops (<= 1e-5)");
     }
 
     CHECK_HIP(hipStreamDestroy(st));

@@ -21,8 +21,9 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
     free = torch.cuda.mem_get_info()[0]
-    if free < 250e9:
-        pytest.skip(f"needs ~250 GB of free HBM, {free / 1e9:.0f} GB available")
+    # three BASELINE configurations ride on these tests: a box that cannot hold them is a FAILED run, not a skipped one
+    # (under `-m gpu` a skip would silently un-exercise C3, C4 and C5)
+    assert free >= 250e9, f"the full-size tests need ~250 GB of free HBM, {free / 1e9:.0f} GB available"
     return torch.device("cuda:0")
 
 
