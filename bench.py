@@ -516,6 +516,13 @@ def main():
                                    f"{args.mode} CP, 10 alpha levels; streamed as {n_slabs} t-slabs of {slabs} interior "
                                    f"planes (+2 halo planes each)",
                        "mode": args.mode, "batch_per_rank": B, "slab": args.slab, **par,
+                       # the per-rank slab plan: resident bytes, and what the t-slab halo re-reads cost (strong scaling
+                       # shrinks the per-rank batch, which affords thicker slabs - up to the whole T axis, no halo)
+                       "slab_plan": {"slabs": slabs, "resident_gb": round(resident_bytes(B, args.nt, args.slab, X, Y) / 1e9, 1),
+                                     "input_planes_read_per_plane_computed": round(sum(sl + 2 for sl in slabs) / sum(slabs), 3)},
+                       "scaling_note": ("weak: every rank streams its own 4096-sample batch" if args.scaling == "weak" else
+                                        "strong: one calibration set split over the ranks (north_star's '>= 6x 1->8 GPUs' "
+                                        "speaks of this curve)"),
                        # `value` is measured with the fields resident in HBM (contract); if the 3 fields came from host
                        # memory instead, PCIe Gen5 x16 (63 GB/s spec) would bound the job at 63e9 / 12 B per cell
                        "inputs": "resident in HBM", "host_fed_bound_cells_per_s": 63e9 / 12.0,

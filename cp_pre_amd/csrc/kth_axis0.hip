@@ -66,6 +66,9 @@ namespace {
 #ifndef KA_U_B
 #define KA_U_B 16
 #endif
+#ifndef KA_KEEP
+#define KA_KEEP 80
+#endif
 constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16;
 constexpr int KA_LATE_WORDS = KA_MAXK * 64 * 32;          // later sweeps (and up to 31-entry collect lists): 80 KiB
 constexpr int KA_FLAGS_AT = 1008;                         // per-wave flags (words 640..1023 are never used otherwise)
@@ -164,15 +167,16 @@ __device__ __forceinline__ float ka_row(const float *p, int loff)
 // by scalar adds, and every load uses the SAME per-lane offset register (per-lane 64-bit addresses cost 2 registers
 // per load in flight and spilled).  (Issuing the next batch before processing the current one was tried: no gain,
 // the sweeps are bound by VALU issue, not by loads in flight.)
+// (`first`: start at this thread's row number `first`, i.e. skip rows wave, wave+16, ... wave+16(first-1))
 template <int U, class F>
-__device__ __forceinline__ void ka_sweep(const float *__restrict__ col, bool cok, int n, long long M, int wave, F &&f)
+__device__ __forceinline__ void ka_sweep(const float *__restrict__ col, bool cok, int n, long long M, int wave, F &&f, int first = 0)
 {
     if (!cok) return;
     constexpr int STEP = U * KA_WAVES, SPAN = (U - 1) * KA_WAVES;
     const int loff = (int)(threadIdx.x & 63u) * 4;
     const long long stride = (long long)KA_WAVES * M;
-    const float *p = col + (long long)wave * M;
-    int i = wave;
+    int i = wave + first * KA_WAVES;
+    const float *p = col + (long long)i * M;
     for (; i + SPAN < n; i += STEP) {
         float v[U];
 #pragma unroll
@@ -379,10 +383,30 @@ __device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok,
     __syncthreads();
     const unsigned int inc = C::inc(lane);
     unsigned long long nan = 0ull;
-    ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+    // KEEP: where one workgroup has the CU to itself (1024 buckets: n > 2048, 256 rows per thread at n = 4096) there are
+    // ~60 registers to spare: the first KEEP rows of every thread stay in them after this sweep, and the collect sweep
+    // re-reads only the others - 2.06 reads of the scores become 1.88 at n = 4096 (the kernel is HBM-bound there)
+    constexpr int KEEP = (Cfg::BYTEMAP && !WIDE) ? KA_KEEP : 0;
+    static_assert(KEEP * KA_WAVES <= 2048 || KEEP == 0, "the kept rows must exist for every n the instantiation serves");
+    float kept[KEEP ? KEEP : 1];
+    auto count1 = [&](float v) __attribute__((always_inline)) {
         nan |= __ballot(v != v);
         atomicAdd(&hist[C::word(ka_frow<NB1>(v, sf, vlo), lane)], inc);
-    });
+    };
+    if constexpr (KEEP > 0) {
+        if (cok) {
+            const int loff = lane * 4;
+            const float *p = col + (long long)wave * M;
+#pragma unroll
+            for (int u0 = 0; u0 < KEEP; u0 += U) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { kept[u0 + u] = ka_row(p, loff); p += (long long)KA_WAVES * M; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) count1(kept[u0 + u]);
+            }
+        }
+    }
+    ka_sweep<U>(col, cok, n, M, wave, count1, KEEP);
     __syncthreads();
     unsigned int myr = k0, count;
     int digit;
@@ -411,13 +435,20 @@ __device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok,
         unsigned char *map = reinterpret_cast<unsigned char *>(hist + Cfg::BM_AT);
         if (state) map[myrow * 64 + lane] = (unsigned char)(myslot + 1);
         __syncthreads();
-        ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+        auto collect = [&](float v) __attribute__((always_inline)) {
             const int m = map[ka_frow<NB1>(v, sf, vlo) * 64 + lane];
             if (m) {
                 const unsigned int pos = atomicAdd(&hist[ka_list<LS>(m - 1, CAP, lane)], 1u);
                 if (pos < (unsigned)CAP) hist[ka_list<LS>(m - 1, (int)pos, lane)] = f2key(v);  // (always: the histogram counted them)
             }
-        });
+        };
+        if constexpr (KEEP > 0) {
+            if (cok) {
+#pragma unroll
+                for (int u = 0; u < KEEP; ++u) collect(kept[u]);
+            }
+        }
+        ka_sweep<U>(col, cok, n, M, wave, collect, KEEP);
     } else {
         unsigned int *myword = &hist[Cfg::BM_AT + (myrow >> 4) * 64 + lane];
         if (state) atomicOr(myword, 1u << (myrow & 15));
