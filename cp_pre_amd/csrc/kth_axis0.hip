@@ -69,7 +69,7 @@ namespace {
 #ifndef KA_KEEP
 #define KA_KEEP 80
 #endif
-constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16;
+constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16, KA_MAPROW = 68;
 constexpr int KA_LATE_WORDS = KA_MAXK * 64 * 32;          // later sweeps (and up to 31-entry collect lists): 80 KiB
 constexpr int KA_FLAGS_AT = 1008;                         // per-wave flags (words 640..1023 are never used otherwise)
 struct KAList { int nk; int k[KA_MAXK]; int o[KA_MAXK]; };    // ranks (ascending) and the output row of each
@@ -97,7 +97,9 @@ struct KACfg {
     //     less per element (measured at n = 4096: 3.60 vs 3.77 ms) at the price of 2-way bank conflicts inside a quad
     //     of lanes, which nothing waits for.
     static constexpr bool BYTEMAP = WG_PER_CU == 1;
-    static constexpr int BM_WORDS = BYTEMAP ? (NB1 + 1) * 16 : ((NB1 + 1 + 15) / 16) * 64;
+    // (byte map rows are KA_MAPROW = 68 bytes apart, not 64: with 16-word rows the 32 lanes an LDS cycle serves fall on
+    // 16 of the 32 banks whatever rows they look up - measured 34 % of the LDS cycles lost to conflicts; 17 words spread them)
+    static constexpr int BM_WORDS = BYTEMAP ? (NB1 + 1) * (KA_MAPROW / 4) : ((NB1 + 1 + 15) / 16) * 64;
     static constexpr int LS = WG_PER_CU == 2 ? 28 : 32, CAP = LS - 1;
     static constexpr int BM_AT = KA_MAXK * LS * 64;
     static constexpr int COLLECT_WORDS = BM_AT + BM_WORDS;
@@ -433,10 +435,10 @@ __device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok,
     const int myrow = digit + 1;
     if constexpr (Cfg::BYTEMAP) {
         unsigned char *map = reinterpret_cast<unsigned char *>(hist + Cfg::BM_AT);
-        if (state) map[myrow * 64 + lane] = (unsigned char)(myslot + 1);
+        if (state) map[myrow * KA_MAPROW + lane] = (unsigned char)(myslot + 1);
         __syncthreads();
         auto collect = [&](float v) __attribute__((always_inline)) {
-            const int m = map[ka_frow<NB1>(v, sf, vlo) * 64 + lane];
+            const int m = map[ka_frow<NB1>(v, sf, vlo) * KA_MAPROW + lane];
             if (m) {
                 const unsigned int pos = atomicAdd(&hist[ka_list<LS>(m - 1, CAP, lane)], 1u);
                 if (pos < (unsigned)CAP) hist[ka_list<LS>(m - 1, (int)pos, lane)] = f2key(v);  // (always: the histogram counted them)
@@ -695,7 +697,7 @@ struct KTCfg {
     static constexpr int FIRST_WORDS = (NB1 + 1) * 32 + KA_WAVES * 64;       // first-digit histogram + group sums
     static constexpr int LIST_WORDS = KA_MAXK * LS * 64;                     // (aliases the histogram: filled after the narrowing)
     static constexpr int WORDS = FIRST_WORDS > LIST_WORDS ? FIRST_WORDS : LIST_WORDS;
-    static constexpr int MAP_WORDS = (NB1 + 1) * 16;                         // a byte per (row, cell): list + 1, 0 = not wanted
+    static constexpr int MAP_WORDS = (NB1 + 1) * (KA_MAPROW / 4);            // a byte per (row, cell): list + 1, 0 = not wanted
     // side arrays that are NOT aliased: window (min key, max key, NaN flag per cell), published rows, list fill
     // counters, per-wave flags
     static constexpr int WIN_AT = 0, PUB_AT = 192, CNT_AT = PUB_AT + KA_MAXK * 64, FLG_AT = CNT_AT + KA_MAXK * 64,
@@ -805,7 +807,6 @@ template <int LOG_NB1, int R, int WGS>
 __global__ void __launch_bounds__(1024, 4 * WGS)
 kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntiles, const KAList kl, float *__restrict__ out)
 {
-    constexpr bool SAVE = false;
     using Cfg = KTCfg<LOG_NB1, WGS>;
     using C = Ctr<false>;
     constexpr int NB1 = Cfg::NB1, LS = Cfg::LS, CAP = Cfg::CAP;
@@ -889,9 +890,8 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
         }
 
         // ---- first digit: NB1 - 1 value-linear buckets over the window (rows 1 .. NB1-1; rows 0 and NB1 stay empty)
-        // SAVE (R = 32, where the registers allow it): the rows are kept, two per register and as byte offsets into the
-        // map (row * 64 < 2^16), for the second sweep
-        unsigned int rows[SAVE ? R / 2 : 1];
+        // (keeping the row numbers for the second sweep, two per register, was measured at R = 32 with one workgroup per
+        // CU: no gain - the sweeps were latency-, not instruction-bound - and with two per CU there are no registers for it)
         {
             const int lane = kt_lane(), nu = kt_opq_s(nu0);
             const unsigned int inc = C::inc(lane);
@@ -899,9 +899,8 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
 #pragma unroll
             for (int u = 0; u < R; ++u)
                 if (u < R / 2 || u < nu) {
-                    const unsigned int r64 = (unsigned)ka_frow<NB1>(v[u], sf, vlo) << 6;
-                    atomicAdd(reinterpret_cast<unsigned int *>(hb + (r64 << 1)), inc);       // word row * 32 + (lane & 31)
-                    if constexpr (SAVE) rows[u / 2] = (u & 1) ? rows[u / 2] | (r64 << 16) : r64;
+                    const unsigned int row = (unsigned)ka_frow<NB1>(v[u], sf, vlo);
+                    atomicAdd(reinterpret_cast<unsigned int *>(hb + (row << 7)), inc);      // word row * 32 + (lane & 31)
                 }
         }
         __syncthreads();
@@ -952,7 +951,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
             cmax = __builtin_amdgcn_readfirstlane(cmax);
-            if (first) map[myrow * 64 + lane] = (unsigned char)(wave + 1);
+            if (first) map[myrow * KA_MAPROW + lane] = (unsigned char)(wave + 1);
         }
         __syncthreads();
         {
@@ -973,10 +972,8 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int u = u0 + i;
-                    unsigned int r64;
-                    if constexpr (SAVE) r64 = (u & 1) ? rows[u / 2] >> 16 : rows[u / 2] & 0xffffu;
-                    else r64 = (unsigned)ka_frow<NB1>(v[u], sf2, vlo2) << 6;
-                    m[i] = ((u < R / 2 || u < nu) && ok) ? (int)mapl[r64] : 0;
+                    const unsigned int row = (unsigned)ka_frow<NB1>(v[u], sf2, vlo2);
+                    m[i] = ((u < R / 2 || u < nu) && ok) ? (int)mapl[row * KA_MAPROW] : 0;
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -1016,7 +1013,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
             const long long c = c0 + lane;
             if (state && c < M) out[(long long)kl.o[wave] * M + c] = nancell ? __uint_as_float(0x7fc00000u) : key2f(ans);
             if (first) {                                            // leave the map and the counters as they were found
-                map[myrow * 64 + lane] = 0;
+                map[myrow * KA_MAPROW + lane] = 0;
                 cnt[wave * 64 + lane] = 0u;
             }
         } else if (wave == 0 && kt_lane() == 0) {
