@@ -1215,11 +1215,14 @@ extern "C" int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, cons
     hipStream_t st = as_stream(stream);
     if (n <= 64) return launch_kth_small<64>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     if (n <= 128) return launch_kth_small<128>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
-    // 128 < n <= 1024: the tile in registers, read once (16, 32 rows per thread: two workgroups per CU; 64: one)
+    // 128 < n <= 1024: the tile in registers, read once (16, 24, 32 rows per thread: two workgroups per CU; 48, 64: one).
+    // Every instantiation serves R/2 < rows per thread <= R (its first R/2 rows need no "is this row below n" test)
     if (n <= 256) return launch_kth_tile<8, 16, 2>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     // 16-bit counters hold n < 65536; 1024 first-digit buckets (one workgroup per CU) pay off once 512 buckets
     // would leave more than CAP elements per bucket (n above ~2000)
+    if (n <= 384) return launch_kth_tile<8, 24, 2>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     if (n <= 512) return launch_kth_tile<8, 32, 2>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    if (n <= 768) return launch_kth_tile<9, 48, 1>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     if (n <= 1024) return launch_kth_tile<9, 64, 1>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     if (n >= 65536) return launch_kth<9, true>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
     if (n > 2048) return launch_kth<10, false>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
