@@ -225,7 +225,7 @@ def run_secondary(args, cfg, dev, group, rank, world, par):
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": SYNTH + "; whole per-rank tensor resident",
             "config": {"workload": f"{cfg['title']} {shape} per rank, {args.mode} CP, 10 alpha levels", "mode": args.mode, **par,
-                       **({"score_pass": "branch-and-bound (bit-identical scores)" if pruned[0] else "full"}
+                       **({"score_pass": "branch-and-bound (same scores as the full pass for the same modulation)" if pruned[0] else "full"}
                           if args.mode == "joint" else {})},
             "roofline": {"bound": "hbm", "kernel": cfg["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,

@@ -195,10 +195,19 @@ class JointCalibration:
         When the slab allows it (``HipOps.prune_view``: dense, large enough, ...) the moments pass also delivers
         per-segment maxima of |res| and the score pass reads only the segments that can still raise a sample's
         score - the same scores for the same modulation, bit for bit (``prune=False`` forces the full pass).  The
-        route adapts to the data: a sample whose bounds prune little is swept whole inside the kernel, and a stream
-        whose first pruned slab read more than ``PRUNE_GIVE_UP`` of its segments takes the plain passes from then on."""
+        route adapts to the data: a sample whose bounds prune little is flagged and takes the full pass, and a stream
+        whose first pruned slab read more than ``PRUNE_GIVE_UP`` of its segments takes the plain passes from its
+        second slab on."""
         ops = self.ops
         M = res[0].numel() if hasattr(res[0], "numel") else res[0].size
+        if self.prune and self.prune_stats is not None and not self.prune_checked:
+            # ONE host read per stream, when its SECOND slab arrives (a single-slab stream never synchronises for it):
+            # were the bounds worth their segment maxima on the first?  (Every rank reads its own counters; the
+            # decision only changes which LOCAL kernels run.)
+            self.prune_checked = True
+            read, total, _ = (int(v) for v in self.prune_stats.tolist())
+            if total and read > self.PRUNE_GIVE_UP * total:
+                self.prune = False
         view = ops.prune_view(res, crop) if self.prune and getattr(ops, "prune_view", None) else None
         if view is not None:
             resc, cropc = view                                           # cell axes in memory order
@@ -220,13 +229,6 @@ class JointCalibration:
                 self.prune_stats = ops.zeros_prune_stats(self.device)
             kw2 = {"stats": self.prune_stats} if self.prune_stats is not None else {}
             ops.max_scores_pruned(resc, icp.canon_cells(mod, icp.canon(res)[1]), segmax, cropc, self.scores, **kw2)
-            if self.prune_stats is not None and not self.prune_checked:
-                # ONE host read per stream, after its first pruned slab: were the bounds worth their segment maxima?
-                # (every rank reads its own counters; the decision only changes which LOCAL kernels run)
-                self.prune_checked = True
-                read, total, _ = (int(v) for v in self.prune_stats.tolist())
-                if total and read > self.PRUNE_GIVE_UP * total:
-                    self.prune = False
         else:
             ops.max_scores(res, mod, crop, self.scores)
         self.modulation.append(mod)

@@ -186,7 +186,7 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod,
 /* Branch-and-bound form of the streaming joint score.  The score of a sample is a maximum, and for a segment (one row
  * x, 64 columns, the slab's planes)  max |r_c| / min mod_c  bounds every |r_c| / mod_c in it (correctly rounded division
  * is monotone), so a segment whose bound does not exceed the sample's best score so far - scores[i] from earlier slabs,
- * then the segment with the largest bound - is never read.  Bit-identical to pre_joint_score_f32; on noise-like
+ * then the segment with the largest bound - is never read.  For the same modulation the scores are those of pre_joint_score_f32, bit for bit; on noise-like
  * residuals it reads well under 1 % of them.
  * A segment is 64 consecutive cells of the flattened (x, y) plane x 16 planes: NS = ceil(X*Y/64) segments per
  * chunk of planes, TC = ceil(T/16) chunks, index [tc][s] (a segment may straddle rows: a bound needs no geometry).

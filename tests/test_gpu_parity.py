@@ -933,7 +933,8 @@ def test_pruned_joint_score_adapts_to_wild_modulation(gpu, shape, monkeypatch):
         if slab == 0:
             read, total, swept = (int(v) for v in ad_jc.prune_stats.tolist())
             assert total == B * ((T + 15) // 16) * ((X * Y + 63) // 64) and swept > B // 2 and read > 0.25 * total
-            assert ad_jc.prune is False                                    # the stream gave the bounds up
+        if slab == 1:
+            assert ad_jc.prune is False                                    # the stream gave the bounds up at its second slab
     assert ad_jc.score_pass_read_frac() > 0.25
     assert torch.allclose(full_jc.finish(alphas), ad_jc.finish(alphas), rtol=1e-5, atol=0.0)
     # smooth data keeps them (at a few hundred samples sigma-hat is noisy enough for the odd sample to be swept whole)
