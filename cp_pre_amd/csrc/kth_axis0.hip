@@ -708,6 +708,15 @@ struct KTCfg {
     static_assert(TOTAL * 4 * WGS <= 160 * 1024, "does not fit the 160 KiB LDS");
 };
 
+// row of an element under the EXACT window [vlo, vlo + r], sf = (NB1-1)/r * 0.999999: t = (v - vlo) sf + 1 lies in
+// [1, NB1) for every finite element without any clamp (0 <= v - vlo <= r, and the 1e-6 margin is 8 ulps of NB1); a NaN
+// gives row 0 (v_cvt_u32_f32 of a NaN; the cell is settled by its flag), and a window that is not finite has sf = 0:
+// row 1, or 0 for inf * 0.  So rows never leave [0, NB1) - the streaming form's v_med3 is not needed here.
+__device__ __forceinline__ unsigned int kt_frow(float v, float sf, float vlo)
+{
+    return (unsigned int)__builtin_fmaf(v - vlo, sf, 1.0f);       // (v_cvt_u32_f32 saturates: negative -> 0, NaN -> 0)
+}
+
 // one row of a tile: 64 consecutive floats at the wave-uniform address p, `valid` bytes of them inside the tensor
 // (0: a row beyond n, or no next tile - the load then returns 0 and moves nothing)
 __device__ __forceinline__ float kt_row(const float *p, int valid, int loff)
@@ -899,7 +908,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
 #pragma unroll
             for (int u = 0; u < R; ++u)
                 if (u < R / 2 || u < nu) {
-                    const unsigned int row = (unsigned)ka_frow<NB1>(v[u], sf, vlo);
+                    const unsigned int row = kt_frow(v[u], sf, vlo);
                     atomicAdd(reinterpret_cast<unsigned int *>(hb + (row << 7)), inc);      // word row * 32 + (lane & 31)
                 }
         }
@@ -972,16 +981,19 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int u = u0 + i;
-                    const unsigned int row = (unsigned)ka_frow<NB1>(v[u], sf2, vlo2);
+                    const unsigned int row = kt_frow(v[u], sf2, vlo2);
                     m[i] = ((u < R / 2 || u < nu) && ok) ? (int)mapl[row * KA_MAPROW] : 0;
                 }
+                // (the positions of the batch's wanted elements first - up to eight returning atomics in flight - then the
+                // stores: one LDS round trip per batch instead of one per wanted element)
+                unsigned int pos[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    pos[i] = m[i] ? atomicAdd(reinterpret_cast<unsigned int *>(cb + (m[i] << 8)), 1u) : 0u;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int u = u0 + i;
-                    if (m[i]) {
-                        const unsigned int pos = atomicAdd(reinterpret_cast<unsigned int *>(cb + (m[i] << 8)), 1u);
-                        *reinterpret_cast<unsigned int *>(lb + m[i] * (LS * 256) + (pos << 8)) = f2key(v[u]);
-                    }
+                    if (m[i]) *reinterpret_cast<unsigned int *>(lb + m[i] * (LS * 256) + (pos[i] << 8)) = f2key(v[u]);
                     // the next tile, row by row into the register just consumed.  An unconditional load - rows beyond n, or
                     // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
                     // being finished or not: no copy has to wait for it here, no second definition to reconcile
