@@ -914,9 +914,21 @@ int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float
     if (crop_x < 0 || crop_y < 0 || row_stride < T * X * Y) return PRE_E_RANGE;
     const long long nseg = (X * Y + JP_SEG - 1) / JP_SEG, TC = (T + MS_TMAX - 1) / MS_TMAX, total = TC * nseg;
     if (n > 0x7fffffff || T > 0x7fffffff || X > 0x7fffffff || Y > 0x7fffffff) return PRE_E_SHAPE;
-    // the work list lives in LDS, next to 136 bytes of static state: 64 KiB in all, the limit of a workgroup on every
-    // CDNA part (gfx950 itself would allow 160 KiB)
-    if (total * 4 + 256 > 64 * 1024) return PRE_E_UNSUPPORTED;
+    // the work list lives in LDS, next to 136 bytes of static state: up to what a workgroup of this device may hold
+    // (gfx950: 160 KiB - a whole-T slab of 62 planes x 512 x 512, the strong-scaling C3 shard, has 16384 segments);
+    // above 64 KiB the kernel has to be told
+    int dev = 0, lds_max = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess)
+        lds_max = 64 * 1024;
+    if (total * 4 + 256 > lds_max) return PRE_E_UNSUPPORTED;
+    if (total * 4 + 256 > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(joint_score_pruned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_max - 256) != hipSuccess) {
+            (void)hipGetLastError();
+            return PRE_E_UNSUPPORTED;
+        }
+    }
     // a block per sample: few samples get more waves each to work through their lists
     const int threads = n >= 2048 ? 256 : n >= 512 ? 512 : 1024;
     hipLaunchKernelGGL(joint_score_pruned_kernel, dim3((unsigned)n), dim3(threads), (size_t)total * 4, as_stream(stream), res,

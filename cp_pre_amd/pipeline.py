@@ -88,15 +88,16 @@ class HipOps:
     # the joint calibration is a few launch latencies either way and sigma-hat is too noisy for tight bounds
     PRUNE_MIN_CELLS = 1 << 27
     PRUNE_MIN_SAMPLES = 256
+    PRUNE_MAX_SEGMENTS = (160 * 1024 - 256) // 4      # pre_joint_score_pruned_f32's work list: the LDS of a gfx950 workgroup
 
     @staticmethod
     def prune_view(res, crop):
         """(contiguous view of ``res`` with its cell axes in memory order, the crop in that order) when the
         branch-and-bound score applies, else None.  It takes a dense [n,T,X,Y] tensor in any axis order (the surrogate's
         Nt-fastest layout included: a segment is defined on the memory order) with at least one plane of the slowest
-        cell axis inside its crop and at most 16384 segments (64 consecutive cells of the two faster axes' flattened
-        plane x 16 planes) per sample - the work list lives in LDS; it pays from a few hundred samples and ~1e8 cells
-        on."""
+        cell axis inside its crop and at most ``PRUNE_MAX_SEGMENTS`` segments (64 consecutive cells of the two faster
+        axes' flattened plane x 16 planes) per sample - the work list lives in LDS; it pays from a few hundred samples
+        and ~1e8 cells on."""
         if res.dim() != 4 or res.numel() < HipOps.PRUNE_MIN_CELLS or res.shape[0] < HipOps.PRUNE_MIN_SAMPLES:
             return None
         resc, order = icp.canon(res)
@@ -105,7 +106,7 @@ class HipOps:
         cropc = tuple(crop) if order is None else tuple(crop[o - 1] for o in order)
         A0, A1, A2 = resc.shape[1:]
         planes = A0 - 2 * cropc[0]
-        if planes < 1 or ((planes + 15) // 16) * ((A1 * A2 + 63) // 64) > 16320:    # (pre_joint_score_pruned_f32's LDS list)
+        if planes < 1 or ((planes + 15) // 16) * ((A1 * A2 + 63) // 64) > HipOps.PRUNE_MAX_SEGMENTS:
             return None
         return resc, cropc
 

@@ -197,8 +197,8 @@ int pre_joint_score_f32(const float *a, const float *b, const float *mod,
  *     additions may differ).
  *   pre_segmin_mod_f32: segmin[tc][s] = min of mod[T,X,Y] over the segment's uncropped cells; +inf if there is none,
  *     0 if the segment holds a NaN or a non-positive modulation (-> always read).
- *   pre_joint_score_pruned_f32: scores as pre_joint_score_f32 with crop_t = 0 over the same planes; TC*NS <= 16320
- *     (the work list lives in LDS; else PRE_E_UNSUPPORTED).  flags (device uint32 [n], may be NULL; ABI v6): a sample
+ *   pre_joint_score_pruned_f32: scores as pre_joint_score_f32 with crop_t = 0 over the same planes; TC*NS*4 + 256 bytes
+ *     must fit the LDS of a workgroup (the work list lives there; gfx950: TC*NS <= 40896; else PRE_E_UNSUPPORTED).  flags (device uint32 [n], may be NULL; ABI v6): a sample
  *     whose bounds leave more than a quarter of its segments to read (a modulation that jumps between neighbouring
  *     cells) is not read segment by segment but flagged, flags[i] = 1 (else 0), for pre_joint_score_flagged_f32 - the
  *     full pass at its full speed over those samples.  stats (device, 3 x uint64, may be NULL): [0] += segments read

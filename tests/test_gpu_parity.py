@@ -901,10 +901,32 @@ def test_pruned_joint_score_equals_full_pass(gpu, shape, crop, monkeypatch):
     # tensors the pruned form does not take fall back silently: no plane inside the crop, too many segments, a view
     # that is not dense; and small tensors by default
     assert not ops.can_prune(res, (T, 1, 1))
-    assert not ops.can_prune(torch.empty(1, 16 * 65, 256, 64, device=gpu), (0, 0, 0))
+    assert not ops.can_prune(torch.empty(1, 16 * 170, 256, 64, device=gpu), (0, 0, 0))       # 43520 segments > the LDS list
     assert Y < 3 or not ops.can_prune(res[..., ::2], crop)                 # not dense
     monkeypatch.undo()
     assert not ops.can_prune(res, crop)
+
+
+def test_pruned_joint_score_whole_t_shard(gpu, monkeypatch):
+    """A strong-scaling C3 shard keeps the whole T axis resident: 64 planes x 512 x 512 = 16384 segments per sample, a work
+    list of 64 KiB + the kernel's static LDS - beyond the 64 KiB a dynamic allocation gets by default, inside the 160 KiB of
+    a gfx950 workgroup (round 3).  Pruned == full pass; smooth data, so almost nothing is read."""
+    from cp_pre_amd import pipeline
+    ops = pipeline.HipOps
+    monkeypatch.setattr(ops, "PRUNE_MIN_CELLS", 0)
+    monkeypatch.setattr(ops, "PRUNE_MIN_SAMPLES", 0)
+    B, T, X, Y = 96, 64, 512, 512
+    g = torch.Generator(device=gpu).manual_seed(5)
+    res = torch.randn(B, T, X, Y, device=gpu, generator=g) * (0.5 + torch.rand(T, X, Y, device=gpu, generator=g))
+    res[7, 40, 100:102, 300:310] *= 30.0
+    crop = (0, 1, 1)
+    assert ops.can_prune(res, crop) and ((T + 15) // 16) * ((X * Y + 63) // 64) == 16384
+    full, pr = pipeline.JointCalibration(B, gpu, prune=False), pipeline.JointCalibration(B, gpu)
+    full.add_slab(res, crop=crop)
+    pr.add_slab(res, crop=crop)
+    assert pr.prune_stats is not None and int(pr.prune_stats[1]) == B * 16384
+    assert torch.allclose(full.scores, pr.scores, rtol=1e-5, atol=0.0)
+    assert torch.equal(torch.argmax(full.scores), torch.argmax(pr.scores)) and int(torch.argmax(pr.scores)) == 7
 
 
 @pytest.mark.parametrize("shape", [(300, 16, 64, 256), (64, 5, 24, 128)])
