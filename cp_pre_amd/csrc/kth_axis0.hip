@@ -984,16 +984,15 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
                     const unsigned int row = kt_frow(v[u], sf2, vlo2);
                     m[i] = ((u < R / 2 || u < nu) && ok) ? (int)mapl[row * KA_MAPROW] : 0;
                 }
-                // (the positions of the batch's wanted elements first - up to eight returning atomics in flight - then the
-                // stores: one LDS round trip per batch instead of one per wanted element)
-                unsigned int pos[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    pos[i] = m[i] ? atomicAdd(reinterpret_cast<unsigned int *>(cb + (m[i] << 8)), 1u) : 0u;
+                // (issuing the batch's returning atomics together before the stores was measured: eight more live registers,
+                // spills under the 64-register cap of the two-workgroup form - n = 512 1.21 -> 1.86 ms - and no gain with one)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int u = u0 + i;
-                    if (m[i]) *reinterpret_cast<unsigned int *>(lb + m[i] * (LS * 256) + (pos[i] << 8)) = f2key(v[u]);
+                    if (m[i]) {
+                        const unsigned int pos = atomicAdd(reinterpret_cast<unsigned int *>(cb + (m[i] << 8)), 1u);
+                        *reinterpret_cast<unsigned int *>(lb + m[i] * (LS * 256) + (pos << 8)) = f2key(v[u]);
+                    }
                     // the next tile, row by row into the register just consumed.  An unconditional load - rows beyond n, or
                     // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
                     // being finished or not: no copy has to wait for it here, no second definition to reconcile

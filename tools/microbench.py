@@ -45,6 +45,16 @@ def bench_eval():
         report(f"mhd_momentum 28B/cell", timeit(lambda: mhd.residual_momentum(v, True)), 28 * cells)
         report(f"mhd_energy 28B/cell", timeit(lambda: mhd.residual_energy(v, True)), 28 * cells)
         del v, out
+    # reduced MHD (JOREK): the script's [BS,F,Nx,Ny,Nt] layout (Nt fastest through unstack_fields) and an Ny-fastest copy
+    for (B, N, Nt) in [(512, 256, 20), (128, 512, 40)]:
+        v3 = torch.empty(B, 3, N, N, Nt, device=dev).uniform_(0.5, 1.5)
+        jo = R.JOREK(torch.linspace(1.0, 2.0, N))
+        cells = B * N * N * Nt
+        report(f"jorek continuity [BS={B},Nx=Ny={N},Nt={Nt}] Nt-fastest 12B/cell", timeit(lambda: jo.residual_continuity(v3, True)), 12 * cells)
+        report(f"jorek temperature, Nt-fastest 16B/cell", timeit(lambda: jo.residual_temperature(v3, True)), 16 * cells)
+        vy = v3.permute(0, 1, 4, 2, 3).contiguous().permute(0, 1, 3, 4, 2)
+        report(f"jorek temperature, Ny-fastest 16B/cell", timeit(lambda: jo.residual_temperature(vy, True)), 16 * cells)
+        del v3, vy
     B, T, X = 8192, 200, 512
     u = torch.empty(B, T, X, device=dev).uniform_(0.5, 1.5)
     bur = R.Burgers(2 / 512, 1.25 / 200, 0.002)
