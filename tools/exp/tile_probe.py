@@ -2,7 +2,9 @@
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
-from cp_pre_amd import inductive_cp as icp
+from cp_pre_amd import _lib, inductive_cp as icp
+if os.environ.get("PROBE_SO"):                       # an experimental build of the library (tools/exp/*.so)
+    _lib.SO_PATH = os.path.abspath(os.environ["PROBE_SO"])
 
 n, M = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
