@@ -60,6 +60,7 @@ SIGNATURES = {
     "pre_joint_score_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, _fp, c_void_p],
     "pre_kth_f32": [_fp, c_int64, POINTER(c_int64), c_int, _fp, c_void_p],
     "pre_kth_axis0_f32": [_fp, c_int64, c_int64, POINTER(c_int32), c_int, _fp, c_void_p],
+    "pre_kth_axis0_strided_f32": [_fp, c_int64, c_int64, c_int64, POINTER(c_int32), c_int, _fp, c_void_p],
     "pre_cov_count_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int, _fp, c_void_p],
     "pre_cov_rowcount_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int, c_int, _fp, c_void_p],
     "pre_cov_joint_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int, _fp, c_void_p],

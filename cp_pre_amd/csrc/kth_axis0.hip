@@ -597,8 +597,8 @@ __device__ __forceinline__ void ka_collect(const Src &src, int nk, int known,
 
 // one tile (64 cells from c0) of the streaming form, all phases, by the whole workgroup
 template <int LOG_NB1, bool WIDE>
-__device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long long M, long long c0, const KAList &kl, int fast,
-                                        float *__restrict__ out, unsigned int *hist)
+__device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long long M, long long S, long long c0, const KAList &kl,
+                                        int fast, float *__restrict__ out, unsigned int *hist)
 {
     using Cfg = KACfg<LOG_NB1, WIDE>;
     constexpr int U = Cfg::U, BITS = Cfg::BITS;
@@ -612,11 +612,12 @@ __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long
 
     unsigned int klo = 0u;
     float sf = 0.f, vlo = 0.f;
-    int shift = ka_window<LOG_NB1>(col, cok, n, M, hist, klo, sf, vlo, lane, wave);
+    // (the helpers below use their `M` argument only as the distance between rows: they get the row stride S)
+    int shift = ka_window<LOG_NB1>(col, cok, n, S, hist, klo, sf, vlo, lane, wave);
     bool outside = false;
     if (fast) {
         unsigned int key = 0u;
-        if (ka_fast<LOG_NB1, WIDE>(col, cok, n, M, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid)) {
+        if (ka_fast<LOG_NB1, WIDE>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid)) {
             if (state && cok) out[(long long)kl.o[wave] * M + c] = key2f(key);
             return;
         }
@@ -624,7 +625,7 @@ __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long
     }
     unsigned int myp = 0u, myr = k0;
     bool many = true, nanl = false;
-    const HbmSrc src{col, cok, n, M, wave};
+    const HbmSrc src{col, cok, n, S, wave};
     if (!outside) {
         many = ka_first<LOG_NB1, WIDE, U, Cfg::CAP>(src, nk, shift, klo, true, hist, myp, myr, outside, nanl, lane, wave, tid);
         if (outside) __syncthreads();
@@ -658,10 +659,11 @@ __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long
 
 template <int LOG_NB1, bool WIDE>
 __global__ void __launch_bounds__(1024, (4 * KACfg<LOG_NB1, WIDE>::WG_PER_CU))
-kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long tile0, const KAList kl, int fast, float *__restrict__ out)
+kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long S, long long tile0, const KAList kl, int fast,
+                 float *__restrict__ out)
 {
     __shared__ unsigned int hist[KACfg<LOG_NB1, WIDE>::WORDS];
-    ka_tile<LOG_NB1, WIDE>(s, n, M, (tile0 + blockIdx.x) * KA_W, kl, fast, out, hist);
+    ka_tile<LOG_NB1, WIDE>(s, n, M, S, (tile0 + blockIdx.x) * KA_W, kl, fast, out, hist);
 }
 
 // ---- 128 < n <= 1024: the tile lives in REGISTERS ---------------------------------------------------------------
@@ -814,7 +816,8 @@ __device__ __forceinline__ unsigned int kt_pick(const unsigned int *hist, int sl
 
 template <int LOG_NB1, int R, int WGS>
 __global__ void __launch_bounds__(1024, 4 * WGS)
-kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntiles, const KAList kl, float *__restrict__ out)
+kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, long long ntiles, const KAList kl,
+                float *__restrict__ out)
 {
     using Cfg = KTCfg<LOG_NB1, WGS>;
     using C = Ctr<false>;
@@ -836,11 +839,11 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
         const long long c0 = tile * KA_W;
         const int valid = (int)((M - c0) * 4 < 256 ? (M - c0) * 4 : 256);
         const int nu = (n - wave0 + KA_WAVES - 1) / KA_WAVES;
-        const float *p = s + c0 + (long long)wave0 * M;
+        const float *p = s + c0 + (long long)wave0 * S;
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             v[u] = kt_row(p, u < nu ? valid : 0, (tid0 & 63) * 4);
-            p += (long long)KA_WAVES * M;
+            p += (long long)KA_WAVES * S;
         }
     }
     __syncthreads();
@@ -940,7 +943,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
         const bool more = tile + gridDim.x < ntiles;               // (block-uniform)
         const long long nc0 = more ? (tile + gridDim.x) * KA_W : c0;
         const int nvalid = more ? (int)((M - nc0) * 4 < 256 ? (M - nc0) * 4 : 256) : 0;
-        const float *nbase = s + nc0 + (long long)wave * M;        // my first row of the next tile
+        const float *nbase = s + nc0 + (long long)wave * S;        // my first row of the next tile
 
         // ---- collect + pick (when every pair has its <= CAP candidates: ok, block-uniform).  The list of a rank = the
         // list of the FIRST rank of its cell with the same row.
@@ -997,7 +1000,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
                     // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
                     // being finished or not: no copy has to wait for it here, no second definition to reconcile
                     v[u] = kt_row(np, (u < R / 2 || u < nu) ? nvalid : 0, lane * 4);
-                    np += (long long)KA_WAVES * M;
+                    np += (long long)KA_WAVES * S;
                 }
             }
         }
@@ -1052,7 +1055,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long ntile
             while (todo) {
                 const int b = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                ka_tile<9, false>(s, n, M, (blockIdx.x + (ib + b) * gridDim.x) * KA_W, kl, 1, out, lds);
+                ka_tile<9, false>(s, n, M, S, (blockIdx.x + (ib + b) * gridDim.x) * KA_W, kl, 1, out, lds);
                 __syncthreads();
             }
         }
@@ -1119,7 +1122,7 @@ __device__ __forceinline__ unsigned int ks_take(const unsigned int (&v)[N], int 
 }
 
 template <int N>
-__global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict__ s, int n, long long M, const KAList kl,
+__global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict__ s, int n, long long M, long long S, const KAList kl,
                                                        float *__restrict__ out)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1136,7 +1139,7 @@ __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict_
     for (int i = 0; i < N; ++i) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, valid, 0x00020000);
         raw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, 0, 0));
-        p += (i + 1 < n) ? M : 0;
+        p += (i + 1 < n) ? S : 0;
     }
     unsigned int v[N];
 #pragma unroll
@@ -1154,7 +1157,7 @@ __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict_
 }
 
 template <int N>
-int launch_kth_small(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
+int launch_kth_small(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
 {
     const long long blocks = ((M + KA_W - 1) / KA_W + 3) / 4;
     if (blocks > 0x7fffffffLL) return PRE_E_SHAPE;
@@ -1162,14 +1165,14 @@ int launch_kth_small(const float *scores, int n, long long M, const int32_t *ks,
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : -1; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
-        hipLaunchKernelGGL((kth_small_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, kl, out);
+        hipLaunchKernelGGL((kth_small_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, S, kl, out);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
 }
 
 template <int LOG_NB1, bool WIDE>
-int launch_kth(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
+int launch_kth(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
 {
     const long long tiles = (M + KA_W - 1) / KA_W;
     const long long per_launch = 1LL << 21;                     // x 1024 threads: the dispatch packet counts work-items in 32 bits
@@ -1181,7 +1184,7 @@ int launch_kth(const float *scores, int n, long long M, const int32_t *ks, const
             const long long nt = tiles - t0 < per_launch ? tiles - t0 : per_launch;
             // the fast first digit pays while a full bucket holds well under CAP elements (n <= ~6 NB1 on
             // bell-shaped scores); beyond that it would be a wasted sweep
-            hipLaunchKernelGGL((kth_axis0_kernel<LOG_NB1, WIDE>), dim3((unsigned)nt), dim3(1024), 0, st, scores, n, M, t0, kl,
+            hipLaunchKernelGGL((kth_axis0_kernel<LOG_NB1, WIDE>), dim3((unsigned)nt), dim3(1024), 0, st, scores, n, M, S, t0, kl,
                                n <= 6 * (1 << LOG_NB1) ? 1 : 0, out);
             PRE_LAUNCH_CHECK();
         }
@@ -1190,7 +1193,7 @@ int launch_kth(const float *scores, int n, long long M, const int32_t *ks, const
 }
 
 template <int LOG_NB1, int R, int WGS>
-int launch_kth_tile(const float *scores, int n, long long M, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
+int launch_kth_tile(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
 {
     const long long tiles = (M + KA_W - 1) / KA_W;
     int dev = 0, cus = 0;
@@ -1201,7 +1204,7 @@ int launch_kth_tile(const float *scores, int n, long long M, const int32_t *ks, 
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
-        hipLaunchKernelGGL((kth_tile_kernel<LOG_NB1, R, WGS>), dim3((unsigned)grid), dim3(1024), 0, st, scores, n, M, tiles, kl, out);
+        hipLaunchKernelGGL((kth_tile_kernel<LOG_NB1, R, WGS>), dim3((unsigned)grid), dim3(1024), 0, st, scores, n, M, S, tiles, kl, out);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
@@ -1209,9 +1212,12 @@ int launch_kth_tile(const float *scores, int n, long long M, const int32_t *ks, 
 
 }  // namespace
 
-extern "C" int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks, int nk, float *out, void *stream)
+extern "C" int pre_kth_axis0_strided_f32(const float *scores, int64_t row_stride, int64_t n, int64_t M, const int32_t *ks, int nk,
+                                         float *out, void *stream)
 {
     if (!scores || !ks || !out || n <= 0 || M <= 0 || nk <= 0) return PRE_E_NULL;
+    if (row_stride < M) return PRE_E_RANGE;
+    const long long S = (long long)row_stride;
     if (n > 0x7fffffff || nk > 64) return PRE_E_SHAPE;
     // the kernels want ascending ranks (their slots rely on it): sort here, each result goes to its caller's row
     int32_t sk[64], rows[64];
@@ -1224,18 +1230,23 @@ extern "C" int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, cons
     }
     ks = sk;
     hipStream_t st = as_stream(stream);
-    if (n <= 64) return launch_kth_small<64>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
-    if (n <= 128) return launch_kth_small<128>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    if (n <= 64) return launch_kth_small<64>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
+    if (n <= 128) return launch_kth_small<128>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
     // 128 < n <= 1024: the tile in registers, read once (16, 24, 32 rows per thread: two workgroups per CU; 48, 64: one).
     // Every instantiation serves R/2 < rows per thread <= R (its first R/2 rows need no "is this row below n" test)
-    if (n <= 256) return launch_kth_tile<8, 16, 2>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    if (n <= 256) return launch_kth_tile<8, 16, 2>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
     // 16-bit counters hold n < 65536; 1024 first-digit buckets (one workgroup per CU) pay off once 512 buckets
     // would leave more than CAP elements per bucket (n above ~2000)
-    if (n <= 384) return launch_kth_tile<8, 24, 2>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
-    if (n <= 512) return launch_kth_tile<8, 32, 2>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
-    if (n <= 768) return launch_kth_tile<9, 48, 1>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
-    if (n <= 1024) return launch_kth_tile<9, 64, 1>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
-    if (n >= 65536) return launch_kth<9, true>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
-    if (n > 2048) return launch_kth<10, false>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
-    return launch_kth<9, false>(scores, (int)n, (long long)M, ks, rows, nk, out, st);
+    if (n <= 384) return launch_kth_tile<8, 24, 2>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
+    if (n <= 512) return launch_kth_tile<8, 32, 2>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
+    if (n <= 768) return launch_kth_tile<9, 48, 1>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
+    if (n <= 1024) return launch_kth_tile<9, 64, 1>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
+    if (n >= 65536) return launch_kth<9, true>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
+    if (n > 2048) return launch_kth<10, false>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
+    return launch_kth<9, false>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
+}
+
+extern "C" int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks, int nk, float *out, void *stream)
+{
+    return pre_kth_axis0_strided_f32(scores, M, n, M, ks, nk, out, stream);
 }

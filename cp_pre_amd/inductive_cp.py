@@ -101,7 +101,13 @@ def kth_axis0(scores, ks):
     """Order statistics ``ks`` (0-based ranks, any order) along axis 0 of a device tensor
     [n, ...] -> [len(ks), ...].  1-D scores use the scalar radix select."""
     lib = _lib.load()
-    scores, cell_order = canon(scores)
+    pitch = None
+    if scores.dim() >= 2 and not scores.is_contiguous() and scores[0].is_contiguous() and scores.stride(0) > scores[0].numel():
+        # rows with a pitch (a driver that pads its residual buffer so that the rows of a cell's column are not a power
+        # of two apart, pipeline.row_padded): selected where they lie
+        pitch, cell_order = scores.stride(0), None
+    else:
+        scores, cell_order = canon(scores)
     n = scores.shape[0]
     with torch.cuda.device(scores.device):
         if scores.dim() == 1:
@@ -116,10 +122,10 @@ def kth_axis0(scores, ks):
             if inv != list(range(len(ks))):      # device-only reorder (no index upload: stays HIP-graph capturable)
                 out = out.flip(0) if inv == list(range(len(ks) - 1, -1, -1)) else torch.stack([out[i] for i in inv])
         else:
-            M = scores.numel() // n
+            M = scores[0].numel()
             out = torch.empty((len(ks),) + tuple(scores.shape[1:]), dtype=torch.float32, device=scores.device)
-            _lib.check(lib.pre_kth_axis0_f32(_lib.ptr(scores), n, M, _lib.iarr32([int(k) for k in ks]), len(ks), _lib.ptr(out),
-                                             _lib.stream()), "pre_kth_axis0_f32")      # (any rank order: out[j] <-> ks[j])
+            _lib.check(lib.pre_kth_axis0_strided_f32(_lib.ptr(scores), pitch or M, n, M, _lib.iarr32([int(k) for k in ks]), len(ks),
+                                                     _lib.ptr(out), _lib.stream()), "pre_kth_axis0_strided_f32")   # (out[j] <-> ks[j])
     return uncanon(out, cell_order, 1)
 
 

@@ -262,6 +262,22 @@ def time_major(n_local, cells, dtype=torch.float32, device=None):
     return torch.empty((T, n_local) + rest, dtype=dtype, device=device).transpose(0, 1)
 
 
+def row_padded(n_local, cells, pad=64, dtype=torch.float32, device=None):
+    """A score / residual buffer [n_local, *cells] whose rows are ``pad`` elements further apart than they are long.
+    With M = 2^k cells per row every row of a cell's column shares its low address bits, which costs the per-cell select's
+    column sweeps 4-11 % on the MI355X (``profiles/r03/row_pitch.txt``); ``marginal_qhat`` / ``kth_axis0`` select
+    where the rows lie (``pre_kth_axis0_strided_f32``), the residual kernels write through any batch stride."""
+    M = 1
+    for d in cells:
+        M *= d
+    buf = torch.empty(n_local * (M + pad), dtype=dtype, device=device)
+    strides, acc = [], 1
+    for d in reversed(cells):
+        strides.append(acc)
+        acc *= d
+    return buf.as_strided((n_local,) + tuple(cells), (M + pad,) + tuple(reversed(strides)))
+
+
 def _is_time_major(scores):
     """[n, T, ...] whose memory is [T][n][...] dense (see :func:`time_major`)."""
     if scores.dim() < 3 or scores.shape[1] < 1:

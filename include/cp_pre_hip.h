@@ -231,6 +231,11 @@ int pre_joint_score_flagged_f32(const float *a, const float *b, const float *mod
 int pre_kth_f32(const float *scores, int64_t N, const int64_t *ks /*host*/, int nk, float *out, void *stream);
 int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks /*host*/, int nk,
                       float *out, void *stream);
+/* ... with the rows row_stride >= M elements apart (ABI v6).  A power-of-two distance between the rows of a cell's column
+ * - M = 2^k cells - lines every row of a tile up on the same low address bits and costs the column sweeps 4-11 % on
+ * the MI355X (profiles/r03/row_pitch.txt); a driver that owns the buffer pads its rows by 64 floats. */
+int pre_kth_axis0_strided_f32(const float *scores, int64_t row_stride, int64_t n, int64_t M, const int32_t *ks /*host*/, int nk,
+                              float *out, void *stream);
 
 /* ---- a14: emp_cov / emp_cov_joint / filter_sims_joint -----------------------------------
  * (Joint/Burgers_Residuals_CP.py:298-300; Tests/test_advection_inv_sampling_marginal.py:465)

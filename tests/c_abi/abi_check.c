@@ -141,6 +141,18 @@ int main(void)
             for (int j = 0; j < 3; ++j) exact2 &= (hq[j * M + c] == col[mixed[j]]);
         }
         EXPECT(rc3 == PRE_OK && exact2, "pre_kth_axis0_f32: ranks in any order, out[j] <-> ks[j]");
+        /* rows with a pitch: the first M - 2 cells of every row, rows still M apart */
+        int rc4 = pre_kth_axis0_strided_f32(dout, M, n, M - 2, ks, 3, dq, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(hq, dq, sizeof hq, hipMemcpyDeviceToHost));
+        int exact3 = 1;
+        for (int c = 0; c < M - 2; ++c) {
+            for (int i = 0; i < n; ++i) col[i] = fabsf(hu[i * M + c] - hv[i * M + c]);
+            qsort(col, n, sizeof(float), cmp_float);
+            for (int j = 0; j < 3; ++j) exact3 &= (hq[j * (M - 2) + c] == col[ks[j]]);
+        }
+        EXPECT(rc4 == PRE_OK && exact3, "pre_kth_axis0_strided_f32: rows with a pitch");
+        EXPECT(pre_kth_axis0_strided_f32(dout, M - 3, n, M - 2, ks, 3, dq, st) == PRE_E_RANGE, "row_stride < M -> PRE_E_RANGE");
         int32_t bad[2] = {2, (int32_t)n};
         EXPECT(pre_kth_axis0_f32(dout, n, M, bad, 2, dq, st) == PRE_E_RANGE, "rank >= n -> PRE_E_RANGE");
         EXPECT(pre_kth_axis0_f32(NULL, n, M, ks, 3, dq, st) == PRE_E_NULL, "null pointer -> PRE_E_NULL");

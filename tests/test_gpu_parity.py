@@ -1850,6 +1850,38 @@ def _sharded_worker(rank, world, port, n_local, shape, out_dir):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("n", [33, 100, 200, 300, 500, 700, 1000, 2049, 5000, 9000, 66000])
+def test_marginal_qhat_rows_with_a_pitch(gpu, n):
+    """pre_kth_axis0_strided_f32 / pipeline.row_padded: the per-cell select over rows that are further apart than they are
+    long (every regime of n: register sort, register tiles, streaming fast and general forms, 32-bit counters) equals the
+    select over a contiguous copy, bit for bit; ragged cell counts, a NaN and a tie column included; the fused residual
+    kernel writes through the padded view."""
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    g = torch.Generator(device=gpu).manual_seed(n)
+    for cells in ((7, 19), (1000,), (3, 8, 64)) if n < 60000 else ((130,),):
+        s = pipeline.row_padded(n, cells, pad=64 if n % 2 else 36, device=gpu)
+        assert not s.is_contiguous() and s[0].is_contiguous()
+        s.copy_(torch.randn((n,) + cells, device=gpu, generator=g).abs_())
+        s.view(n, -1)[: n // 2, 3] = 1.25
+        if s[0].numel() > 5:
+            s.view(n, -1)[n // 3, 5] = float("nan")
+        ks = sorted({0, n // 2, n - 1} | {icp.kth_index(n, n, float(a)) for a in icp.ALPHA_LEVELS if icp.quantile_level(n, float(a)) <= 1})[:10]
+        got, want = icp.kth_axis0(s, ks), icp.kth_axis0(s.contiguous(), ks)
+        assert got.shape == want.shape and torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(want, nan=-1.0)), (n, cells)
+    if n == 300:
+        from cp_pre_amd.residuals import NavierStokes
+        B, T, X, Y = 21, 6, 16, 64
+        v = (torch.rand(B, 3, T, X, Y, device=gpu, generator=g) + 0.5)
+        ns = NavierStokes(1e-2, 1.0 / X, 1.0 / Y, nu=1e-3)
+        ref = torch.empty(B, T - 2, X, Y, device=gpu)
+        ns.residual_momentum(v, boundary=True, absolute=True, out=ref, skip_t_rim=True)
+        pad = pipeline.row_padded(B, (T - 2, X, Y), device=gpu)
+        ns.residual_momentum(v, boundary=True, absolute=True, out=pad, skip_t_rim=True)
+        assert torch.equal(pad, ref)
+        assert torch.equal(pipeline.marginal_qhat(pad, [0.1, 0.5]), pipeline.marginal_qhat(ref, [0.1, 0.5]))
+
+
 def test_time_major_residual_buffer_and_planewise_qhat(gpu):
     """The t-slab driver's residual buffer for sharded marginal CP: memory [T][B][X][Y] handed to the fused kernel as
     an interior-plane ``out`` view [B,T-2,X,Y] (any batch / time strides over dense planes).  Same numbers as the
