@@ -426,11 +426,12 @@ def main():
         synth_(vars_[:, i], 100 * rank + 20 + i)
     # residual buffer: the slab's INTERIOR planes only (the slab's first and last plane are halo planes that every
     # consumer would crop: they are neither computed nor stored, PRE_FLAG_OUT_INTERIOR_T)
-    res_buf = torch.empty(B * (S * X * Y + 64), dtype=torch.float32, device=dev)
+    res_buf = torch.empty(B * S * (X * Y + 64), dtype=torch.float32, device=dev)      # (room for either padded layout)
     if args.mode == "marginal" and group is not None:
         # time-major [sl][B][X][Y] seen as [B,sl,X,Y]: plane t of all local samples is one contiguous block, the send
         # block of the all-to-all that hands plane t to rank t % world (pipeline.marginal_qhat: no pack copy)
-        res_of = {sl: res_buf[:B * sl * X * Y].view(sl, B, X, Y).transpose(0, 1) for sl in set(slabs)}
+        # (samples of a plane 64 floats further apart than a plane is long: profiles/r03/row_pitch.txt)
+        res_of = {sl: res_buf.as_strided((B, sl, X, Y), (X * Y + 64, B * (X * Y + 64), Y, 1)) for sl in set(slabs)}
     elif args.mode == "marginal":
         # rows 64 floats further apart than they are long: a power-of-two distance between the rows of a cell's column
         # (16 x 512 x 512 cells) costs the per-cell select ~10 % (pipeline.row_padded, profiles/r03/row_pitch.txt)

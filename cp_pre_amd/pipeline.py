@@ -252,14 +252,24 @@ class JointCalibration:
         return self.ops.kth(scores, _ranks(self.n_total, alphas))
 
 
-def time_major(n_local, cells, dtype=torch.float32, device=None):
-    """A score / residual buffer for ``marginal_qhat``'s zero-copy exchange: memory [T][n_local][*rest] (time-major),
-    returned as its logical [n_local, T, *rest] view.  Plane t of every local sample is then one contiguous block -
-    the send block of the all-to-all that gives plane t to rank t % world - so a residual kernel that writes through
-    this view (``NavierStokes.residual_momentum(out=...)``: any batch / time strides over dense planes) has already
-    packed the exchange."""
+def time_major(n_local, cells, pad=0, dtype=torch.float32, device=None):
+    """A score / residual buffer for ``marginal_qhat``'s zero-copy exchange: memory [T][n_local][*rest (+ pad)]
+    (time-major), returned as its logical [n_local, T, *rest] view.  Plane t of every local sample is then one contiguous
+    block - the send block of the all-to-all that gives plane t to rank t % world - so a residual kernel that writes
+    through this view (``NavierStokes.residual_momentum(out=...)``: any batch / time strides over dense planes) has
+    already packed the exchange.  ``pad``: floats between a sample's plane and the next sample's (64 keeps the rows of a
+    power-of-two plane from sharing their low address bits, see :func:`row_padded`; the pad travels with the plane)."""
     T, rest = cells[0], tuple(cells[1:])
-    return torch.empty((T, n_local) + rest, dtype=dtype, device=device).transpose(0, 1)
+    per = 1
+    for d in rest:
+        per *= d
+    pitch = per + pad
+    buf = torch.empty(T * n_local * pitch, dtype=dtype, device=device)
+    strides, acc = [], 1
+    for d in reversed(rest):
+        strides.append(acc)
+        acc *= d
+    return buf.as_strided((n_local, T) + rest, (pitch, n_local * pitch) + tuple(reversed(strides)))
 
 
 def row_padded(n_local, cells, pad=64, dtype=torch.float32, device=None):
@@ -279,10 +289,15 @@ def row_padded(n_local, cells, pad=64, dtype=torch.float32, device=None):
 
 
 def _is_time_major(scores):
-    """[n, T, ...] whose memory is [T][n][...] dense (see :func:`time_major`)."""
+    """[n, T, ...] whose memory is [T][n][... (+ pad)]: dense planes, the samples of a plane ``pitch`` >= plane size
+    apart, the planes n * pitch apart (see :func:`time_major`)."""
     if scores.dim() < 3 or scores.shape[1] < 1:
         return False
-    return scores.transpose(0, 1).is_contiguous() and (scores.shape[0] > 1 and scores.shape[1] > 1 or scores.is_contiguous())
+    n, T = scores.shape[0], scores.shape[1]
+    if not scores[0, 0].is_contiguous():
+        return False
+    per, pitch = scores[0, 0].numel(), scores.stride(0)
+    return pitch >= per and (T == 1 or scores.stride(1) == n * pitch) and (n == 1 or T == 1 or pitch < scores.stride(1))
 
 
 def _marginal_planes(scores, alphas, group, ops, overlap):
@@ -300,19 +315,21 @@ def _marginal_planes(scores, alphas, group, ops, overlap):
         per *= d
     ks = _ranks(n_local * world, alphas)          # raises before any collective if a level exceeds 1
     nk = len(alphas)
-    tm = scores.transpose(0, 1).reshape(T, n_local * per)       # the memory as it lies: [T][n_local * per], no copy
+    pitch = scores.stride(0) if n_local > 1 else per            # floats from one sample's plane to the next one's
+    blk = n_local * pitch                                       # one plane of all local samples, as it lies
+    tm = scores.as_strided((T, blk), (blk, 1))                  # the memory as it lies: [T][n_local * pitch], no copy
     runs = (T + world - 1) // world
     nbuf = 2 if (overlap and runs > 1) else 1
-    recv = [tm.new_empty(world * n_local * per) for _ in range(nbuf)]
+    recv = [tm.new_empty(world * blk) for _ in range(nbuf)]
     q_own = tm.new_zeros(runs, nk, per)           # the q-hat planes this rank owns (plane k * world + rank), run by run
     work = [None] * nbuf
 
     def exchange(k, b):
         t0 = k * world
         pr = min(world, T - t0)                   # planes in this run: ranks >= pr receive nothing
-        send = tm[t0:t0 + pr].reshape(-1)         # contiguous: [pr][n_local * per]
-        in_split = [n_local * per if r < pr else 0 for r in range(world)]
-        out_split = [n_local * per if rank < pr else 0] * world
+        send = tm[t0:t0 + pr].reshape(-1)         # contiguous: [pr][n_local * pitch]
+        in_split = [blk if r < pr else 0 for r in range(world)]
+        out_split = [blk if rank < pr else 0] * world
         out = recv[b] if rank < pr else recv[b][:0]
         return dist.all_to_all_single(out, send, out_split, in_split, group=group, async_op=nbuf > 1)
 
@@ -322,7 +339,8 @@ def _marginal_planes(scores, alphas, group, ops, overlap):
             work[b].wait()                        # the compute stream waits for run k's exchange
             work[b] = None
         if k * world + rank < T:
-            q_own[k] = ops.kth(recv[b].reshape(world * n_local, per), ks).reshape(nk, per)
+            rows = recv[b].as_strided((world * n_local, per), (pitch, 1))        # (rows with the senders' pitch)
+            q_own[k] = ops.kth(rows, ks).reshape(nk, per)
 
     for k in range(runs):
         b = k % nbuf
@@ -361,7 +379,7 @@ def marginal_qhat(scores, alphas, group=None, ops=None, stage_bytes=4 << 30, ove
     ops = ops or HipOps
     n_local, cells = scores.shape[0], tuple(scores.shape[1:])
     world = torch.distributed.get_world_size(group) if group is not None else 1
-    tmajor = _is_time_major(scores) and not scores.is_contiguous()
+    tmajor = _is_time_major(scores) and not scores.is_contiguous() and cells[0] > 1
     if world == 1:
         ks = _ranks(n_local, alphas)
         if tmajor:                                # plane by plane: each [n_local, *rest] is contiguous

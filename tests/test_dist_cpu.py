@@ -90,6 +90,11 @@ def _worker(rank, world, port, n_local, shape, slabs, out_dir):
         for ov in (False, True):
             q_tm = pipeline.marginal_qhat(tm, ALPHAS, group=dist.group.WORLD, ops=CpuOps, overlap=ov)
             assert q_tm.shape == qm.shape and torch.equal(q_tm, qm), ov
+        tmp = pipeline.time_major(n_local, mine.shape[1:], pad=5)          # samples of a plane 5 floats further apart than
+        tmp.copy_(mine.abs())                                              # a plane is long: the pad travels with the plane
+        assert pipeline._is_time_major(tmp) and tmp.stride(0) == mine[0, 0].numel() + 5
+        for ov in (False, True):
+            assert torch.equal(pipeline.marginal_qhat(tmp, ALPHAS, group=dist.group.WORLD, ops=CpuOps, overlap=ov), qm), ov
         one = pipeline.time_major(n_local, (1,) + tuple(mine.shape[2:]))       # a single plane: rank 0 owns it, the others idle
         one.copy_(mine.abs()[:, 3:4])
         assert torch.equal(pipeline.marginal_qhat(one, ALPHAS, group=dist.group.WORLD, ops=CpuOps), qm[:, 3:4])
@@ -151,3 +156,6 @@ def test_single_rank_pipeline_equals_whole_tensor_oracle():
     tm = pipeline.time_major(12, t.shape[1:])                 # time-major buffer, no group: plane by plane, same result
     tm.copy_(t.abs())
     assert np.array_equal(pipeline.marginal_qhat(tm, ALPHAS, ops=CpuOps).numpy(), qm)
+    tmp = pipeline.time_major(12, t.shape[1:], pad=7)
+    tmp.copy_(t.abs())
+    assert np.array_equal(pipeline.marginal_qhat(tmp, ALPHAS, ops=CpuOps).numpy(), qm)

@@ -1844,6 +1844,10 @@ def _sharded_worker(rank, world, port, n_local, shape, out_dir):
         tm.copy_(mine.abs())
         for ov in (False, True):
             assert torch.equal(pipeline.marginal_qhat(tm, alphas, group=dist.group.WORLD, overlap=ov), qm), ov
+        tmp = pipeline.time_major(n_local, shape, pad=64, device=dev)    # padded planes: the pad travels with the plane
+        tmp.copy_(mine.abs())
+        for ov in (False, True):
+            assert torch.equal(pipeline.marginal_qhat(tmp, alphas, group=dist.group.WORLD, overlap=ov), qm), ov
         np.save(os.path.join(out_dir, f"q_{rank}.npy"), q.cpu().numpy())
         np.save(os.path.join(out_dir, f"qm_{rank}.npy"), qm.cpu().numpy())
     finally:
@@ -1901,6 +1905,11 @@ def test_time_major_residual_buffer_and_planewise_qhat(gpu):
     assert torch.equal(tm, ref)
     alphas = [0.1, 0.5, 0.9]
     assert torch.equal(pipeline.marginal_qhat(tm, alphas), pipeline.marginal_qhat(ref, alphas))
+    tmp = pipeline.time_major(B, (T - 2, X, Y), pad=64, device=gpu)   # samples of a plane 64 floats further apart
+    tmp.fill_(float("nan"))
+    ns.residual_momentum(v, boundary=True, absolute=True, out=tmp, skip_t_rim=True)
+    assert pipeline._is_time_major(tmp) and tmp.stride(0) == X * Y + 64 and torch.equal(tmp, ref)
+    assert torch.equal(pipeline.marginal_qhat(tmp, alphas), pipeline.marginal_qhat(ref, alphas))
 
 
 @pytest.mark.timeout(300)
