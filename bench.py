@@ -79,7 +79,11 @@ def parse():
     ap.add_argument("--nx", type=int, default=None)
     ap.add_argument("--ny", type=int, default=None)
     ap.add_argument("--slab", type=int, default=0,
-                    help="interior planes per t-slab (c3); 0 = the largest of Nt, Nt/2, Nt/3, 16, 13, 8 whose resident set fits the free HBM")
+                    help="c3: rows per x-slab / interior planes per t-slab; 0 = the largest of N, N/2, N/3, N/4, ... whose "
+                         "resident set fits the free HBM")
+    ap.add_argument("--slab-axis", choices=["x", "t"], default="x",
+                    help="c3: cut the grid into x-slabs (T whole, one halo ROW per side: 2/rows re-read; default) or into "
+                         "t-slabs (two halo PLANES per slab: 2/planes re-read; rounds 1-3)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch samples per rank; strong: --batch samples in total, split over the ranks")
     ap.add_argument("--plumbing-check", action="store_true",
@@ -115,12 +119,13 @@ def launch_plan(gpus, environ, argv, script=None):
     return "run", int(ws)
 
 
-def resident_bytes(B, nt, slab, X, Y):
-    """HBM held by the c3 driver: three input slabs of B + n_slabs - 1 samples with their halo planes + the residual
-    buffer of the slab's interior planes."""
-    slabs = split_slabs(nt, slab)
+def resident_bytes(B, n, slab, other):
+    """HBM held by the c3 driver: three input slabs of B + n_slabs - 1 samples with their two halo planes (t-slabs) or
+    rows (x-slabs) + the residual buffer of the slab's own planes / rows.  ``n``: extent of the slab axis, ``other``:
+    cells per unit of it (X*Y for t-slabs, T*Y for x-slabs)."""
+    slabs = split_slabs(n, slab)
     S = max(slabs)
-    return ((B + len(slabs) - 1) * 3 * (S + 2) + B * S) * X * Y * 4
+    return ((B + len(slabs) - 1) * 3 * (S + 2) + B * S) * other * 4 + B * 256      # (+ the residual rows' pad)
 
 
 def split_slabs(nt, slab):
@@ -243,13 +248,14 @@ def pmc_traffic(args):
     want = {"batch": args.batch, "nt": args.nt, "nx": args.nx, "ny": args.ny}
     if args.config == "c3":
         want["slab"] = args.slab
+        want["slab_axis"] = args.slab_axis
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_hbm_{args.config}.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         w = d.get("workload", {})
-        if all(w.get(k) == v for k, v in want.items()):
+        if all(w.get(k, "t" if k == "slab_axis" else None) == v for k, v in want.items()):
             best = d
     return best
 
@@ -267,20 +273,21 @@ def host_cores():
     return n
 
 
-def cpu_baseline(args, alphas, slab):
+def cpu_baseline(args, alphas, slab, xs=False):
     """The oracle (reference arithmetic: F.conv3d per operator + torch elementwise + numpy
     calibration) on a bounded sample of the same workload, on this box's host cores."""
     import numpy as np
     from oracle import conformal as oc
     from oracle import residuals as orr
-    T = slab + 2
+    # one slab with its two halo planes (t-slabs) / rows (x-slabs), as the device job streams it
+    T, X = (args.nt, slab + 2) if xs else (slab + 2, args.nx)
     dt, dx, dy = 1e-2, 1.0 / args.nx, 1.0 / args.ny
     threads = host_cores()
     torch.set_num_threads(threads)
 
     def run(nb):
         g = torch.Generator().manual_seed(0)
-        v = torch.rand(nb, 3, T, args.nx, args.ny, generator=g) + 0.5
+        v = torch.rand(nb, 3, T, X, args.ny, generator=g) + 0.5
         t0 = time.perf_counter()
         res = orr.ns_momentum(v, dt, dx, dy, boundary=False).contiguous().numpy()
         if args.mode == "joint":
@@ -295,9 +302,9 @@ def cpu_baseline(args, alphas, slab):
     t_probe = run(4)
     nb = int(max(4, min(256, 4 * args.cpu_seconds / max(t_probe, 1e-3))))
     t = run(nb)
-    cells = nb * slab * args.nx * args.ny                 # useful (interior-plane) cells, as in `value`
+    cells = nb * slab * (args.nt if xs else args.nx) * args.ny       # the slab's own rows / planes, as in `value`
     return {"value": cells / t, "unit": "cells/s", "cores": threads, "kind": "port",
-            "sample": f"oracle NS-momentum + {args.mode} calibrate on [{nb},{T},{args.nx},{args.ny}] x3 fields "
+            "sample": f"oracle NS-momentum + {args.mode} calibrate on [{nb},{T},{X},{args.ny}] x3 fields "
                       f"(one slab, {nb}/{args.batch} of the batch), {t:.1f} s on {threads} torch threads"}
 
 
@@ -381,18 +388,28 @@ def main():
     from cp_pre_amd import pipeline
     from cp_pre_amd.residuals import NavierStokes
 
-    B, X, Y = args.batch, args.nx, args.ny
+    B, T, X, Y = args.batch, args.nt, args.nx, args.ny
+    xs = args.slab_axis == "x"
+    # The grid does not fit the HBM next to its residual (C3: 3 x 275 GB of fields), so the job streams SLABS of it, all
+    # samples of a slab at a time (a per-cell std / quantile needs every sample of its cell).  x-slabs (default): the T
+    # axis whole - the kernel marches along it with the planes in registers - and rows [x0, x1) of the grid with one halo
+    # ROW per side (PRE_FLAG_HALO_X): 2 rows re-read per 128.  t-slabs (rounds 1-3): planes [t0, t1) with one halo
+    # PLANE per side: 2 planes re-read per 16, 12 % more input traffic.
+    n_axis, other = (X, T * Y) if xs else (T, X * Y)
     free = torch.cuda.mem_get_info(dev)[0]
     if not args.slab:
-        # fewer, thicker slabs re-read fewer halo planes (64 planes: 16 -> 4 slabs, 13 -> 5, 8 -> 8); the resident
-        # set of S = 16 at the full batch is 301 GB of the 309 GB the device reports, so it is taken only if it fits.
-        # Smaller per-rank batches (--scaling strong, --batch) afford thicker slabs, up to the whole T axis (no halo).
+        # fewer, thicker slabs re-read fewer halo rows / planes; the resident set must fit the free HBM (t-slabs of 16
+        # planes at the full batch: 301 GB of the 309 GB the device reports; x-slabs of 128 rows: 279 GB).
+        # Smaller per-rank batches (--scaling strong, --batch) afford thicker slabs, up to the whole axis (no halo).
         # sharded marginal CP: the exchange receives ONE plane of all ranks' samples at a time (no send staging: the
         # residual is written time-major, pipeline.time_major)
-        extra = 4 * world * B * X * Y if (args.mode == "marginal" and world > 1) else 0
+        per_plane = (X * Y if not xs else (n_axis // 4 + 2) * Y)
+        extra = 4 * world * B * per_plane if (args.mode == "marginal" and world > 1) else 0
         extra += (1 << 30) if group is not None else 0                 # headroom for RCCL's own scratch beyond the warm-up collective
-        cands = [c for c in (args.nt, (args.nt + 1) // 2, (args.nt + 2) // 3, 16, 13, 8) if 0 < c <= args.nt]
-        idx = next((i for i, c in enumerate(cands) if resident_bytes(B, args.nt, c, X, Y) + extra <= free - (4 << 30)),
+        div = [n_axis, (n_axis + 1) // 2, (n_axis + 2) // 3, (n_axis + 3) // 4]
+        cands = [c for c in (div + ([96, 64, 32, 16] if xs else [16, 13, 8])) if 0 < c <= n_axis]
+        cands = sorted(set(cands), reverse=True)
+        idx = next((i for i, c in enumerate(cands) if resident_bytes(B, n_axis, c, other) + extra <= free - (4 << 30)),
                    len(cands) - 1)
         if group is not None:
             # the ranks must stream the SAME slabs (the per-slab collectives carry one slab's cells): free memory differs
@@ -401,17 +418,18 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
             idx = int(t.item())
         args.slab = cands[idx]
-    slabs = split_slabs(args.nt, args.slab)                   # interior planes per slab position
+    slabs = split_slabs(n_axis, args.slab)                    # rows (x) / interior planes (t) per slab position
     n_slabs, S = len(slabs), max(slabs)
     alphas = [float(a) for a in icp.ALPHA_LEVELS]
     dt, dx, dy = 1e-2, 1.0 / X, 1.0 / Y
     ns = NavierStokes(dt, dx, dy, nu=1e-3)
 
-    # resident synthetic slab: vars[:, i] views of one [B,3,S+2,X,Y] tensor, like the reference's `vars`
+    # resident synthetic slab: vars[:, i] views of one [B,3,S+2,X,Y] (t-slabs) or [B,3,T,S+2,Y] (x-slabs) tensor, like
+    # the reference's `vars`
     torch.manual_seed(1234 + rank)
     # n_slabs - 1 extra samples: slab position s reads the batch window [s, s + B), so no two slab passes of a
     # step see the same input (and no layer of the memory system could serve one from another)
-    need = resident_bytes(B, args.nt, args.slab, X, Y)
+    need = resident_bytes(B, n_axis, args.slab, other)
     short = need > free - (2 << 30)
     if short:
         print(f"bench.py: --slab {args.slab} needs {need / 1e9:.0f} GB resident, {free / 1e9:.0f} GB free", file=sys.stderr, flush=True)
@@ -421,23 +439,31 @@ def main():
         short = bool(t.item())
     if short:
         return 2
-    vars_ = torch.empty(B + n_slabs - 1, 3, S + 2, X, Y, dtype=torch.float32, device=dev)
+    vars_ = torch.empty((B + n_slabs - 1, 3, T, S + 2, Y) if xs else (B + n_slabs - 1, 3, S + 2, X, Y),
+                        dtype=torch.float32, device=dev)
     for i in range(3):
         synth_(vars_[:, i], 100 * rank + 20 + i)
-    # residual buffer: the slab's INTERIOR planes only (the slab's first and last plane are halo planes that every
-    # consumer would crop: they are neither computed nor stored, PRE_FLAG_OUT_INTERIOR_T)
-    res_buf = torch.empty(B * S * (X * Y + 64), dtype=torch.float32, device=dev)      # (room for either padded layout)
+    # residual buffer: the slab's OWN rows / planes only (its first and last row / plane are halo: read by the kernel,
+    # neither computed nor stored - PRE_FLAG_HALO_X / PRE_FLAG_OUT_INTERIOR_T)
+    def rshape(sl):
+        return (B, T, sl, Y) if xs else (B, sl, X, Y)
+    plane = lambda sl: (sl * Y) if xs else (X * Y)           # cells of one time plane of the residual
+    res_buf = torch.empty(B * (other * S + 64 * (T if xs else S)), dtype=torch.float32, device=dev)      # (room for either padded layout)
     if args.mode == "marginal" and group is not None:
-        # time-major [sl][B][X][Y] seen as [B,sl,X,Y]: plane t of all local samples is one contiguous block, the send
-        # block of the all-to-all that hands plane t to rank t % world (pipeline.marginal_qhat: no pack copy)
+        # time-major [planes][B][plane] seen as [B,planes,..]: plane t of all local samples is one contiguous block, the
+        # send block of the all-to-all that hands plane t to rank t % world (pipeline.marginal_qhat: no pack copy)
         # (samples of a plane 64 floats further apart than a plane is long: profiles/r03/row_pitch.txt)
-        res_of = {sl: res_buf.as_strided((B, sl, X, Y), (X * Y + 64, B * (X * Y + 64), Y, 1)) for sl in set(slabs)}
+        res_of = {sl: res_buf.as_strided(rshape(sl), (plane(sl) + 64, B * (plane(sl) + 64), Y, 1)) for sl in set(slabs)}
     elif args.mode == "marginal":
         # rows 64 floats further apart than they are long: a power-of-two distance between the rows of a cell's column
-        # (16 x 512 x 512 cells) costs the per-cell select ~10 % (pipeline.row_padded, profiles/r03/row_pitch.txt)
-        res_of = {sl: res_buf.as_strided((B, sl, X, Y), (sl * X * Y + 64, X * Y, Y, 1)) for sl in set(slabs)}
+        # (2^22 cells) costs the per-cell select ~10 % (pipeline.row_padded, profiles/r03/row_pitch.txt)
+        res_of = {sl: res_buf.as_strided(rshape(sl), (rshape(sl)[1] * plane(sl) + 64, plane(sl), Y, 1)) for sl in set(slabs)}
     else:
-        res_of = {sl: res_buf[:B * sl * X * Y].view(B, sl, X, Y) for sl in set(slabs)}
+        res_of = {sl: res_buf[:B * rshape(sl)[1] * plane(sl)].view(rshape(sl)) for sl in set(slabs)}
+    # cells within `crop` of the slab's rim are excluded from the scores: the y rim always; x-slabs: the t rim (the
+    # grid's own: every plane is computed, zero padding beyond, as the reference's conv3d has it), no rows (all own);
+    # t-slabs: the x rim, no planes (all interior)
+    crop = (1, 0, 1) if xs else (0, 1, 1)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(n_slabs * (args.steps + args.warmup + 2))]          # (+2: the full-score-pass steps after the timed loop)
@@ -453,14 +479,18 @@ def main():
             res = res_of[sl]
             e0, e1 = ev[k * n_slabs + s]
             e0.record()
-            ns.residual_momentum(vars_[s:s + B, :, :sl + 2], boundary=True, absolute=(args.mode == "marginal"), out=res,
-                                 skip_t_rim=True)
+            if xs:
+                ns.residual_momentum(vars_[s:s + B, :, :, 1:sl + 1], boundary=True, absolute=(args.mode == "marginal"), out=res,
+                                     halo_x=True)
+            else:
+                ns.residual_momentum(vars_[s:s + B, :, :sl + 2], boundary=True, absolute=(args.mode == "marginal"), out=res,
+                                     skip_t_rim=True)
             e1.record()
             ev_used.append((k, sl, e0, e1))
             if jc is not None:
-                jc.add_slab(res, crop=(0, 1, 1))                         # every plane of `res` is an interior plane
+                jc.add_slab(res, crop=crop)
             else:
-                q = pipeline.marginal_qhat(res, alphas, group=group)     # [10, sl, X, Y]
+                q = pipeline.marginal_qhat(res, alphas, group=group)     # [10, *slab cells]
         return jc.finish(alphas) if jc is not None else q
 
     def sync():
@@ -482,7 +512,7 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    cells_per_step = B * sum(slabs) * X * Y * world                   # whole job, all ranks
+    cells_per_step = B * sum(slabs) * other * world                   # whole job, all ranks
     value = cells_per_step * args.steps / elapsed
 
     # The branch-and-bound score pass makes `value` depend on the data (how much of the residual the bounds let it
@@ -507,8 +537,8 @@ def main():
         kms = sum(d for _, d in timed) / len(timed)
         # 3 fields read + 1 residual written = 16 B per cell the launch COMPUTES (its interior
         # planes); the two halo planes each slab re-reads are overhead, reported apart
-        launch_bytes = sum(16 * B * sl * X * Y for sl, _ in timed) / len(timed)
-        halo_bytes = sum((12 * (sl + 2) + 4 * sl) * B * X * Y for sl, _ in timed) / len(timed)
+        launch_bytes = sum(16 * B * sl * other for sl, _ in timed) / len(timed)
+        halo_bytes = sum((12 * (sl + 2) + 4 * sl) * B * other for sl, _ in timed) / len(timed)
         achieved = launch_bytes / (kms * 1e-3) / 1e9
         pmc = pmc_traffic(args)
         out = {
@@ -516,15 +546,17 @@ def main():
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32",
-            "data": SYNTH + "; one resident t-slab, slab position s reads the batch window [s, s+B) of it",
+            "data": SYNTH + f"; one resident {'x' if xs else 't'}-slab, slab position s reads the batch window [s, s+B) of it",
             "config": {"workload": f"C3 2D Navier-Stokes momentum residual [{B},{args.nt},{X},{Y}] x3 fields per rank, "
-                                   f"{args.mode} CP, 10 alpha levels; streamed as {n_slabs} t-slabs of {slabs} interior "
-                                   f"planes (+2 halo planes each)",
-                       "mode": args.mode, "batch_per_rank": B, "slab": args.slab, **par,
+                                   f"{args.mode} CP, 10 alpha levels; streamed as " +
+                                   (f"{n_slabs} x-slabs of {slabs} rows (+2 halo rows each), T whole" if xs else
+                                    f"{n_slabs} t-slabs of {slabs} interior planes (+2 halo planes each)"),
+                       "mode": args.mode, "batch_per_rank": B, "slab_axis": args.slab_axis, "slab": args.slab, **par,
                        # the per-rank slab plan: resident bytes, and what the t-slab halo re-reads cost (strong scaling
                        # shrinks the per-rank batch, which affords thicker slabs - up to the whole T axis, no halo)
-                       "slab_plan": {"slabs": slabs, "resident_gb": round(resident_bytes(B, args.nt, args.slab, X, Y) / 1e9, 1),
-                                     "input_planes_read_per_plane_computed": round(sum(sl + 2 for sl in slabs) / sum(slabs), 3)},
+                       "slab_plan": {"axis": args.slab_axis, "slabs": slabs,
+                                     "resident_gb": round(resident_bytes(B, n_axis, args.slab, other) / 1e9, 1),
+                                     "input_read_per_cell_computed": round(sum(sl + 2 for sl in slabs) / sum(slabs), 4)},
                        "scaling_note": ("weak: every rank streams its own 4096-sample batch" if args.scaling == "weak" else
                                         "strong: one calibration set split over the ranks (north_star's '>= 6x 1->8 GPUs' "
                                         "speaks of this curve)"),
@@ -533,7 +565,7 @@ def main():
                        "inputs": "resident in HBM", "host_fed_bound_cells_per_s": 63e9 / 12.0,
                        **({"score_pass": "branch-and-bound (same scores as the full pass for the same modulation; adaptive: "
                                          "flagged samples and wasteful streams take the full pass)"
-                           if not args.no_prune and pipeline.HipOps.can_prune(res_of[slabs[0]], (0, 1, 1)) else "full"}
+                           if not args.no_prune and pipeline.HipOps.can_prune(res_of[slabs[0]], crop) else "full"}
                           if args.mode == "joint" else {})},
             # data dependence of `value`: share of the score pass's segments that were read (the synthetic residuals are
             # noise-like: tight bounds), and the same step with the full score pass (--no-prune)
@@ -550,7 +582,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             del vars_, res_buf, res_of
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args, alphas, S)
+            out["cpu_baseline"] = cpu_baseline(args, alphas, S, xs)
         print(json.dumps(out), flush=True)
     return done()
 

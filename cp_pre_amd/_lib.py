@@ -19,6 +19,7 @@ PRE_OK, PRE_E_NULL, PRE_E_SHAPE, PRE_E_UNSUPPORTED, PRE_E_RANGE = 0, -1, -2, -3,
 PRE_FLAG_ABS = 1
 PRE_FLAG_INTERIOR_T = 2
 PRE_FLAG_OUT_INTERIOR_T = 4
+PRE_FLAG_HALO_X = 8
 _ERR = {PRE_E_NULL: "null pointer / bad size", PRE_E_SHAPE: "unsupported shape",
         PRE_E_UNSUPPORTED: "operator kernels not star-shaped or layout not streamable",
         PRE_E_RANGE: "rank / crop out of range"}

@@ -332,6 +332,9 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
     bool ldown = inb;
     if constexpr (BC) {
         if (x == g.X && y < g.Yc) { xl = bc.xhi; ghost = bc.vxhi; ldown = bc.xhi >= 0; }
+    } else {
+        // PRE_FLAG_HALO_X, partial last tile: row X is real data and the x+ neighbour of row X-1 (loaded, never stored)
+        if ((g.flags & PRE_FLAG_HALO_X) && x == g.X && y < g.Yc) ldown = true;
     }
     int t0 = ts * g.tSeg;
     int t1 = min(t0 + g.tSeg, g.T);
@@ -343,7 +346,9 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
     // halo-row duty: thread-row 0 fetches the row above the tile, thread-row NR-1 the row below
     const bool top = (ty == 0), bot = (ty == NR - 1);
     int hx = top ? x - 1 : x + 1;
-    bool hrow = (top || bot) && (hx >= 0) && (hx < g.X) && (y < g.Yc);
+    // PRE_FLAG_HALO_X: rows -1 and X of the views exist (an x-slab of a larger grid): read, not zero padding
+    const bool halox = (g.flags & PRE_FLAG_HALO_X) != 0;
+    bool hrow = (top || bot) && (halox ? (hx >= -1 && hx <= g.X) : (hx >= 0 && hx < g.X)) && (y < g.Yc);
     float hfill = 0.f;          // value of an out-of-domain halo row
     const int hslot = top ? 0 : NR + 1;
     // y-halo duty: the edge lanes of each wave (and of the tile) fetch one scalar
@@ -721,6 +726,8 @@ int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const
     // A SHORT contiguous axis (the surrogate's Nt = 10..40 in its native [BS,F,Nx,Ny,Nt] layout) would leave most
     // lanes of a row idle.  When the next axis is contiguous with it (stride == extent) the two are merged into
     // one long axis for the flat form of the kernel: only their product has to be a multiple of 4.
+    if ((flags & PRE_FLAG_HALO_X) && relabeled) return PRE_E_UNSUPPORTED;      // the halo rows are on the caller's x axis
+    if (flags & PRE_FLAG_HALO_X) allow_flat = false;                           // (the flat form pads x with zeros)
     bool flat = allow_flat && D[p[2]] < 96 && ostride(p[1]) == D[p[2]] && (D[p[1]] * D[p[2]]) % 4 == 0 && D[p[1]] > 1;
     for (int i = 0; i < nf; ++i) flat = flat && stride(fs[i], p[1]) == D[p[2]];
     g.flat = flat;
@@ -784,6 +791,7 @@ int pre_star_try_linear1(const pre_field_t *in, const pre_out_t *out, const floa
     int rc = prepare(g, rel, fs, 1, out, B, T, X, Y, flags, stars, 1, true);
     if (rc) return rc;
     *tail_axis = -1;
+    if (g.Yc < g.Y && (flags & PRE_FLAG_HALO_X)) return PRE_E_UNSUPPORTED;      // (the tail pass pads x with zeros)
     if (g.Yc < g.Y) {
         *tail_axis = rel == 0 ? 2 : (rel == 1 ? 0 : 1);
         *tail_from = g.Yc;
@@ -838,7 +846,7 @@ int pre_residual_burgers_f32(const float *u, const int64_t in_strides[3], float 
                              int64_t B, int64_t T, int64_t X, int flags, void *stream)
 {
     if (!u || !in_strides || !out || !out_strides || !K_t || !K_x || !K_xx) return PRE_E_NULL;
-    if (flags & PRE_FLAG_OUT_INTERIOR_T) return PRE_E_UNSUPPORTED;     // [B,T,X]: the marched axis is the batch
+    if (flags & (PRE_FLAG_OUT_INTERIOR_T | PRE_FLAG_HALO_X)) return PRE_E_UNSUPPORTED;     // [B,T,X]: the marched axis is the batch
     // [B,T,X] -> [1, B, T, X]; 3x3 kernel (a over Nt, b over Nx) -> dense27 index (1, a, b)
     pre_field_t f{u, 0, in_strides[0], in_strides[1], in_strides[2]};
     pre_out_t o{out, 0, out_strides[0], out_strides[1], out_strides[2]};
@@ -969,7 +977,7 @@ int pre_spatial2d_bc_f32(const float *in, const int64_t in_strides[3], float *ou
                          const float *K, const pre_bc_t *bc, int64_t B, int64_t X, int64_t Y, int flags, void *stream)
 {
     if (!in || !out || !in_strides || !out_strides || !K) return PRE_E_NULL;
-    if (flags & PRE_FLAG_OUT_INTERIOR_T) return PRE_E_UNSUPPORTED;
+    if (flags & (PRE_FLAG_OUT_INTERIOR_T | PRE_FLAG_HALO_X)) return PRE_E_UNSUPPORTED;
     // planes [B,X,Y] -> [1,B,X,Y]: the plane axis is the tap-free marching axis
     pre_field_t f{in, 0, in_strides[0], in_strides[1], in_strides[2]};
     pre_out_t o{out, 0, out_strides[0], out_strides[1], out_strides[2]};
@@ -992,7 +1000,7 @@ int pre_spatial2d_linear2_bc_f32(const float *in0, const int64_t s0[3], const fl
                                  const pre_bc_t *bc, int64_t B, int64_t X, int64_t Y, int flags, void *stream)
 {
     if (!in0 || !in1 || !out || !s0 || !s1 || !out_strides || !K0 || !K1) return PRE_E_NULL;
-    if (flags & PRE_FLAG_OUT_INTERIOR_T) return PRE_E_UNSUPPORTED;
+    if (flags & (PRE_FLAG_OUT_INTERIOR_T | PRE_FLAG_HALO_X)) return PRE_E_UNSUPPORTED;
     pre_field_t f0{in0, 0, s0[0], s0[1], s0[2]}, f1{in1, 0, s1[0], s1[1], s1[2]};
     pre_out_t o{out, 0, out_strides[0], out_strides[1], out_strides[2]};
     if (f0.sY != 1 || f1.sY != 1 || o.sY != 1) return PRE_E_UNSUPPORTED;

@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) wgrad27_kernel(const float *__restrict__ 
 
 extern "C" {
 
-int pre_abi_version(void) { return 6; }
+int pre_abi_version(void) { return 7; }
 
 int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *tap_w, const int32_t *tap_off, int ntaps,
                       int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)
@@ -507,6 +507,7 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *
             box[tail_axis] = (int)tail_from;       // streaming kernel done; <= 3 leftover columns follow
         }
     }
+    if (flags & PRE_FLAG_HALO_X) return PRE_E_UNSUPPORTED;      // only the streaming star kernel reads the halo rows
 
     // whole domain, input and output share a unit-stride axis long enough to fill a tile row: relabel it to be
     // the last one (the tap list is symmetric in the axes) and group the taps by (dt, dx) row
@@ -691,6 +692,7 @@ int pre_stencil2d_f32(const float *in, const int64_t in_strides[3], float *out, 
 {
     if (!in || !in_strides || !out || !out_strides || (ntaps > 0 && !tap_off)) return PRE_E_NULL;
     if (ntaps < 0 || ntaps > MAX_TAPS) return PRE_E_SHAPE;
+    if (flags & PRE_FLAG_HALO_X) return PRE_E_UNSUPPORTED;      // (the kernel's row axis is the caller's Nt here)
     // [B,T,X] with taps (dt,dx)  ==  [1,B,T,X] with taps (0,dt,dx): the batch axis becomes the
     // (tap-free) marching axis, Nt the row axis and Nx the contiguous axis.
     int32_t off3[3 * MAX_TAPS];

@@ -122,7 +122,7 @@ class NavierStokes(_Residual2D):
             res = _on_device((u, v), lambda u, v: self.D_x(u) + ratio * self.D_y(v))
         return _finish(res, boundary, _CROP3, absolute, done_abs)
 
-    def residual_momentum(self, vars, boundary=False, absolute=False, out=None, skip_t_rim=False):
+    def residual_momentum(self, vars, boundary=False, absolute=False, out=None, skip_t_rim=False, halo_x=False):
         """``out``: optional preallocated device tensor [BS,Nt,Nx,Ny] for the uncropped residual
         (fused route only; lets a streaming driver reuse one buffer).  ``skip_t_rim``: the caller
         crops the first and last time plane anyway, so they need not be computed or stored
@@ -130,7 +130,12 @@ class NavierStokes(_Residual2D):
         also be a [BS,Nt-2,Nx,Ny] tensor (contiguous, or any batch / time strides over dense planes): it then receives
         the interior planes only
         (``PRE_FLAG_OUT_INTERIOR_T``; what a t-slab driver that feeds slabs with their two halo planes
-        wants) and the result is that tensor, cropped in x and y unless ``boundary``."""
+        wants) and the result is that tensor, cropped in x and y unless ``boundary``.
+        ``halo_x``: ``vars`` is an x-slab ``full[:, :, :, x0:x1]`` (1 <= x0, x1 <= Nx - 1) of a larger grid whose rows
+        x0 - 1 and x1 lie in the same memory: they are read as the x-neighbours of the slab's first and last row instead
+        of the zero padding (``PRE_FLAG_HALO_X``), so the slab's residual rows are those of the whole grid.  What an
+        x-slab driver wants: the T axis stays whole and a slab re-reads 2 rows of Nx_slab instead of 2 planes of
+        Nt_slab.  Fused route only (raises otherwise)."""
         u, v, p = vars[:, 0], vars[:, 1], vars[:, 2]
         dt, dx, dy, nu = self.dt, self.dx, self.dy, self.nu
         D_t, D_x, D_y, D_xx_yy = self.D_t, self.D_x, self.D_y, self.D_xx_yy
@@ -157,20 +162,25 @@ class NavierStokes(_Residual2D):
                 if interior and not (dense_planes and origin is None and not _dispatch.needs_grad(u, v, p)):
                     raise ValueError("an interior-plane out needs device-resident fields, dense [Nx,Ny] planes and no autograd")
                 flags = (_lib.PRE_FLAG_ABS if absolute else 0) | (_lib.PRE_FLAG_INTERIOR_T if skip_t_rim else 0) | \
-                        (_lib.PRE_FLAG_OUT_INTERIOR_T if interior else 0)
+                        (_lib.PRE_FLAG_OUT_INTERIOR_T if interior else 0) | (_lib.PRE_FLAG_HALO_X if halo_x else 0)
+                if halo_x and (origin is not None or _dispatch.needs_grad(u, v, p) or
+                               any(d.data_ptr() != f.data_ptr() or d.stride(3) != 1 for d, f in zip((du, dv, dp), (u, v, p)))):
+                    raise ValueError("halo_x needs device-resident, Ny-contiguous views of a larger grid and no autograd")
                 fu, fv, fp, fo = _lib.field(du), _lib.field(dv), _lib.field(dp), _lib.field(out)
                 with torch.cuda.device(du.device):
                     ok = _fused_call("pre_residual_ns_momentum_f32", lambda: _lib.load().pre_residual_ns_momentum_f32(
                         ctypes.byref(fu), ctypes.byref(fv), ctypes.byref(fp), ctypes.byref(fo), *ks,
                         float(dt), float(dx), float(dy), float(nu), *du.shape, flags, _lib.stream()))
+                if (interior or halo_x) and not ok:
+                    raise RuntimeError("pre_residual_ns_momentum_f32: an interior-plane out / halo_x needs Ny-contiguous "
+                                       "views and star-shaped operator kernels")
                 if interior:
-                    if not ok:
-                        raise RuntimeError("pre_residual_ns_momentum_f32: an interior-plane out needs Ny-contiguous views "
-                                           "and star-shaped operator kernels")
                     return out if boundary else out[..., 1:-1, 1:-1]
             if ok:
                 res = _attach(_dispatch.from_device(out, origin), (u, v, p), composed, absolute)
                 return _finish(res, boundary, _CROP3, absolute, True)
+        if halo_x:
+            raise RuntimeError("halo_x: only the fused route reads the halo rows")
         return _finish(_on_device((u, v, p), composed), boundary, _CROP3, absolute, False)
 
     def periodic_bc_residual(self, u, wall='right'):

@@ -39,6 +39,14 @@ extern "C" {
                                   planes and keep one residual buffer of the slab's interior.  PRE_E_UNSUPPORTED when
                                   the views are not Y-contiguous (relabelled layouts) or T < 3. */
 
+#define PRE_FLAG_HALO_X 8      /* fused residuals / star stencils: rows x = -1 and x = X of every field view EXIST in memory
+                                  (ptr - sX and ptr + X*sX are readable) and are the x-neighbours of rows 0 and X-1
+                                  instead of the zero padding; `out` holds the X rows.  For streaming drivers that cut
+                                  the grid into x-slabs (T whole, one halo ROW per side: 2/X re-read instead of the 2/T
+                                  halo planes of a t-slab; the reference's conv3d sees the whole grid,
+                                  Utils/ConvOps_2d.py:149).  PRE_E_UNSUPPORTED when the views are not Y-contiguous, the
+                                  taps are not star-shaped, Y % 4 != 0, or on the 1-D / boundary-condition entries. */
+
 /* A strided view of one field [B,T,X,Y] (what `vars[:, i]` or a permuted surrogate
  * output is, Marginal/NS_Residuals_CP.py:282; Other_UQ/Evaluation/PRE_estimations.py:41). */
 typedef struct {
@@ -57,7 +65,7 @@ typedef struct {
     int64_t sB, sT, sX, sY;
 } pre_out_t;
 
-int pre_abi_version(void);     /* 6 */
+int pre_abi_version(void);     /* 7 (v7: PRE_FLAG_HALO_X) */
 
 /* ---- a4/a5/a6: ConvOperator.convolution ---------------------------------------------
  * Utils/ConvOps_2d.py:135-150  F.conv3d(field[:,None], K[None,None], padding=k//2)

@@ -48,7 +48,7 @@ static int cmp_float(const void *a, const void *b) { const float x = *(const flo
 int main(void)
 {
     int failures = 0;
-    EXPECT(pre_abi_version() == 6, "pre_abi_version() == 6");
+    EXPECT(pre_abi_version() == 7, "pre_abi_version() == 7");
 
     /* ---- the reference's kernels: kernel_3d(stencil, axis) with the stencil on slab 1 (Utils/ConvOps_2d.py:67-79) */
     float Kt[27] = {0}, Kx[27] = {0}, Ky[27] = {0}, Kl[27] = {0};
@@ -103,6 +103,25 @@ int main(void)
             want[i] = rx + ry;
         }
         EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-5, "pre_residual_ns_momentum_f32 vs operator-by-operator C loops (<= 1e-5)");
+        /* PRE_FLAG_HALO_X (ABI v7): rows [3, 8) of the same fields as an x-slab whose rows 2 and 8 exist in memory -
+         * the slab's residual rows are the whole grid's (an x-slab driver: T whole, one halo row per side) */
+        {
+            enum { X0 = 3, XS = 5 };
+            const pre_field_t su = {du + X0 * Y, fu.sB, fu.sT, fu.sX, 1}, sv = {dv + X0 * Y, fv.sB, fv.sT, fv.sX, 1},
+                              sp = {dp + X0 * Y, fp.sB, fp.sT, fp.sX, 1};
+            float *dslab;
+            static float hslab[B * T * XS * Y];
+            CHECK_HIP(hipMalloc((void **)&dslab, sizeof hslab));
+            const pre_out_t so = {dslab, (int64_t)T * XS * Y, (int64_t)XS * Y, Y, 1};
+            rc = pre_residual_ns_momentum_f32(&su, &sv, &sp, &so, Kt, Kx, Ky, Kl, dt, dx, dy, nu, B, T, XS, Y, PRE_FLAG_HALO_X, st);
+            CHECK_HIP(hipStreamSynchronize(st));
+            CHECK_HIP(hipMemcpy(hslab, dslab, sizeof hslab, hipMemcpyDeviceToHost));
+            int same = rc == PRE_OK;
+            for (int b = 0; b < B && same; ++b) for (int t = 0; t < T && same; ++t) for (int x = 0; x < XS && same; ++x)
+                same = memcmp(&hslab[((b * T + t) * XS + x) * Y], &got[((b * T + t) * X + X0 + x) * Y], Y * sizeof(float)) == 0;
+            EXPECT(same, "PRE_FLAG_HALO_X: an x-slab with its halo rows == the whole grid's rows, bit for bit");
+            CHECK_HIP(hipFree(dslab));
+        }
         float Kbad[27];
         memcpy(Kbad, Kl, sizeof Kl);
         Kbad[0] = 1.f;                                                             /* a corner tap: off the star */

@@ -1972,3 +1972,80 @@ def test_short_nt_surrogate_layout_flat_form(gpu, T):
     small = torch.rand(2, 3, 7, 22, max(T // 2, 6), generator=g) + 0.5
     got = R.NavierStokes(dt, dx, dy).residual_momentum(small.to(gpu), True)
     assert rel_err(got.cpu().numpy(), orr.ns_momentum(small, dt, dx, dy, boundary=True).numpy()) <= RES_TOL
+
+
+# ---------------------------------------------------------------- x-slabs (round 3): PRE_FLAG_HALO_X
+@pytest.mark.parametrize("X,Y,x0,x1", [(40, 256, 1, 17), (40, 256, 8, 39), (21, 256, 5, 12), (30, 128, 3, 14), (40, 64, 5, 38)])
+def test_x_slab_with_halo_rows_equals_the_whole_grid_rows(gpu, X, Y, x0, x1):
+    """An x-slab driver hands the fused kernel the rows [x0, x1) of a larger grid and says that the rows x0-1 and x1
+    exist (``halo_x`` -> PRE_FLAG_HALO_X): the slab's residual is then the whole grid's residual on those rows, bit for
+    bit (whole and partial 8-row tiles, the 16x32 and 32x16 tile shapes, |.|, an out buffer, the skipped t rim)."""
+    from cp_pre_amd import _dispatch, _lib
+    from cp_pre_amd.convops_2d import ConvOperator
+    from cp_pre_amd.residuals import NavierStokes
+    B, T = 5, 7
+    g = torch.Generator().manual_seed(X * 1000 + Y + x0)
+    v = (torch.rand(B + 1, 3, T, X, Y, generator=g) + 0.5).to(gpu)[:B]      # (memory beyond the last sample's last row)
+    ns = NavierStokes(1e-2, 1.0 / X, 1.0 / Y, nu=1e-3, device=gpu)
+    full = ns.residual_momentum(v, boundary=True)
+    slab = ns.residual_momentum(v[:, :, :, x0:x1], boundary=True, halo_x=True)
+    assert slab.shape == (B, T, x1 - x0, Y) and torch.equal(slab, full[:, :, x0:x1])
+    zero = ns.residual_momentum(v[:, :, :, x0:x1], boundary=True)          # without the flag: zero padding at the cut
+    assert not torch.equal(zero[:, :, 0], full[:, :, x0]) and torch.equal(zero[:, :, 1:-1], full[:, :, x0 + 1:x1 - 1])
+    out = torch.full((B, T, x1 - x0, Y), float("nan"), device=gpu)
+    got = ns.residual_momentum(v[:, :, :, x0:x1], boundary=True, absolute=True, out=out, skip_t_rim=True, halo_x=True)
+    assert got.data_ptr() == out.data_ptr() and torch.equal(out[:, 1:-1], full[:, 1:-1, x0:x1].abs())
+    # a single star-shaped operator through pre_stencil3d_f32 (the wave's additive kernel)
+    D = ConvOperator(("x", "y"), 2, device=gpu)
+    D.kernel = D.kernel + 0.25 * ConvOperator("t", 2, device=gpu).kernel
+    u = v[:, 0]
+    assert torch.equal(_dispatch._xcorr_impl(u[:, :, x0:x1], D.kernel, 3, flags=_lib.PRE_FLAG_HALO_X), D(u)[:, :, x0:x1])
+
+
+def test_x_slab_flag_is_refused_where_no_kernel_reads_the_halo(gpu):
+    """PRE_E_UNSUPPORTED (never a silently zero-padded result): off-star taps, a width that leaves tail columns, the
+    1-D entry, a T-contiguous (relabelled) view."""
+    from cp_pre_amd import _dispatch, _lib
+    from cp_pre_amd.convops_1d import ConvOperator as C1
+    from cp_pre_amd.convops_2d import ConvOperator
+    from cp_pre_amd.residuals import NavierStokes
+    g = torch.Generator().manual_seed(3)
+    u = torch.rand(3, 6, 20, 66, generator=g).to(gpu)
+    dense = torch.rand(3, 3, 3, generator=g)
+    for field, k, nd in ((u[:, :, 2:9, :64], dense, 3), (u[:, :, 2:9], ConvOperator("x", 2, device=gpu).kernel, 3),
+                         (u[0][:, 2:9, :64], C1("x", 2, device=gpu).kernel, 2)):
+        with pytest.raises(RuntimeError, match="-3"):
+            _dispatch._xcorr_impl(field, k, nd, flags=_lib.PRE_FLAG_HALO_X)
+    v = (torch.rand(2, 3, 16, 16, 8, generator=g) + 0.5).to(gpu).permute(0, 1, 4, 2, 3)        # Nt fastest
+    with pytest.raises((RuntimeError, ValueError)):
+        NavierStokes(1e-2, 1 / 16, 1 / 16, device=gpu).residual_momentum(v[:, :, :, 2:9], boundary=True, halo_x=True)
+
+
+@pytest.mark.parametrize("B,T,X,Y,rows", [(40, 9, 34, 64, 16), (300, 18, 130, 512, 64)])
+def test_x_slab_stream_equals_whole_grid_calibration(gpu, B, T, X, Y, rows):
+    """The x-slab driver of bench.py (rows [x0, x1) + halo rows, T whole, crop (1, 0, 1)) against the whole grid in one
+    piece (crop (1, 1, 1)): the same joint scores / q-hat (moment sums in another order: 1e-6) and, slab by slab, the
+    whole grid's per-cell q-hat bit for bit.  The second shape is large enough for the branch-and-bound score pass."""
+    from cp_pre_amd import pipeline
+    from cp_pre_amd.residuals import NavierStokes
+    g = torch.Generator().manual_seed(B + X)
+    v = (torch.rand(B, 3, T, X, Y, generator=g) * 0.2 + 0.9).to(gpu)
+    ns = NavierStokes(1e-2, 1.0 / X, 1.0 / Y, nu=1e-3, device=gpu)
+    alphas = [0.1, 0.5, 0.9]
+    whole = ns.residual_momentum(v, boundary=True)
+    jc0 = pipeline.JointCalibration(B, gpu, prune=False)
+    jc0.add_slab(whole, crop=(1, 1, 1))
+    q0 = jc0.finish(alphas)
+    qm0 = pipeline.marginal_qhat(whole.abs(), alphas)
+    jc = pipeline.JointCalibration(B, gpu)
+    assert (X - 2) % rows == 0
+    buf = torch.empty(B, T, rows, Y, device=gpu)
+    for x0 in range(1, X - 1, rows):
+        res = ns.residual_momentum(v[:, :, :, x0:x0 + rows], boundary=True, out=buf, halo_x=True)
+        assert torch.equal(res, whole[:, :, x0:x0 + rows])
+        if B >= 256:
+            assert pipeline.HipOps.can_prune(res, (1, 0, 1))
+        jc.add_slab(res, crop=(1, 0, 1))
+        assert torch.equal(pipeline.marginal_qhat(res.abs(), alphas), qm0[:, :, x0:x0 + rows])
+    q = jc.finish(alphas)
+    assert torch.allclose(jc.scores, jc0.scores, rtol=1e-6, atol=0) and torch.allclose(q, q0, rtol=QHAT_TOL, atol=0)

@@ -88,7 +88,7 @@ def hbm_report(tag, fetch_src, write_src, kernel, cmd, workload, alg_bytes, halo
         o.write(f"\n{kernel} per launch (average over the profiled launches){note}:\n")
         o.write(f"   algorithmic bytes (SURVEY 8d: 4*(F+1) B x cells computed)       {alg_bytes/1e9:.3f} GB\n")
         if halo_bytes:
-            o.write(f"   + the two halo planes each t-slab re-reads (overhead)            {halo_bytes/1e9:.3f} GB\n")
+            o.write(f"   + the two halo rows / planes each slab re-reads (overhead)       {halo_bytes/1e9:.3f} GB\n")
         o.write(f"   measured HBM traffic  read {f/1e9:.3f} GB + write {w/1e9:.3f} GB = {(f+w)/1e9:.3f} GB  = {(f+w)/alg_bytes:.4f} x algorithmic")
         if halo_bytes:
             o.write(f", {(f+w)/halo_bytes:.4f} x (algorithmic + slab halo)")
@@ -104,13 +104,19 @@ try:                                                     # the slab size the pro
     slab = int(json.loads(bench_line("gpurun_out/prof/bench_fetch.log"))["config"]["slab"])
 except Exception:
     pass
-slabs = bench.split_slabs(c3[1], slab)
-cells_xy = c3[0] * c3[2] * c3[3]
+axis = "t"
+try:
+    axis = json.loads(bench_line("gpurun_out/prof/bench_fetch.log"))["config"].get("slab_axis", "t")
+except Exception:
+    pass
+slabs = bench.split_slabs(c3[2] if axis == "x" else c3[1], slab)
+cells_xy = c3[0] * (c3[1] * c3[3] if axis == "x" else c3[2] * c3[3])        # batch x cells per row (x-slabs) / plane (t-slabs)
 hbm_report("c3", "fetch", "write", MK, "--steps 1 --warmup 0 --no-cpu-baseline",
-           {"batch": c3[0], "nt": c3[1], "nx": c3[2], "ny": c3[3], "slab": slab},
+           {"batch": c3[0], "nt": c3[1], "nx": c3[2], "ny": c3[3], "slab": slab, "slab_axis": axis},
            sum(16 * sl * cells_xy for sl in slabs) / len(slabs),
            sum((12 * (sl + 2) + 4 * sl) * cells_xy for sl in slabs) / len(slabs),
-           note=f" [4096,S+2,512,512] x3 -> [4096,S,512,512], S in {slabs}")
+           note=(f" [4096,64,S+2,512] x3 -> [4096,64,S,512], S in {slabs}" if axis == "x" else
+                 f" [4096,S+2,512,512] x3 -> [4096,S,512,512], S in {slabs}"))
 for c in ("c2", "c4", "c5"):
     cfg = bench.CONFIGS[c]
     shp = cfg["shape"]
@@ -131,7 +137,7 @@ for tag, srcs, mode in (("pmc_sq_c3.txt", ("sq1", "sq2"), "joint"), ("pmc_sq_c3_
     with open(f"{out}/{tag}", "w") as o:
         o.write(f"rocprofv3 --pmc <counters, one group per pass> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --batch 1024"
                 f"{' --mode marginal' if mode == 'marginal' else ''}\n"
-                f"(C3 {mode}, quarter batch: [1024,S+2,512,512] per launch, S = the slab size of the run; per-dispatch sums over all SEs/XCDs, averaged over dispatches;\n"
+                f"(C3 {mode}, quarter batch: 1024 samples per launch, the slab plan of the run; per-dispatch sums over all SEs/XCDs, averaged over dispatches;\n"
                 f" FETCH_SIZE in KiB, x2 for bytes on gfx950)\n\n")
         kernels = sorted({k for (_, k) in sq if k.startswith(OURS)})
         for k in kernels:
