@@ -683,6 +683,8 @@ int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st, const BCInfo
     // 12x64 (768 threads: 3 waves per SIMD where the 82 KB tile of 8x64 leaves induction 2) -5..-8 %;
     // own cells prefetched three planes ahead instead of two on induction (200 VGPRs): within the +-5 % run-to-run noise;
     // induction capped at 128 VGPRs (17 dwords spilled) so that two of its 80 KB workgroups share a CU: -30 %
+    // round 3, x-slabs (64-plane marches: x-neighbour tiles drift apart, 8 % of the input is fetched twice): NS momentum
+    // 16x64 (1024 threads) 50.5 ms, 16x32 48.5, 32x16 50.7 against 47.4 for 8x64 (gpurun_out/r3b/nr_*.log)
     if (g.Y >= 192) return launch_tiled<Fn, 8, 64, BC>(g, prm, st, bc);
     if (g.Y >= 96) return launch_tiled<Fn, 16, 32, BC>(g, prm, st, bc);
     return launch_tiled<Fn, 32, 16, BC>(g, prm, st, bc);
