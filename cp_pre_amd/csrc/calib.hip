@@ -130,32 +130,48 @@ __device__ __forceinline__ void ms_butterfly(unsigned int (&m)[US], int lane)
 
 // US samples starting at sample i of one thread's column: ms_load issues the loads, ms_use adds them to the sums and
 // writes the per-sample wave maxima.
-template <int TCH, int US>
-__device__ __forceinline__ void ms_load(const float *__restrict__ a, long long row_stride, long long plane, int i, int nt, float (&v)[US][TCH])
+// one plane of one sample at the wave-uniform address `p` (a buffer descriptor assembled by scalar instructions), this lane's
+// cell at byte offset `cb`: no vector address arithmetic (the compiler otherwise spends a 64-bit vector add on every load)
+__device__ __forceinline__ float ms_cell(const float *p, unsigned int cb, unsigned int plane_bytes)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, plane_bytes, 0x00020000);
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)cb, 0, 0));
+}
+
+// (`au`: wave-uniform pointer to plane t0 of sample 0, `c`: BYTE offset of this lane's cell - the loads then take a scalar base
+// and a 32-bit lane offset, with no 64-bit vector address arithmetic per load.  FULL: the chunk has all TCH planes - no selects.)
+template <int TCH, int US, bool FULL>
+__device__ __forceinline__ void ms_load(const float *__restrict__ au, unsigned int c, long long row_stride, long long plane, int i, int nt,
+                                        float (&v)[US][TCH])
 {
 #pragma unroll
     for (int u = 0; u < US; ++u)
 #pragma unroll
         for (int t = 0; t < TCH; ++t)       // (no branch around a load: planes past the chunk's last re-read it and are not used)
-            v[u][t] = a[(i + u) * row_stride + (TCH == 1 || t < nt ? t : nt - 1) * plane];
+            v[u][t] = ms_cell(au + ((i + u) * row_stride + (FULL || TCH == 1 || t < nt ? t : nt - 1) * plane), c, (unsigned int)plane * 4u);
 }
 
-template <int TCH, int US>
+template <int TCH, int US, bool FULL>
 __device__ __forceinline__ void ms_use(const float (&v)[US][TCH], int i, int nt, bool scored, double (&s)[TCH], double (&q)[TCH],
                                        unsigned int *__restrict__ seg, long long seg_stride)
 {
     unsigned int m[US];
 #pragma unroll
     for (int u = 0; u < US; ++u) {
-        m[u] = 0u;
+        // max |x| without an AND per element: the signed maximum of the raw patterns is the largest non-negative value (a
+        // +NaN above everything), the unsigned maximum the largest-magnitude negative one if there is any (a -NaN on top)
+        int mp = 0;
+        unsigned int mn = 0u;
 #pragma unroll
         for (int t = 0; t < TCH; ++t) {     // (branch-free: a plane past the chunk's last adds +0 to sums that are never stored)
-            const float x = (TCH == 1 || t < nt) ? v[u][t] : 0.f;
+            const float x = (FULL || TCH == 1 || t < nt) ? v[u][t] : 0.f;
             const double d = (double)x;
             s[t] += d;
-            q[t] += d * d;
-            m[u] = max(m[u], __float_as_uint(x) & 0x7fffffffu);             // non-negative floats order like their patterns, NaN on top
+            q[t] = __builtin_fma(d, d, q[t]);           // (d * d is exact in fp64 for an fp32 d: the same sum as multiply-then-add)
+            mp = max(mp, (int)__float_as_uint(x));
+            mn = max(mn, __float_as_uint(x));
         }
+        m[u] = max((unsigned int)mp, mn & 0x7fffffffu);                     // non-negative floats order like their patterns, NaN on top
         m[u] = scored ? m[u] : 0u;
     }
     // wave maxima of US samples at once: each butterfly step halves the samples a lane is responsible for (US-1
@@ -178,6 +194,42 @@ __device__ __forceinline__ void ms_use(const float (&v)[US][TCH], int i, int nt,
     }
 }
 
+// the sample loop of moments_segmax_kernel (two load buffers: the next group's loads are in flight while this one is summed)
+template <int TCH, int US, bool FULL>
+__device__ __forceinline__ void ms_samples(const float *__restrict__ au, unsigned int c, long long row_stride, long long plane, int i0, int i1,
+                                           int nt, bool scored, double (&s)[TCH], double (&q)[TCH], unsigned int *__restrict__ seg,
+                                           long long seg_stride)
+{
+    int i = i0;
+    if constexpr (US == 1) {
+        // (the last trip re-reads its own sample)
+        float va[1][TCH], vb[1][TCH];
+        if (i < i1) ms_load<TCH, 1, FULL>(au, c, row_stride, plane, i, nt, va);
+        for (; i < i1; i += 2) {
+            ms_load<TCH, 1, FULL>(au, c, row_stride, plane, min(i + 1, i1 - 1), nt, vb);
+            ms_use<TCH, 1, FULL>(va, i, nt, scored, s, q, seg, seg_stride);
+            if (i + 1 >= i1) break;
+            ms_load<TCH, 1, FULL>(au, c, row_stride, plane, min(i + 2, i1 - 1), nt, va);
+            ms_use<TCH, 1, FULL>(vb, i + 1, nt, scored, s, q, seg, seg_stride);
+        }
+    } else {
+        float v[US][TCH], w[US][TCH], v1[1][TCH];
+        const int ilast = i0 + (i1 - i0) / US * US - US;                                   // start of the last full group
+        if (i + US <= i1) ms_load<TCH, US, FULL>(au, c, row_stride, plane, i, nt, v);
+        for (; i + US <= i1; i += 2 * US) {
+            ms_load<TCH, US, FULL>(au, c, row_stride, plane, min(i + US, ilast), nt, w);
+            ms_use<TCH, US, FULL>(v, i, nt, scored, s, q, seg, seg_stride);
+            if (i + 2 * US > i1) { i += US; break; }
+            ms_load<TCH, US, FULL>(au, c, row_stride, plane, min(i + 2 * US, ilast), nt, v);
+            ms_use<TCH, US, FULL>(w, i + US, nt, scored, s, q, seg, seg_stride);
+        }
+        for (; i < i1; ++i) {
+            ms_load<TCH, 1, FULL>(au, c, row_stride, plane, i, nt, v1);
+            ms_use<TCH, 1, FULL>(v1, i, nt, scored, s, q, seg, seg_stride);
+        }
+    }
+}
+
 template <int TCH, int US>
 __global__ void __launch_bounds__(256) moments_segmax_kernel(const float *__restrict__ a, long long row_stride, int n, int T, int X,
                                                              int Y, int cx, int cy, int rows_per_split, double *__restrict__ sum,
@@ -194,40 +246,15 @@ __global__ void __launch_bounds__(256) moments_segmax_kernel(const float *__rest
     const bool scored = live && x >= cx && x < X - cx && y >= cy && y < Y - cy;
     const int i0 = blockIdx.y * rows_per_split, i1 = min(n, i0 + rows_per_split);
     const int tc = blockIdx.z, TC = gridDim.z, t0 = tc * MS_TMAX, nt = min(TCH, T - t0);
-    a += (long long)t0 * plane + c;
+    const float *au = a + (long long)t0 * plane;                                           // wave-uniform
     const long long seg_stride = (long long)TC * nseg;                                     // segmax [n][TC][nseg]
     unsigned int *seg = segmax + (long long)tc * nseg + (cl >> 6);
     double s[TCH], q[TCH];
 #pragma unroll
     for (int t = 0; t < TCH; ++t) s[t] = q[t] = 0.0;
-    int i = i0;
-    if constexpr (US == 1) {
-        // two buffers: the next sample's loads are in flight while this one is summed (the last trip re-reads its own)
-        float va[1][TCH], vb[1][TCH];
-        if (i < i1) ms_load<TCH, 1>(a, row_stride, plane, i, nt, va);
-        for (; i < i1; i += 2) {
-            ms_load<TCH, 1>(a, row_stride, plane, min(i + 1, i1 - 1), nt, vb);
-            ms_use<TCH, 1>(va, i, nt, scored, s, q, seg, seg_stride);
-            if (i + 1 >= i1) break;
-            ms_load<TCH, 1>(a, row_stride, plane, min(i + 2, i1 - 1), nt, va);
-            ms_use<TCH, 1>(vb, i + 1, nt, scored, s, q, seg, seg_stride);
-        }
-    } else {
-        float v[US][TCH], w[US][TCH], v1[1][TCH];
-        const int ilast = i0 + (i1 - i0) / US * US - US;                                   // start of the last full group
-        if (i + US <= i1) ms_load<TCH, US>(a, row_stride, plane, i, nt, v);
-        for (; i + US <= i1; i += 2 * US) {                                                // (two buffers, as above)
-            ms_load<TCH, US>(a, row_stride, plane, min(i + US, ilast), nt, w);
-            ms_use<TCH, US>(v, i, nt, scored, s, q, seg, seg_stride);
-            if (i + 2 * US > i1) { i += US; break; }
-            ms_load<TCH, US>(a, row_stride, plane, min(i + 2 * US, ilast), nt, v);
-            ms_use<TCH, US>(w, i + US, nt, scored, s, q, seg, seg_stride);
-        }
-        for (; i < i1; ++i) {
-            ms_load<TCH, 1>(a, row_stride, plane, i, nt, v1);
-            ms_use<TCH, 1>(v1, i, nt, scored, s, q, seg, seg_stride);
-        }
-    }
+    const unsigned int cb = (unsigned int)c * 4u;                                           // (X * Y <= 2^30: checked by the host)
+    if (nt == TCH) ms_samples<TCH, US, true>(au, cb, row_stride, plane, i0, i1, nt, scored, s, q, seg, seg_stride);
+    else ms_samples<TCH, US, false>(au, cb, row_stride, plane, i0, i1, nt, scored, s, q, seg, seg_stride);
     sum += (long long)t0 * plane + c;
     sumsq += (long long)t0 * plane + c;
 #pragma unroll
@@ -816,6 +843,7 @@ int pre_moments_segmax_f64(const float *a, int64_t row_stride, int64_t n, int64_
     if (crop_x < 0 || crop_y < 0 || row_stride < T * X * Y) return PRE_E_RANGE;
     const long long bx = (X * Y + 255) / 256, TC = (T + MS_TMAX - 1) / MS_TMAX;
     if (n > 0x7fffffff || bx > 0x7fffffffLL || TC > 65535 || T > 0x7fffffff) return PRE_E_SHAPE;
+    if (X * Y >= (1LL << 30)) return PRE_E_SHAPE;                        // (a lane's cell is a 32-bit BYTE offset from the plane's base)
     const int us = T == 1 ? 16 : T <= 4 ? 4 : 1;
     long long splits = 1;
     const long long want = us > 1 ? 2048 : 1024;          // (the few-plane forms run 8 waves per SIMD)
