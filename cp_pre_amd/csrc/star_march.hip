@@ -201,6 +201,7 @@ struct MHDEnergy {     // Marginal/MHD_Residuals_CP.py:247-256; PRE_estimations.
 template <int MODE>
 struct MHDInduction {  // Marginal/MHD_Residuals_CP.py:259-268   fields u,v,Bx,By
     static constexpr int F = 4;
+    static constexpr int MIN_WAVES = MODE == 0 ? 4 : 1;
     using Params = MHDParams;
     static __device__ __forceinline__ float4 eval(const Nbr (&n)[4], const Params &p)
     {
@@ -294,7 +295,14 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int F> struct Halo { float4 row[F]; float yl[F], yr[F]; };
+// the halo of one plane as this thread holds it: ONE float of the row above / below the tile per field (the two rows are
+// 8*TYQ floats, fetched by the first 8*TYQ threads of the workgroup, a float each - as float4s held by the threads of the
+// tile's first and last row they cost every thread 8 registers per field, and these registers are live across the
+// functor: round 3), and ONE y-neighbour scalar (`ye`): the y- cell of a wave's first lane, the y+ cell of a wave's / tile's
+// last lane - no lane is both.  (A row's last computed quad elsewhere takes its y+ cell from the next lane like every
+// interior quad: the lanes beyond the computed width hold the grid's next column, if there is one, in C.x.)  The
+// boundary-condition instantiations, where the last quad of a row maps its y+ cell wherever it lies, keep a second one.
+template <int F, bool BC> struct Halo { float row[F]; float ye[F]; float yr[BC ? F : 1]; };
 
 // Boundary conditions on the (x, y) rim for the BC=true instantiations (Utils/boundary_conditions.py:
 // BoundaryManager.pad_signal followed by a 'valid' conv == a 'same' conv whose out-of-domain neighbour
@@ -343,56 +351,89 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
         t1 = min(t1, g.T - 1);
     }
 
-    // halo-row duty: thread-row 0 fetches the row above the tile, thread-row NR-1 the row below
-    const bool top = (ty == 0), bot = (ty == NR - 1);
-    int hx = top ? x - 1 : x + 1;
+    // halo-row duty: the workgroup's first 4*TYQ threads fetch the row above the tile, the next 4*TYQ the row below, one
+    // float each (a wave = 64 consecutive floats of one row)
+    static_assert(NR >= 8 && (4 * TYQ) % 64 == 0, "the two halo rows are fetched by the first 8*TYQ threads, a wave per 64 floats");
+    const int hl = ty * TYQ + q;                     // linear thread index
+    const bool hduty = hl < 8 * TYQ, hbot = hl >= 4 * TYQ;
+    const int hcol = hl & (4 * TYQ - 1);             // column within the tile
+    const int hy = yt * (4 * TYQ) + hcol;            // column of the grid
+    int hx = hbot ? xt * NR + NR : xt * NR - 1;
     // PRE_FLAG_HALO_X: rows -1 and X of the views exist (an x-slab of a larger grid): read, not zero padding
     const bool halox = (g.flags & PRE_FLAG_HALO_X) != 0;
-    bool hrow = (top || bot) && (halox ? (hx >= -1 && hx <= g.X) : (hx >= 0 && hx < g.X)) && (y < g.Yc);
+    bool hrow = hduty && (halox ? (hx >= -1 && hx <= g.X) : (hx >= 0 && hx < g.X)) && (hy < g.Yc);
     float hfill = 0.f;          // value of an out-of-domain halo row
-    const int hslot = top ? 0 : NR + 1;
+    const int hslot = hbot ? NR + 1 : 0;
     // y-halo duty: the edge lanes of each wave (and of the tile) fetch one scalar
     const bool ledge = ((q & 63) == 0);
-    // (the last computed float4 of a row is an edge too: beyond it lie either the domain end or the
-    // <= 3 columns of an odd-width grid that this kernel leaves to the generic one)
-    bool redge = ((q & 63) == 63) || (q == TYQ - 1) || (y + 4 >= g.Yc);
+    bool redge = ((q & 63) == 63) || (q == TYQ - 1);
     bool lload = ledge && inb && (y > 0);
     bool rload = redge && inb && (y + 4 < g.Y);
     int yloff = -1, yroff = 4;  // element offsets of the y- / y+ scalar relative to the own float4
     float ylfill = 0.f, yrfill = 0.f;
+    // a lane just beyond the computed width (the <= 3 last columns of an odd-width grid are left to the generic kernel)
+    // holds the grid's column y in C.x: the y+ cell of the row's last computed quad, taken by the shuffle like any other
+    const bool tailq = !BC && (x < g.X) && (y >= g.Yc) && (y < g.Y);
     if constexpr (BC) {
-        if ((top || bot) && y < g.Yc && (hx == -1 || hx == g.X)) {
+        if (hduty && hy < g.Yc && (hx == -1 || hx == g.X)) {
             const int m = hx < 0 ? bc.xlo : bc.xhi;
             hfill = hx < 0 ? bc.vxlo : bc.vxhi;
             hrow = m >= 0;
             hx = m >= 0 ? m : 0;
         }
+        // (the fused BC entries take whole quads only: Yc == Y)
         if (inb && y == 0) { lload = bc.ylo >= 0; yloff = bc.ylo; ylfill = bc.vylo; }
         if (inb && y + 4 >= g.Y) { redge = true; rload = bc.yhi >= 0; yroff = bc.yhi - y; yrfill = bc.vyhi; }
     }
+    // non-BC: ONE edge scalar per lane (y- for a wave's first lane, y+ for a wave's / tile's last lane)
+    const bool eload = BC ? lload : (ledge ? lload : rload);
+    const int eoff4 = 4 * (BC ? yloff : (ledge ? yloff : yroff));
+    const float efill = BC ? ylfill : 0.f;
 
-    const float *own[F], *hal[F];
+    // Addresses: a plane of a field of this sample is a wave-uniform BUFFER DESCRIPTOR (scalar registers, advanced by scalar
+    // arithmetic), a thread's place in it a 32-bit byte offset - its own quad (voff), the halo-row float it fetches
+    // (hoff), its edge scalar (voff + eoff4).  As 64-bit pointers these cost 4 registers per field, live across the
+    // functor, plus a 64-bit vector add per load (round 3).  The descriptors are based one row BEFORE row 0, so that
+    // row -1 (PRE_FLAG_HALO_X) has a non-negative offset; the host has checked that every offset fits 32 bits.
+    unsigned int voff[F], hoff[F];
 #pragma unroll
     for (int i = 0; i < F; ++i) {
-        const float *base = g.f[i] + (long long)b * g.sB[i];
-        own[i] = base + (long long)xl * g.sX[i] + y;
-        hal[i] = base + (long long)hx * g.sX[i] + y;
+        voff[i] = (unsigned int)(((long long)(xl + 1) * g.sX[i] + y) * 4);
+        hoff[i] = (unsigned int)(((long long)(hx + 1) * g.sX[i] + hy) * 4);
     }
     float *outp = g.out + (long long)b * g.oB + (long long)x * g.oX + y;
     const long long oT = g.oT;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto plane = [&](int i, int t) __attribute__((always_inline)) {
+        const float *p = g.f[i] + ((long long)b * g.sB[i] - g.sX[i] + (long long)t * g.sT[i]);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, -1, 0x00020000);
+    };
 
     auto load_own = [&](int t, float4(&dst)[F]) __attribute__((always_inline)) {
         const bool ok = ldown && (t >= 0) && (t < g.T);
 #pragma unroll
-        for (int i = 0; i < F; ++i) dst[i] = ok ? ldg4(own[i] + (long long)t * g.sT[i]) : f4(BC ? ghost : 0.f);
+        for (int i = 0; i < F; ++i) {
+            if (ok) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(plane(i, t), (int)voff[i], 0, 0);
+                dst[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            } else {
+                dst[i] = f4(BC ? ghost : 0.f);
+                if (tailq && (t >= 0) && (t < g.T))
+                    dst[i].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(plane(i, t), (int)voff[i], 0, 0));
+            }
+        }
     };
-    auto load_halo = [&](int t, Halo<F> &h) __attribute__((always_inline)) {
+    auto load_halo = [&](int t, Halo<F, BC> &h) __attribute__((always_inline)) {
         const bool okt = (t >= 0) && (t < g.T);
 #pragma unroll
         for (int i = 0; i < F; ++i) {
-            h.row[i] = (hrow && okt) ? ldg4(hal[i] + (long long)t * g.sT[i]) : f4(BC ? hfill : 0.f);
-            h.yl[i] = (lload && okt) ? own[i][(long long)t * g.sT[i] + (BC ? yloff : -1)] : (BC ? ylfill : 0.f);
-            h.yr[i] = (rload && okt) ? own[i][(long long)t * g.sT[i] + (BC ? yroff : 4)] : (BC ? yrfill : 0.f);
+            h.row[i] = (hrow && okt) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(plane(i, t), (int)hoff[i], 0, 0))
+                                     : (BC ? hfill : 0.f);
+            h.ye[i] = (eload && okt) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(plane(i, t), (int)voff[i] + eoff4, 0, 0))
+                                     : (BC ? efill : 0.f);
+            if constexpr (BC)
+                h.yr[i] = (rload && okt) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(plane(i, t), (int)voff[i] + 4 * yroff, 0, 0))
+                                         : yrfill;
         }
     };
 
@@ -400,12 +441,12 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
     // hc is the halo of plane t, hn receives the halo of plane t+1.  The caller rotates the
     // roles instead of moving registers, so D/hn stay in flight until they are first read.
     auto step = [&](int t, float4(&P)[F], float4(&C)[F], float4(&N)[F], float4(&D)[F],
-                    Halo<F> &hc, Halo<F> &hn) __attribute__((always_inline)) {
+                    Halo<F, BC> &hc, Halo<F, BC> &hn) __attribute__((always_inline)) {
         const int bi = (t - t0) & 1;
 #pragma unroll
         for (int i = 0; i < F; ++i) {
             lds[bi][i][ty + 1][q] = C[i];
-            if (top || bot) lds[bi][i][hslot][q] = hc.row[i];
+            if (hduty) reinterpret_cast<float *>(&lds[bi][i][hslot][0])[hcol] = hc.row[i];
         }
         // halo first: it is consumed first (next plane's LDS staging), and vmcnt retires in
         // issue order, so the own-cell loads of plane t+2 stay in flight behind it
@@ -424,8 +465,8 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
             n[i].xp = lds[bi][i][ty + 2][q];
             float lft = __shfl_up(C[i].w, 1);
             float rgt = __shfl_down(C[i].x, 1);
-            lft = ledge ? hc.yl[i] : lft;
-            rgt = redge ? hc.yr[i] : rgt;
+            lft = ledge ? hc.ye[i] : lft;
+            rgt = redge ? (BC ? hc.yr[i] : hc.ye[i]) : rgt;
             n[i].ym = make_float4(lft, C[i].x, C[i].y, C[i].z);
             n[i].yp = make_float4(C[i].y, C[i].z, C[i].w, rgt);
         }
@@ -437,7 +478,7 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
     };
 
     float4 w0[F], w1[F], w2[F], w3[F];
-    Halo<F> h0, h1;
+    Halo<F, BC> h0, h1;
     load_own(t0 - 1, w0);
     load_own(t0, w1);
     load_own(t0 + 1, w2);
@@ -493,6 +534,8 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const 
     {
     g.nXT = (g.X + NR - 1) / NR;
     g.nYT = (g.Yc + 4 * TYQ - 1) / (4 * TYQ);
+    for (int i = 0; i < Fn::F; ++i)            // a thread's place in a plane is a 32-bit byte offset (from one row before row 0)
+        if (g.sX[i] < 0 || ((long long)(g.X + 2 + NR) * g.sX[i] + g.Y + 8) * 4 >= (1LL << 32)) return PRE_E_UNSUPPORTED;
     // split long T axes so the grid fills the chip (>= ~4 workgroups per CU) without
     // paying the 2-plane window prologue too often
     long long tiles = (long long)g.B * g.nXT * g.nYT;
