@@ -213,33 +213,43 @@ class MHD(_Residual2D):
         super().__init__(**kw)
         self.gamma = gamma
 
-    def _fused(self, eq, vars, absolute):
+    def _fused(self, eq, vars, absolute, halo_x=False):
+        """``halo_x`` (every ``residual_*`` below takes it): ``vars`` is an x-slab ``full[:, :, :, x0:x1]`` whose rows
+        x0 - 1 and x1 lie in the same memory and are read as x-neighbours instead of the zero padding
+        (``PRE_FLAG_HALO_X``, see ``NavierStokes.residual_momentum``); fused route only."""
         ks = self._k27(self.D_t, self.D_x, self.D_y) if self._want_fused(vars) else None
         if ks is None or vars.shape[1] < 6:
+            if halo_x:
+                raise RuntimeError("halo_x: only the fused route reads the halo rows")
             return None
         with torch.no_grad():
             fields, origin = _stage([vars[:, i] for i in range(6)])
+        if halo_x and (origin is not None or _dispatch.needs_grad(vars) or
+                       any(d.data_ptr() != vars[:, i].data_ptr() or d.stride(3) != 1 for i, d in enumerate(fields))):
+            raise ValueError("halo_x needs device-resident, Ny-contiguous views of a larger grid and no autograd")
         out = _lib.empty_like_layout(fields[0])
         arr = (_lib.PreField * 6)(*[_lib.field(f) for f in fields])
         fo = _lib.field(out)
+        flags = (_lib.PRE_FLAG_ABS if absolute else 0) | (_lib.PRE_FLAG_HALO_X if halo_x else 0)
         with torch.cuda.device(out.device):
             ok = _fused_call("pre_residual_mhd_f32", lambda: _lib.load().pre_residual_mhd_f32(
-                _MHD_EQ[eq], arr, ctypes.byref(fo), *ks, float(self.gamma), *out.shape,
-                _lib.PRE_FLAG_ABS if absolute else 0, _lib.stream()))
+                _MHD_EQ[eq], arr, ctypes.byref(fo), *ks, float(self.gamma), *out.shape, flags, _lib.stream()))
+        if halo_x and not ok:
+            raise RuntimeError("pre_residual_mhd_f32: halo_x needs Ny-contiguous views and star-shaped operator kernels")
         return _dispatch.from_device(out, origin) if ok else None
 
-    def residual_continuity(self, vars, boundary=False, absolute=False):
+    def residual_continuity(self, vars, boundary=False, absolute=False, halo_x=False):
         D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
         fields = (vars[:, 0], vars[:, 1], vars[:, 2])
 
         def composed(rho, u, v):
             return D_t(rho) + u*D_x(rho) + rho*D_x(u) + v*D_y(rho) + rho*D_y(v)
-        res = _attach(self._fused('continuity', vars, absolute), fields, composed, absolute)
+        res = _attach(self._fused('continuity', vars, absolute, halo_x), fields, composed, absolute)
         if res is None:
             return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)
 
-    def residual_momentum(self, vars, boundary=False, absolute=False):
+    def residual_momentum(self, vars, boundary=False, absolute=False, halo_x=False):
         D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
         fields = tuple(vars[:, i] for i in range(6))
 
@@ -247,12 +257,12 @@ class MHD(_Residual2D):
             res_x = D_t(u) + u*D_x(u) + (1/rho)*D_x(p) - 2*(Bx/rho)*D_x(Bx) + v*D_y(u) - (By/rho)*D_y(Bx) - (Bx/rho)*D_y(By)
             res_y = D_t(v) + u*D_x(v) + (1/rho)*D_y(p) - 2*(By/rho)*D_y(By) + v*D_y(v) - (By/rho)*D_x(Bx) - (Bx/rho)*D_x(By)
             return res_x + res_y
-        res = _attach(self._fused('momentum', vars, absolute), fields, composed, absolute)
+        res = _attach(self._fused('momentum', vars, absolute, halo_x), fields, composed, absolute)
         if res is None:
             return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)
 
-    def residual_energy(self, vars, boundary=False, absolute=False):
+    def residual_energy(self, vars, boundary=False, absolute=False, halo_x=False):
         D_t, D_x, D_y, gamma = self.D_t, self.D_x, self.D_y, self.gamma
         fields = tuple(vars[:, i] for i in range(6))
 
@@ -260,12 +270,12 @@ class MHD(_Residual2D):
             p_gas = p - 0.5*(Bx**2 + By**2)
             return (D_t(rho) + u*D_x(p) + v*D_y(p) + (gamma-2)*(u*Bx+v*By)*(D_x(Bx) + D_y(By))
                     + (gamma*p_gas+By**2)*D_x(u) + (gamma*p_gas+Bx**2)*D_y(v) - Bx*By*(D_y(u) + D_x(v)))
-        res = _attach(self._fused('energy', vars, absolute), fields, composed, absolute)
+        res = _attach(self._fused('energy', vars, absolute, halo_x), fields, composed, absolute)
         if res is None:
             return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)
 
-    def residual_induction(self, vars, boundary=False, absolute=False):
+    def residual_induction(self, vars, boundary=False, absolute=False, halo_x=False):
         D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
         fields = (vars[:, 1], vars[:, 2], vars[:, 4], vars[:, 5])
 
@@ -273,7 +283,7 @@ class MHD(_Residual2D):
             res_x = D_t(Bx) - By*D_y(u) + Bx*D_y(v) - v*D_y(Bx) + u*D_y(By)
             res_y = D_t(By) + By*D_x(u) - Bx*D_x(v) - v*D_x(Bx) + u*D_x(By)
             return res_x + res_y
-        res = _attach(self._fused('induction', vars, absolute), fields, composed, absolute)
+        res = _attach(self._fused('induction', vars, absolute, halo_x), fields, composed, absolute)
         if res is None:
             return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)

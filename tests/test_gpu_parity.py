@@ -2002,6 +2002,22 @@ def test_x_slab_with_halo_rows_equals_the_whole_grid_rows(gpu, X, Y, x0, x1):
     assert torch.equal(_dispatch._xcorr_impl(u[:, :, x0:x1], D.kernel, 3, flags=_lib.PRE_FLAG_HALO_X), D(u)[:, :, x0:x1])
 
 
+@pytest.mark.parametrize("eq", ["continuity", "momentum", "energy", "induction"])
+def test_mhd_x_slab_with_halo_rows_equals_the_whole_grid_rows(gpu, eq):
+    """The MHD residuals on an x-slab with its halo rows (float-per-thread halo for induction / continuity, float4 halo
+    rows for the six-field functors; a partial last tile) == the whole grid's rows, bit for bit."""
+    from cp_pre_amd.residuals import MHD
+    g = torch.Generator().manual_seed(11)
+    v = (torch.rand(4, 6, 6, 37, 256, generator=g) + 0.5).to(gpu)[:3]
+    mhd = MHD(device=gpu)
+    fn = getattr(mhd, "residual_" + eq)
+    full = fn(v, boundary=True)
+    for x0, x1 in ((1, 17), (9, 36), (20, 27)):
+        slab = fn(v[:, :, :, x0:x1], boundary=True, halo_x=True)
+        assert torch.equal(slab, full[:, :, x0:x1]), (x0, x1)
+        assert torch.equal(fn(v[:, :, :, x0:x1], boundary=True, absolute=True, halo_x=True), full[:, :, x0:x1].abs())
+
+
 def test_x_slab_flag_is_refused_where_no_kernel_reads_the_halo(gpu):
     """PRE_E_UNSUPPORTED (never a silently zero-padded result): off-star taps, a width that leaves tail columns, the
     1-D entry, a T-contiguous (relabelled) view."""
