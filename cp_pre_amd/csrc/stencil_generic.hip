@@ -20,6 +20,8 @@
 int pre_star_try_linear1(const pre_field_t *in, const pre_out_t *out, const float star7[7],
                          int64_t B, int64_t T, int64_t X, int64_t Y, int flags, hipStream_t st,
                          int *tail_axis, int64_t *tail_from);
+int pre_acc_march_try(const pre_field_t *in, const pre_out_t *out, const float *w125, int radius,
+                      int64_t B, int64_t T, int64_t X, int64_t Y, int flags, hipStream_t st);
 
 namespace {
 
@@ -575,6 +577,23 @@ int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *
 #undef PRE_PT_LAUNCH
                     PRE_LAUNCH_CHECK();
                     return PRE_OK;
+                }
+            }
+            // taps on three adjacent time planes within two cells of the centre, reference layout: the accumulator march
+            // (acc_march.hip; a dense 3^3 kernel, the wave kernel with a Taylor-4 Laplacian)
+            if (unit == 2) {
+                bool fits = true;
+                int rad = 1;
+                float w125[125] = {};
+                for (int i = 0; i < ntaps; ++i) {
+                    const int dt = tap_off[3 * i], dx = tap_off[3 * i + 1], dy = tap_off[3 * i + 2];
+                    if (dt < -1 || dt > 1 || dx < -2 || dx > 2 || dy < -2 || dy > 2) { fits = false; break; }
+                    if (dx < -1 || dx > 1 || dy < -1 || dy > 1) rad = 2;
+                    w125[(dt + 1) * 25 + (dx + 2) * 5 + (dy + 2)] += tap_w[i];
+                }
+                if (fits) {
+                    const int rc = pre_acc_march_try(in, out, w125, rad, B, T, X, Y, flags, st);
+                    if (rc != PRE_E_UNSUPPORTED) return rc;
                 }
             }
             const dim3 grid((unsigned)tiles, (unsigned)(D[p[0]] < 65535 ? D[p[0]] : 65535), (unsigned)(B < 65535 ? B : 65535));

@@ -354,3 +354,34 @@ def test_fuzz_round2_pruned_joint_score(gpu):
                 (case, kind, tuple(res.shape), crop, s_full, s_pr)
         finally:
             ops.PRUNE_MIN_CELLS, ops.PRUNE_MIN_SAMPLES = old
+
+
+@pytest.mark.parametrize("shape", [(2, 7, 19, 64), (1, 40, 9, 320), (3, 5, 8, 256), (2, 1, 12, 128), (5, 2, 30, 516)])
+def test_three_plane_tap_sets_accumulator_march_vs_oracle(gpu, shape):
+    """csrc/acc_march.hip: tap sets on three adjacent time planes within one or two cells of the centre (a dense 3^3
+    kernel, the additive wave kernel with a Taylor-4 Laplacian, sparse radius-2 sets with centre-only rows) on the
+    reference layout - partial row tiles, a 64-column last tile, T = 1 and 2, a T axis long enough to be cut into
+    segments, a batch-strided view, |.| - against the C oracle."""
+    from cp_pre_amd import _dispatch, _lib
+    from cp_pre_amd.convops_2d import ConvOperator
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape[0], 2, *shape[1:], generator=g)[:, 1]                     # batch stride 2 * T * X * Y
+    kernels = {"dense3": torch.randn(3, 3, 3, generator=g)}
+    k5 = torch.zeros(5, 5, 5)
+    k5[1:4, 1:4, 1:4] = ConvOperator("t", 2).kernel
+    kernels["wave_taylor4"] = k5 - 0.25 * ConvOperator(("x", "y"), 2, taylor_order=4).kernel
+    sp = torch.zeros(5, 5, 5)
+    sp[1:4] = torch.randn(3, 5, 5, generator=g) * (torch.rand(3, 5, 5, generator=g) < 0.3)
+    sp[2, 2, 2] = 1.0
+    kernels["sparse_r2"] = sp
+    one = torch.zeros(3, 3, 3)
+    one[0, 2, 0], one[2, 0, 2] = 2.0, -3.0                                            # two corner taps on the outer planes
+    kernels["corners"] = one
+    for name, ker in kernels.items():
+        D = ConvOperator()
+        D.kernel = ker
+        want = xcorr_c(x.contiguous().numpy(), ker.numpy())
+        got = D(x.to(gpu))
+        assert rel_err(got.cpu().numpy(), want) <= RES_TOL, (name, shape)
+        got_abs = _dispatch._xcorr_impl(x.to(gpu), ker, 3, flags=_lib.PRE_FLAG_ABS)
+        assert rel_err(got_abs.cpu().numpy(), np.abs(want)) <= RES_TOL, (name, shape, "abs")
