@@ -129,12 +129,17 @@ __global__ void __launch_bounds__(AM_NT) acc_march_kernel(const AMGeom g, const 
                 float v[4 + 2 * R];
                 const float4 o = *reinterpret_cast<const float4 *>(row);
                 v[R] = o.x; v[R + 1] = o.y; v[R + 2] = o.z; v[R + 3] = o.w;
-                if constexpr (R == 1) {
-                    v[0] = row[-1];
-                    v[5] = row[4];
-                } else {
-                    const float2 l = *reinterpret_cast<const float2 *>(row - 2), r2 = *reinterpret_cast<const float2 *>(row + 4);
-                    v[0] = l.x; v[1] = l.y; v[6] = r2.x; v[7] = r2.y;
+                const unsigned int widebits = (W.wide >> dxi) & (1u | (1u << D) | (1u << (2 * D)));
+#pragma unroll
+                for (int j = 0; j < R; ++j) v[j] = v[R + 4 + j] = 0.f;
+                if (widebits) {                              // (the floats either side of the quad: only where a row needs them)
+                    if constexpr (R == 1) {
+                        v[0] = row[-1];
+                        v[5] = row[4];
+                    } else {
+                        const float2 l = *reinterpret_cast<const float2 *>(row - 2), r2 = *reinterpret_cast<const float2 *>(row + 4);
+                        v[0] = l.x; v[1] = l.y; v[6] = r2.x; v[7] = r2.y;
+                    }
                 }
                 auto add = [&](float4 &a, int dti) __attribute__((always_inline)) {
 #pragma unroll
@@ -153,7 +158,6 @@ __global__ void __launch_bounds__(AM_NT) acc_march_kernel(const AMGeom g, const 
                     a.x = __builtin_fmaf(w, o.x, a.x); a.y = __builtin_fmaf(w, o.y, a.y);
                     a.z = __builtin_fmaf(w, o.z, a.z); a.w = __builtin_fmaf(w, o.w, a.w);
                 };
-                const unsigned int widebits = W.wide >> dxi;
                 if (rowbits & 1u) { if (widebits & 1u) add(anext, 0); else centre(anext, 0); }     // w[dt = -1]: plane p is the t-1 neighbour of out[p+1]
                 if (rowbits & (1u << D)) { if (widebits & (1u << D)) add(acur, 1); else centre(acur, 1); }
                 if (rowbits & (1u << (2 * D))) { if (widebits & (1u << (2 * D))) add(aprev, 2); else centre(aprev, 2); }   // w[dt = +1]
