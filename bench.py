@@ -406,9 +406,11 @@ def main():
         per_plane = (X * Y if not xs else (n_axis // 4 + 2) * Y)
         extra = 4 * world * B * per_plane if (args.mode == "marginal" and world > 1) else 0
         extra += (1 << 30) if group is not None else 0                 # headroom for RCCL's own scratch beyond the warm-up collective
-        div = [n_axis, (n_axis + 1) // 2, (n_axis + 2) // 3, (n_axis + 3) // 4]
-        cands = [c for c in (div + ([96, 64, 32, 16] if xs else [16, 13, 8])) if 0 < c <= n_axis]
-        cands = sorted(set(cands), reverse=True)
+        if xs:      # halves of the axis (whole 8-row tiles for a power-of-two grid), down to 16 rows
+            div = [-(-n_axis // d) for d in (1, 2, 4, 8, 16, 32, 64) if -(-n_axis // d) >= 16] or [n_axis]
+        else:
+            div = [n_axis, (n_axis + 1) // 2, (n_axis + 2) // 3, (n_axis + 3) // 4, 16, 13, 8]
+        cands = sorted(set(c for c in div if 0 < c <= n_axis), reverse=True)
         idx = next((i for i, c in enumerate(cands) if resident_bytes(B, n_axis, c, other) + extra <= free - (4 << 30)),
                    len(cands) - 1)
         if group is not None:
