@@ -439,9 +439,14 @@ class PRE_Wave:
         c = torch.tensor(c, dtype=torch.float32)
         self.D.kernel = D_tt.kernel - ((c * dt / dx) ** 2).to(device) * D_xx_yy.kernel
 
-    def residual(self, uu, boundary=False, absolute=False):
+    def residual(self, uu, boundary=False, absolute=False, halo_x=False):
+        """``halo_x``: ``uu`` is an x-slab ``full[..., x0:x1, :]`` whose rows x0 - 1 and x1 lie in the same device memory and
+        are read instead of the zero padding (``PRE_FLAG_HALO_X``, see ``NavierStokes.residual_momentum``)."""
         uu = uu[:, 0] if uu.dim() == 5 else uu
-        res = _dispatch.xcorr(uu, self.D.kernel, nd=3, flags=_lib.PRE_FLAG_ABS if absolute else 0)
+        flags = (_lib.PRE_FLAG_ABS if absolute else 0) | (_lib.PRE_FLAG_HALO_X if halo_x else 0)
+        if halo_x and not (uu.is_cuda and uu.stride(-1) == 1 and not _dispatch.needs_grad(uu, self.D.kernel)):
+            raise ValueError("halo_x needs a device-resident, Ny-contiguous view of a larger grid and no autograd")
+        res = _dispatch.xcorr(uu, self.D.kernel, nd=3, flags=flags)      # (raises if no kernel reads the halo rows)
         return res if boundary else res[_CROP3]
 
 

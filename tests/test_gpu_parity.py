@@ -2018,6 +2018,17 @@ def test_mhd_x_slab_with_halo_rows_equals_the_whole_grid_rows(gpu, eq):
         assert torch.equal(fn(v[:, :, :, x0:x1], boundary=True, absolute=True, halo_x=True), full[:, :, x0:x1].abs())
 
 
+def test_wave_x_slab_with_halo_rows_equals_the_whole_grid_rows(gpu):
+    from cp_pre_amd.residuals import PRE_Wave
+    g = torch.Generator().manual_seed(12)
+    u = torch.randn(4, 9, 45, 256, generator=g).to(gpu)[:3]
+    w = PRE_Wave(dt=0.005, dx=0.01, c=1.0, device=gpu)
+    full = w.residual(u, boundary=True)
+    for x0, x1 in ((1, 9), (7, 44)):
+        assert torch.equal(w.residual(u[:, :, x0:x1], boundary=True, halo_x=True), full[:, :, x0:x1])
+        assert torch.equal(w.residual(u[:, :, x0:x1], boundary=True, absolute=True, halo_x=True), full[:, :, x0:x1].abs())
+
+
 def test_x_slab_flag_is_refused_where_no_kernel_reads_the_halo(gpu):
     """PRE_E_UNSUPPORTED (never a silently zero-padded result): off-star taps, a width that leaves tail columns, the
     1-D entry, a T-contiguous (relabelled) view."""
