@@ -469,7 +469,8 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
         }
         // halo first: it is consumed first (next plane's LDS staging), and vmcnt retires in
         // issue order, so the own-cell loads of plane t+2 stay in flight behind it
-        // (measured +7 % on NS momentum vs the other order; non-temporal stores: -25 %)
+        // (measured +7 % on NS momentum vs the other order; non-temporal stores: -25 %; round 3: the own-cell loads with
+        // the slc / nt bit -5 ... -12 % on every functor, with glc +-0)
         load_halo(t + 1, hn);
         load_own(t + 2, D);
         lds_barrier();
