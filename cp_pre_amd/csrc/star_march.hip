@@ -201,7 +201,7 @@ struct MHDEnergy {     // Marginal/MHD_Residuals_CP.py:247-256; PRE_estimations.
 template <int MODE>
 struct MHDInduction {  // Marginal/MHD_Residuals_CP.py:259-268   fields u,v,Bx,By
     static constexpr int F = 4;
-    static constexpr int MIN_WAVES = MODE == 0 ? 4 : 1;
+
     using Params = MHDParams;
     static __device__ __forceinline__ float4 eval(const Nbr (&n)[4], const Params &p)
     {
