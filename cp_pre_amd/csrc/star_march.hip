@@ -630,25 +630,35 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
         }
     }
 
-    const float *own[F], *hal[F];
-#pragma unroll
-    for (int i = 0; i < F; ++i) {
-        const float *base = g.f[i] + (long long)b * g.sB[i];
-        own[i] = base + m;
-        hal[i] = base + hm;
-    }
+    // a plane of a field of this sample = a wave-uniform buffer descriptor; the thread's own quad and its halo quad are
+    // two 32-bit byte offsets shared by every field (the flat form takes fields of one in-plane layout): as 64-bit
+    // pointers they cost 4 registers per field (JOREK temperature in its native layout: 139 registers, one workgroup per CU)
+    const unsigned int voff = (unsigned int)m * 4u, hoff = (unsigned int)hm * 4u;       // (hm < 0: never loaded)
     float *outp = g.out + (long long)b * g.oB + m;
     const long long oT = g.oT;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto quad = [&](int i, int t, unsigned int off) __attribute__((always_inline)) {
+        const float *p = g.f[i] + ((long long)b * g.sB[i] + (long long)t * g.sT[i]);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, -1, 0x00020000),
+                                                              (int)off, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
 
     auto load_own = [&](int t, float4(&dst)[F]) __attribute__((always_inline)) {
         const bool ok = inb && (t >= 0) && (t < g.T);
 #pragma unroll
-        for (int i = 0; i < F; ++i) dst[i] = ok ? ldg4(own[i] + (long long)t * g.sT[i]) : f4(0.f);
+        for (int i = 0; i < F; ++i) {
+            if (ok) dst[i] = quad(i, t, voff);
+            else dst[i] = f4(0.f);
+        }
     };
     auto load_halo = [&](int t, float4(&dst)[F]) __attribute__((always_inline)) {
         const bool ok = hok && (t >= 0) && (t < g.T);
 #pragma unroll
-        for (int i = 0; i < F; ++i) dst[i] = ok ? ldg4(hal[i] + (long long)t * g.sT[i]) : f4(0.f);
+        for (int i = 0; i < F; ++i) {
+            if (ok) dst[i] = quad(i, t, hoff);
+            else dst[i] = f4(0.f);
+        }
     };
 
     auto step = [&](int t, float4(&P)[F], float4(&C)[F], float4(&N)[F], float4(&D)[F], float4(&hc)[F],
@@ -712,6 +722,7 @@ int launch_flat(Geom &g, const typename Fn::Params &prm, hipStream_t st)
 {
     static_assert(2 * Fn::F * (FLAT_NT + 2 * FLAT_H) * 16 <= 160 * 1024, "chunk does not fit the 160 KiB LDS");
     g.nXT = 1;
+    if ((long long)g.X * g.Y >= (1LL << 30)) return PRE_E_UNSUPPORTED;      // a thread's place in a plane is a 32-bit byte offset
     // chunk = 512 quads, or 448 / 384 / 320 / 256 when that leaves fewer idle lanes in the row's last chunk (the
     // surrogate's Nt = 10 on a 256-wide grid is a row of 640 quads: two chunks of 320 instead of 512 + 128)
     const long long quads = (long long)g.X * g.Y / 4;
