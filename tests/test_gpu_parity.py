@@ -2076,3 +2076,22 @@ def test_x_slab_stream_equals_whole_grid_calibration(gpu, B, T, X, Y, rows):
         assert torch.equal(pipeline.marginal_qhat(res.abs(), alphas), qm0[:, :, x0:x0 + rows])
     q = jc.finish(alphas)
     assert torch.allclose(jc.scores, jc0.scores, rtol=1e-6, atol=0) and torch.allclose(q, q0, rtol=QHAT_TOL, atol=0)
+
+
+def test_row_stride_beyond_32_bit_offsets_takes_the_generic_route(gpu):
+    """The streaming kernels address a plane by 32-bit byte offsets; a view whose rows lie further apart than that (here
+    64 M floats: 256 MB per row) is declined by them (PRE_E_UNSUPPORTED) and must still come out right - single operators
+    through the strided generic kernel, fused residuals through the composed route."""
+    from cp_pre_amd.convops_2d import ConvOperator
+    from cp_pre_amd.residuals import NavierStokes
+    pitch = 1 << 26
+    big = torch.zeros(6 * pitch + 256, device=gpu)
+    g = torch.Generator().manual_seed(5)
+    vals = (torch.rand(1, 3, 2, 2, 256, generator=g) + 0.5).to(gpu)              # [B, F, T, X, Y] with X = 2 rows per plane
+    view = big.as_strided((1, 3, 2, 2, 256), (0, 2 * pitch, 256, pitch, 1))       # rows 2^26 floats apart
+    view.copy_(vals)
+    D = ConvOperator(("x", "y"), 2, device=gpu)
+    assert torch.equal(D(view[:, 0]), D(vals[:, 0].contiguous()))
+    ns = NavierStokes(1e-2, 0.1, 0.1, nu=1e-3, device=gpu)
+    a, b = ns.residual_momentum(view, boundary=True), ns.residual_momentum(vals, boundary=True)
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= RES_TOL
