@@ -30,6 +30,11 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.pre_abi_version() == 7
+    # the header's flag and error constants are the ones the ctypes mirror uses
+    consts = {k: int(v) for k, v in re.findall(r"#define\s+(PRE_(?:FLAG|E|OK)[A-Z_]*)\s+(-?\d+)", header)}
+    assert consts["PRE_FLAG_HALO_X"] == 8 and len([k for k in consts if k.startswith("PRE_FLAG_")]) == 4
+    for name, val in consts.items():
+        assert getattr(_lib, name) == val, name
     # the spectral family's library (links hipFFT)
     header = open(os.path.join(ROOT, "include", "cp_pre_fft.h")).read()
     declared = set(re.findall(r"\bint\s+(pre_[a-z0-9_]+)\s*\(", header))
