@@ -68,6 +68,19 @@ def main():
     measure("MHD momentum [1024,64,256,256]", 28 * cells, lambda: mhd.residual_momentum(w, boundary=True))
     measure("MHD energy [1024,64,256,256]", 28 * cells, lambda: mhd.residual_energy(w, boundary=True))
     measure("MHD continuity [1024,64,256,256]", 16 * cells, lambda: mhd.residual_continuity(w, boundary=True))
+    del w
+    torch.cuda.empty_cache()
+    # the single-field kernels of C2 / C5 / C1
+    u2 = torch.randn(512, 32, 256, 256, device=dev, generator=g)
+    wave = R.PRE_Wave(dt=0.005, dx=0.01, c=1.0, device=dev)
+    measure("C2 wave additive kernel [512,32,256,256]", 8 * u2.numel(), lambda: wave.residual(u2, boundary=True))
+    u5 = torch.randn(8192, 200, 512, device=dev, generator=g)
+    bur = R.Burgers(2.0 / 512, 1.25 / 200, 0.002)
+    measure("C5 Burgers [8192,200,512]", 8 * u5.numel(), lambda: bur.residual(u5, boundary=True))
+    adv = R.Advection(1.0, 0.005, 0.01, disc=2)
+    measure("advection additive kernel [8192,200,512]", 8 * u5.numel(), lambda: adv.residual(u5, boundary=True))
+    del u2, u5
+    w = torch.rand(B4, 6, 64, 256, 256, device=dev, generator=g).add_(0.5)
     # JOREK: [BS,F,Nx,Ny,Nt] in the script; here the fields Ny-contiguous ([BS,F,Nt,Nx,Ny] permuted to the script's axes)
     jv = w[:, :3].permute(0, 1, 3, 4, 2)                          # -> unstack_fields gives [BS,Nt,Nx,Ny] views, Ny fastest
     jk = R.JOREK(torch.linspace(1.0, 2.0, 256), device=dev)
