@@ -174,7 +174,10 @@ def run_secondary(args, cfg, dev, group, rank, world, par):
     elif kind == "wave":
         u = synth_(torch.empty(B, T, X, Y, device=dev), 100 * rank + 2)
         op = R.PRE_Wave(dt=0.005, dx=0.01, c=1.0)
-        evaluate = lambda: op.residual(u, boundary=True, absolute=absolute)
+        # marginal: the residual's rows (samples) 64 floats further apart than they are long - a power-of-two row
+        # distance costs the per-cell select that follows 4 % (pipeline.row_padded, profiles/r03/row_pitch.txt)
+        wout = pipeline.row_padded(B, (T, X, Y), device=dev) if (args.mode == "marginal" and group is None) else None
+        evaluate = lambda: op.residual(u, boundary=True, absolute=absolute, out=wout)
         crop, cells = (1, 1, 1), B * T * X * Y
     else:
         v = torch.empty(B, 6, T, X, Y, device=dev)              # rho, u, v, p, Bx, By (Marginal/MHD_Residuals_CP.py:225)
