@@ -2095,3 +2095,19 @@ def test_row_stride_beyond_32_bit_offsets_takes_the_generic_route(gpu):
     ns = NavierStokes(1e-2, 0.1, 0.1, nu=1e-3, device=gpu)
     a, b = ns.residual_momentum(view, boundary=True), ns.residual_momentum(vals, boundary=True)
     assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= RES_TOL
+
+
+def test_plane_offsets_between_2_and_4_gigabytes_stream(gpu):
+    """The streaming kernels' 32-bit plane offsets are UNSIGNED: a view whose last rows lie more than 2^31 bytes into
+    the plane (16 rows 128 MB apart) still takes the streaming kernel and comes out bit-identical to the dense copy."""
+    from cp_pre_amd.convops_2d import ConvOperator
+    pitch = 1 << 25
+    X, Y, T = 16, 256, 2
+    big = torch.zeros(T * X * pitch + 256, device=gpu)
+    g = torch.Generator().manual_seed(6)
+    vals = torch.randn(1, T, X, Y, generator=g).to(gpu)
+    view = big.as_strided((1, T, X, Y), (0, X * pitch, pitch, 1))
+    view.copy_(vals)
+    D = ConvOperator(("x", "y"), 2, device=gpu)
+    D.kernel = D.kernel + 0.5 * ConvOperator("t", 2, device=gpu).kernel
+    assert torch.equal(D(view), D(vals.contiguous()))
