@@ -15,6 +15,7 @@ import torch  # imported first on purpose: the .so must bind to the HIP runtime 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libcp_pre_hip.so")
 
+PRE_ABI_VERSION = 8            # include/cp_pre_hip.h: the version SIGNATURES below was written for
 PRE_OK, PRE_E_NULL, PRE_E_SHAPE, PRE_E_UNSUPPORTED, PRE_E_RANGE = 0, -1, -2, -3, -4
 PRE_FLAG_ABS = 1
 PRE_FLAG_INTERIOR_T = 2
@@ -54,6 +55,7 @@ SIGNATURES = {
     "pre_spatial2d_bc_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_int64), POINTER(c_float), POINTER(PreBC), c_int64, c_int64, c_int64, c_int, c_void_p],
     "pre_spatial2d_linear2_bc_f32": [_fp, POINTER(c_int64), _fp, POINTER(c_int64), _fp, POINTER(c_int64), POINTER(c_float), POINTER(c_float),
                                      c_float, POINTER(PreBC), c_int64, c_int64, c_int64, c_int, c_void_p],
+    "pre_edge_residual_f32": [_fld, c_int, c_float, c_int64, c_int64, c_int64, c_int64, _fp, c_void_p],
     "pre_absdiff_f32": [_fp, _fp, _fp, c_int64, c_void_p],
     "pre_std_axis0_f32": [_fp, _fp, c_int64, c_int64, c_float, _fp, c_void_p],
     "pre_moments_axis0_f64": [_fp, _fp, c_int64, c_int64, c_int64, _fp, _fp, c_void_p],
@@ -62,6 +64,8 @@ SIGNATURES = {
     "pre_kth_f32": [_fp, c_int64, POINTER(c_int64), c_int, _fp, c_void_p],
     "pre_kth_axis0_f32": [_fp, c_int64, c_int64, POINTER(c_int32), c_int, _fp, c_void_p],
     "pre_kth_axis0_strided_f32": [_fp, c_int64, c_int64, c_int64, POINTER(c_int32), c_int, _fp, c_void_p],
+    "pre_kth_axis0_planes_f32": [_fp, c_int64, c_int64, c_int64, c_int64, c_int64, POINTER(c_int32), c_int, _fp, c_int64, c_int64, c_void_p],
+    "pre_joint_score_pruned_max_segments": [],
     "pre_cov_count_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int, _fp, c_void_p],
     "pre_cov_rowcount_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int, c_int, _fp, c_void_p],
     "pre_cov_joint_f32": [_fp, _fp, _fp, c_int64, c_int64, c_int, _fp, c_void_p],
@@ -109,10 +113,17 @@ def load():
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  cp_pre_amd has no CPU fallback.")
         lib = ctypes.CDLL(SO_PATH)
+        # first: a stale .so with the same symbol names but other signatures would pass misaligned arguments into a
+        # kernel launch
+        lib.pre_abi_version.argtypes, lib.pre_abi_version.restype = [], c_int
+        have = lib.pre_abi_version()
+        if have != PRE_ABI_VERSION:
+            raise ImportError(f"{SO_PATH} has ABI version {have}, this binding was written for {PRE_ABI_VERSION}: rebuild it "
+                              "(`python -c 'import __graft_entry__ as g; g.build()'`)")
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)        # AttributeError here = header / library out of sync
             fn.argtypes = argtypes
-            fn.restype = c_int64 if name.endswith("_bytes") else c_int
+            fn.restype = c_int64 if name.endswith(("_bytes", "_max_segments")) else c_int
         _lib = lib
     return _lib
 

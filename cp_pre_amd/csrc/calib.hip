@@ -934,6 +934,20 @@ int pre_segmin_mod_f32(const float *mod, int64_t T, int64_t X, int64_t Y, int cr
     return PRE_OK;
 }
 
+// bytes of LDS a workgroup of the current device may hold (64 KiB if the runtime cannot say)
+static int pruned_lds_max()
+{
+    int dev = 0, lds_max = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds_max <= 0) {
+        (void)hipGetLastError();
+        lds_max = 64 * 1024;
+    }
+    return lds_max;
+}
+
+int64_t pre_joint_score_pruned_max_segments(void) { return (pruned_lds_max() - 256) / 4; }
+
 int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float *mod, const uint32_t *segmax, const float *segmin,
                                int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y, float *scores,
                                uint32_t *flags, unsigned long long *stats, void *stream)
@@ -945,10 +959,7 @@ int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float
     // the work list lives in LDS, next to 136 bytes of static state: up to what a workgroup of this device may hold
     // (gfx950: 160 KiB - a whole-T slab of 62 planes x 512 x 512, the strong-scaling C3 shard, has 16384 segments);
     // above 64 KiB the kernel has to be told
-    int dev = 0, lds_max = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess)
-        lds_max = 64 * 1024;
+    const int lds_max = pruned_lds_max();
     if (total * 4 + 256 > lds_max) return PRE_E_UNSUPPORTED;
     if (total * 4 + 256 > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(joint_score_pruned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

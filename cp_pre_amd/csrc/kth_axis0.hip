@@ -73,6 +73,16 @@ constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16, KA_MAPROW = 68;
 constexpr int KA_LATE_WORDS = KA_MAXK * 64 * 32;          // later sweeps (and up to 31-entry collect lists): 80 KiB
 constexpr int KA_FLAGS_AT = 1008;                         // per-wave flags (words 640..1023 are never used otherwise)
 struct KAList { int nk; int k[KA_MAXK]; int o[KA_MAXK]; };    // ranks (ascending) and the output row of each
+// A launch selects `planes` independent [n, M] score matrices (plane p at s + p * PS, its result rows at out + p * OPS, the
+// rows of a result OS apart): the tiles of all planes form ONE grid, tile t = (plane t / tpp, cells 64 (t % tpp) ...), so a
+// driver that holds a time-major residual slab (pipeline.time_major: [T][n][plane]) selects all its planes in one launch
+// instead of T launches that each end on a ragged round of workgroups.
+struct KAPlanes { long long tpp, PS, OS, OPS; };
+__device__ __forceinline__ void ka_locate(const KAPlanes &pl, long long tile, long long &plane, long long &c0)
+{
+    plane = tile / pl.tpp;                 // (wave-uniform, once per tile)
+    c0 = (tile - plane * pl.tpp) * KA_W;
+}
 
 template <bool WIDE> struct Ctr {
     static constexpr int CW = WIDE ? 64 : 32;             // words per histogram row
@@ -598,7 +608,7 @@ __device__ __forceinline__ void ka_collect(const Src &src, int nk, int known,
 // one tile (64 cells from c0) of the streaming form, all phases, by the whole workgroup
 template <int LOG_NB1, bool WIDE>
 __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long long M, long long S, long long c0, const KAList &kl,
-                                        int fast, float *__restrict__ out, unsigned int *hist)
+                                        int fast, float *__restrict__ out, long long OS, unsigned int *hist)
 {
     using Cfg = KACfg<LOG_NB1, WIDE>;
     constexpr int U = Cfg::U, BITS = Cfg::BITS;
@@ -618,7 +628,7 @@ __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long
     if (fast) {
         unsigned int key = 0u;
         if (ka_fast<LOG_NB1, WIDE>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid)) {
-            if (state && cok) out[(long long)kl.o[wave] * M + c] = key2f(key);
+            if (state && cok) out[(long long)kl.o[wave] * OS + c] = key2f(key);
             return;
         }
         __syncthreads();                   // (every wave has read the flags before the histogram memory is cleared again)
@@ -654,16 +664,18 @@ __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long
     __syncthreads();
     if (nanl) hist[lane] = 1u;
     __syncthreads();
-    if (state && cok) out[(long long)kl.o[wave] * M + c] = hist[lane] ? __uint_as_float(0x7fc00000u) : key2f(myp + klo);
+    if (state && cok) out[(long long)kl.o[wave] * OS + c] = hist[lane] ? __uint_as_float(0x7fc00000u) : key2f(myp + klo);
 }
 
 template <int LOG_NB1, bool WIDE>
 __global__ void __launch_bounds__(1024, (4 * KACfg<LOG_NB1, WIDE>::WG_PER_CU))
 kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long S, long long tile0, const KAList kl, int fast,
-                 float *__restrict__ out)
+                 float *__restrict__ out, const KAPlanes pl)
 {
     __shared__ unsigned int hist[KACfg<LOG_NB1, WIDE>::WORDS];
-    ka_tile<LOG_NB1, WIDE>(s, n, M, S, (tile0 + blockIdx.x) * KA_W, kl, fast, out, hist);
+    long long plane, c0;
+    ka_locate(pl, tile0 + blockIdx.x, plane, c0);
+    ka_tile<LOG_NB1, WIDE>(s + plane * pl.PS, n, M, S, c0, kl, fast, out + plane * pl.OPS, pl.OS, hist);
 }
 
 // ---- 128 < n <= 1024: the tile lives in REGISTERS ---------------------------------------------------------------
@@ -817,7 +829,7 @@ __device__ __forceinline__ unsigned int kt_pick(const unsigned int *hist, int sl
 template <int LOG_NB1, int R, int WGS>
 __global__ void __launch_bounds__(1024, 4 * WGS)
 kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, long long ntiles, const KAList kl,
-                float *__restrict__ out)
+                float *__restrict__ out, const KAPlanes pl)
 {
     using Cfg = KTCfg<LOG_NB1, WGS>;
     using C = Ctr<false>;
@@ -836,10 +848,11 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     long long tile = blockIdx.x;
     float v[R];
     {
-        const long long c0 = tile * KA_W;
+        long long plane, c0;
+        ka_locate(pl, tile, plane, c0);
         const int valid = (int)((M - c0) * 4 < 256 ? (M - c0) * 4 : 256);
         const int nu = (n - wave0 + KA_WAVES - 1) / KA_WAVES;
-        const float *p = s + c0 + (long long)wave0 * S;
+        const float *p = s + plane * pl.PS + c0 + (long long)wave0 * S;
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             v[u] = kt_row(p, u < nu ? valid : 0, (tid0 & 63) * 4);
@@ -939,11 +952,13 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             fl = __builtin_amdgcn_readfirstlane(fl);
         }
 
-        const long long c0 = tile * KA_W;
+        long long plane, c0, nplane, nc0;
+        ka_locate(pl, tile, plane, c0);
         const bool more = tile + gridDim.x < ntiles;               // (block-uniform)
-        const long long nc0 = more ? (tile + gridDim.x) * KA_W : c0;
+        ka_locate(pl, more ? tile + gridDim.x : tile, nplane, nc0);
         const int nvalid = more ? (int)((M - nc0) * 4 < 256 ? (M - nc0) * 4 : 256) : 0;
-        const float *nbase = s + nc0 + (long long)wave * S;        // my first row of the next tile
+        const float *nbase = s + nplane * pl.PS + nc0 + (long long)wave * S;        // my first row of the next tile
+        float *outp = out + plane * pl.OPS;
 
         // ---- collect + pick (when every pair has its <= CAP candidates: ok, block-uniform).  The list of a rank = the
         // list of the FIRST rank of its cell with the same row.
@@ -1025,7 +1040,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
                 }
             }
             const long long c = c0 + lane;
-            if (state && c < M) out[(long long)kl.o[wave] * M + c] = nancell ? __uint_as_float(0x7fc00000u) : key2f(ans);
+            if (state && c < M) outp[(long long)kl.o[wave] * pl.OS + c] = nancell ? __uint_as_float(0x7fc00000u) : key2f(ans);
             if (first) {                                            // leave the map and the counters as they were found
                 map[myrow * KA_MAPROW + lane] = 0;
                 cnt[wave * 64 + lane] = 0u;
@@ -1035,7 +1050,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             // window): the tile is MARKED - a NaN pattern no result can have, in the first rank's output of its first
             // cell - and redone by the streaming form after this loop (in the loop its code would compete with the 64
             // data registers)
-            out[(long long)kl.o[0] * M + c0] = __uint_as_float(KT_MARK);
+            outp[(long long)kl.o[0] * pl.OS + c0] = __uint_as_float(KT_MARK);
         }
         lds_barrier();
     }
@@ -1044,18 +1059,24 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     __syncthreads();
     {
         const int lane = threadIdx.x & 63;
-        const float *marks = out + (long long)kl.o[0] * M;
+        const float *marks = out + (long long)kl.o[0] * pl.OS;
         const long long mine = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;      // tiles blockIdx.x + i gridDim.x
 #pragma unroll 1
         for (long long ib = 0; ib < mine; ib += 64) {
             const long long t = blockIdx.x + (ib + lane) * gridDim.x;
-            const bool mk = ib + lane < mine && __float_as_uint(marks[t * KA_W]) == KT_MARK;
+            bool mk = false;
+            if (ib + lane < mine) {
+                const long long tp = t / pl.tpp;
+                mk = __float_as_uint(marks[tp * pl.OPS + (t - tp * pl.tpp) * KA_W]) == KT_MARK;
+            }
             unsigned long long todo = __ballot(mk);
 #pragma unroll 1
             while (todo) {
                 const int b = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                ka_tile<9, false>(s, n, M, S, (blockIdx.x + (ib + b) * gridDim.x) * KA_W, kl, 1, out, lds);
+                long long plane, c0;
+                ka_locate(pl, blockIdx.x + (ib + b) * gridDim.x, plane, c0);
+                ka_tile<9, false>(s + plane * pl.PS, n, M, S, c0, kl, 1, out + plane * pl.OPS, pl.OS, lds);
                 __syncthreads();
             }
         }
@@ -1123,11 +1144,16 @@ __device__ __forceinline__ unsigned int ks_take(const unsigned int (&v)[N], int 
 
 template <int N>
 __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict__ s, int n, long long M, long long S, const KAList kl,
-                                                       float *__restrict__ out)
+                                                       float *__restrict__ out, const KAPlanes pl, long long ntiles)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long c0 = ((long long)blockIdx.x * 4 + wave) * KA_W, c = c0 + lane;
-    if (c0 >= M) return;                   // whole wave beyond the last tile
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;            // whole wave beyond the last tile
+    long long plane, c0;
+    ka_locate(pl, tile, plane, c0);
+    const long long c = c0 + lane;
+    s += plane * pl.PS;
+    out += plane * pl.OPS;
     const bool cok = c < M;
     // all row loads first, unconditionally (rows beyond n re-read row n-1, lanes beyond M are dropped by the buffer's
     // range check): a load inside its own `if` is waited for on the spot, and 128 serialised HBM latencies are what
@@ -1152,29 +1178,31 @@ __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict_
     for (int j = 0; j < KA_MAXK; ++j) {
         if (j >= kl.nk) break;                                    // wave-uniform
         const unsigned int r = ks_take<N>(v, kl.k[j]);
-        if (cok) out[(long long)kl.o[j] * M + c] = nan ? __uint_as_float(0x7fc00000u) : key2f(r);
+        if (cok) out[(long long)kl.o[j] * pl.OS + c] = nan ? __uint_as_float(0x7fc00000u) : key2f(r);
     }
 }
 
 template <int N>
-int launch_kth_small(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
+int launch_kth_small(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out,
+                     const KAPlanes &pl, long long planes, hipStream_t st)
 {
-    const long long blocks = ((M + KA_W - 1) / KA_W + 3) / 4;
+    const long long tiles = pl.tpp * planes, blocks = (tiles + 3) / 4;
     if (blocks > 0x7fffffffLL) return PRE_E_SHAPE;
     for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : -1; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
-        hipLaunchKernelGGL((kth_small_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, S, kl, out);
+        hipLaunchKernelGGL((kth_small_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, S, kl, out, pl, tiles);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
 }
 
 template <int LOG_NB1, bool WIDE>
-int launch_kth(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
+int launch_kth(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out,
+               const KAPlanes &pl, long long planes, hipStream_t st)
 {
-    const long long tiles = (M + KA_W - 1) / KA_W;
+    const long long tiles = pl.tpp * planes;
     const long long per_launch = 1LL << 21;                     // x 1024 threads: the dispatch packet counts work-items in 32 bits
     for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
         KAList kl;
@@ -1185,7 +1213,7 @@ int launch_kth(const float *scores, int n, long long M, long long S, const int32
             // the fast first digit pays while a full bucket holds well under CAP elements (n <= ~6 NB1 on
             // bell-shaped scores); beyond that it would be a wasted sweep
             hipLaunchKernelGGL((kth_axis0_kernel<LOG_NB1, WIDE>), dim3((unsigned)nt), dim3(1024), 0, st, scores, n, M, S, t0, kl,
-                               n <= 6 * (1 << LOG_NB1) ? 1 : 0, out);
+                               n <= 6 * (1 << LOG_NB1) ? 1 : 0, out, pl);
             PRE_LAUNCH_CHECK();
         }
     }
@@ -1193,9 +1221,10 @@ int launch_kth(const float *scores, int n, long long M, long long S, const int32
 }
 
 template <int LOG_NB1, int R, int WGS>
-int launch_kth_tile(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out, hipStream_t st)
+int launch_kth_tile(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out,
+                    const KAPlanes &pl, long long planes, hipStream_t st)
 {
-    const long long tiles = (M + KA_W - 1) / KA_W;
+    const long long tiles = pl.tpp * planes;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
@@ -1204,7 +1233,7 @@ int launch_kth_tile(const float *scores, int n, long long M, long long S, const 
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
-        hipLaunchKernelGGL((kth_tile_kernel<LOG_NB1, R, WGS>), dim3((unsigned)grid), dim3(1024), 0, st, scores, n, M, S, tiles, kl, out);
+        hipLaunchKernelGGL((kth_tile_kernel<LOG_NB1, R, WGS>), dim3((unsigned)grid), dim3(1024), 0, st, scores, n, M, S, tiles, kl, out, pl);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
@@ -1212,13 +1241,21 @@ int launch_kth_tile(const float *scores, int n, long long M, long long S, const 
 
 }  // namespace
 
-extern "C" int pre_kth_axis0_strided_f32(const float *scores, int64_t row_stride, int64_t n, int64_t M, const int32_t *ks, int nk,
-                                         float *out, void *stream)
+extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_stride, int64_t row_stride, int64_t planes, int64_t n,
+                                        int64_t M, const int32_t *ks, int nk, float *out, int64_t out_rank_stride,
+                                        int64_t out_plane_stride, void *stream)
 {
-    if (!scores || !ks || !out || n <= 0 || M <= 0 || nk <= 0) return PRE_E_NULL;
-    if (row_stride < M) return PRE_E_RANGE;
+    if (!scores || !ks || !out || n <= 0 || M <= 0 || nk <= 0 || planes <= 0) return PRE_E_NULL;
+    if (row_stride < M || out_rank_stride < M || plane_stride < 0 || out_plane_stride < 0) return PRE_E_RANGE;
+    if (planes > 1 && (plane_stride < M || out_plane_stride < M)) return PRE_E_RANGE;
     const long long S = (long long)row_stride;
     if (n > 0x7fffffff || nk > 64) return PRE_E_SHAPE;
+    KAPlanes pl;
+    pl.tpp = ((long long)M + KA_W - 1) / KA_W;
+    pl.PS = (long long)plane_stride;
+    pl.OS = (long long)out_rank_stride;
+    pl.OPS = (long long)out_plane_stride;
+    if (pl.tpp > 0x7fffffffLL || planes > 0x7fffffffLL || pl.tpp * planes > (1LL << 40)) return PRE_E_SHAPE;
     // the kernels want ascending ranks (their slots rely on it): sort here, each result goes to its caller's row
     int32_t sk[64], rows[64];
     for (int j = 0; j < nk; ++j) {
@@ -1230,23 +1267,32 @@ extern "C" int pre_kth_axis0_strided_f32(const float *scores, int64_t row_stride
     }
     ks = sk;
     hipStream_t st = as_stream(stream);
-    if (n <= 64) return launch_kth_small<64>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
-    if (n <= 128) return launch_kth_small<128>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
+    const long long P = (long long)planes;
+#define KA_ARGS scores, (int)n, (long long)M, S, ks, rows, nk, out, pl, P, st
+    if (n <= 64) return launch_kth_small<64>(KA_ARGS);
+    if (n <= 128) return launch_kth_small<128>(KA_ARGS);
     // 128 < n <= 1024: the tile in registers, read once (16, 24, 32 rows per thread: two workgroups per CU; 48, 64: one).
     // Every instantiation serves R/2 < rows per thread <= R (its first R/2 rows need no "is this row below n" test)
-    if (n <= 256) return launch_kth_tile<8, 16, 2>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
+    if (n <= 256) return launch_kth_tile<8, 16, 2>(KA_ARGS);
+    if (n <= 384) return launch_kth_tile<8, 24, 2>(KA_ARGS);
+    if (n <= 512) return launch_kth_tile<8, 32, 2>(KA_ARGS);
+    if (n <= 768) return launch_kth_tile<9, 48, 1>(KA_ARGS);
+    if (n <= 1024) return launch_kth_tile<9, 64, 1>(KA_ARGS);
     // 16-bit counters hold n < 65536; 1024 first-digit buckets (one workgroup per CU) pay off once 512 buckets
     // would leave more than CAP elements per bucket (n above ~2000)
-    if (n <= 384) return launch_kth_tile<8, 24, 2>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
-    if (n <= 512) return launch_kth_tile<8, 32, 2>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
-    if (n <= 768) return launch_kth_tile<9, 48, 1>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
-    if (n <= 1024) return launch_kth_tile<9, 64, 1>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
-    if (n >= 65536) return launch_kth<9, true>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
-    if (n > 2048) return launch_kth<10, false>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
-    return launch_kth<9, false>(scores, (int)n, (long long)M, S, ks, rows, nk, out, st);
+    if (n >= 65536) return launch_kth<9, true>(KA_ARGS);
+    if (n > 2048) return launch_kth<10, false>(KA_ARGS);
+    return launch_kth<9, false>(KA_ARGS);
+#undef KA_ARGS
+}
+
+extern "C" int pre_kth_axis0_strided_f32(const float *scores, int64_t row_stride, int64_t n, int64_t M, const int32_t *ks, int nk,
+                                         float *out, void *stream)
+{
+    return pre_kth_axis0_planes_f32(scores, 0, row_stride, 1, n, M, ks, nk, out, M, 0, stream);
 }
 
 extern "C" int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *ks, int nk, float *out, void *stream)
 {
-    return pre_kth_axis0_strided_f32(scores, M, n, M, ks, nk, out, stream);
+    return pre_kth_axis0_planes_f32(scores, 0, M, 1, n, M, ks, nk, out, M, 0, stream);
 }

@@ -472,11 +472,43 @@ __global__ void __launch_bounds__(256) wgrad27_kernel(const float *__restrict__ 
     }
 }
 
+// periodic-wall mismatch (Marginal/NS_Residuals_CP.py:468-478): out[b,t,i] = (u[b,t,P(i)] - u[b,t,Q(i)]) * dx with P, Q
+// two opposite edges of the [X,Y] plane.  O(B T L) work: one thread per output, edge offsets precomputed by the host.
+__global__ void __launch_bounds__(256) edge_residual_kernel(const float *__restrict__ u, long long sB, long long sT, long long sI,
+                                                            long long offP, long long offQ, long long T, long long L,
+                                                            long long total, float dx, float *__restrict__ out)
+{
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const long long i = g % L, bt = g / L, t = bt % T, b = bt / T;
+    const float *row = u + b * sB + t * sT + i * sI;
+    out[g] = (row[offP] - row[offQ]) * dx;
+}
+
 }  // namespace
 
 extern "C" {
 
-int pre_abi_version(void) { return 7; }
+int pre_abi_version(void) { return 8; }
+
+int pre_edge_residual_f32(const pre_field_t *u, int wall, float dx, int64_t B, int64_t T, int64_t X, int64_t Y, float *out,
+                          void *stream)
+{
+    if (!u || !u->ptr || !out) return PRE_E_NULL;
+    if (B < 0 || T < 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
+    if (wall < 0 || wall > 3) return PRE_E_RANGE;
+    // top: u[0,:] - u[X-1,:]   bottom: u[X-1,:] - u[0,:]   (rows; L = Y)     left: u[:,0] - u[:,Y-1]   right: the opposite (L = X)
+    const bool rows = wall < 2;
+    const long long L = rows ? Y : X, sI = rows ? u->sY : u->sX, far = rows ? (X - 1) * u->sX : (Y - 1) * u->sY;
+    const long long offP = (wall == 0 || wall == 2) ? 0 : far, offQ = far - offP;
+    const long long total = (long long)B * T * L;
+    if (total == 0) return PRE_OK;
+    if ((total + 255) / 256 > 0x7fffffffLL) return PRE_E_SHAPE;
+    hipLaunchKernelGGL(edge_residual_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), u->ptr,
+                       (long long)u->sB, (long long)u->sT, sI, offP, offQ, (long long)T, L, total, dx, out);
+    PRE_LAUNCH_CHECK();
+    return PRE_OK;
+}
 
 int pre_stencil3d_f32(const pre_field_t *in, const pre_out_t *out, const float *tap_w, const int32_t *tap_off, int ntaps,
                       int64_t B, int64_t T, int64_t X, int64_t Y, int flags, void *stream)

@@ -88,25 +88,59 @@ class HipOps:
     # the joint calibration is a few launch latencies either way and sigma-hat is too noisy for tight bounds
     PRUNE_MIN_CELLS = 1 << 27
     PRUNE_MIN_SAMPLES = 256
-    PRUNE_MAX_SEGMENTS = (160 * 1024 - 256) // 4      # pre_joint_score_pruned_f32's work list: the LDS of a gfx950 workgroup
+    _max_segments = None
+
+    @staticmethod
+    def prune_max_segments():
+        """Longest work list ``pre_joint_score_pruned_f32`` accepts on the current device: it lives in the LDS of one
+        workgroup, and the library reports what this device gives one (gfx950: 160 KiB -> 40 896 segments)."""
+        if HipOps._max_segments is None:
+            HipOps._max_segments = int(_lib.load().pre_joint_score_pruned_max_segments())
+        return HipOps._max_segments
+
+    @staticmethod
+    def dense_order(res):
+        """(cell-axis order in memory, dense?) of [n, *cells] WITHOUT touching the data: order None = as written."""
+        if res.is_contiguous():
+            return None, True
+        if res.dim() >= 3:
+            order = sorted(range(1, res.dim()), key=lambda k: (-res.stride(k), k))
+            if res.permute(0, *order).is_contiguous():
+                return order, True
+        return None, False
+
+    @staticmethod
+    def interior_planes(res, crop):
+        """Planes per side of the slowest cell axis IN MEMORY that lie inside ``crop`` and are therefore left out of the
+        moments (they may hold garbage, ``PRE_FLAG_INTERIOR_T``): a function of shape, layout and crop alone, the same
+        on the pruned and on the plain route - it fixes the length of the moment vector the ranks all-reduce."""
+        if res.dim() != 4:
+            return 0
+        order, dense = HipOps.dense_order(res)
+        if not dense:
+            return 0
+        slow = 1 if order is None else order[0]
+        c0 = int(crop[slow - 1])
+        return c0 if (c0 > 0 and res.shape[slow] > 2 * c0) else 0
 
     @staticmethod
     def prune_view(res, crop):
         """(contiguous view of ``res`` with its cell axes in memory order, the crop in that order) when the
         branch-and-bound score applies, else None.  It takes a dense [n,T,X,Y] tensor in any axis order (the surrogate's
         Nt-fastest layout included: a segment is defined on the memory order) with at least one plane of the slowest
-        cell axis inside its crop and at most ``PRUNE_MAX_SEGMENTS`` segments (64 consecutive cells of the two faster
+        cell axis inside its crop and at most ``prune_max_segments()`` segments (64 consecutive cells of the two faster
         axes' flattened plane x 16 planes) per sample - the work list lives in LDS; it pays from a few hundred samples
         and ~1e8 cells on."""
         if res.dim() != 4 or res.numel() < HipOps.PRUNE_MIN_CELLS or res.shape[0] < HipOps.PRUNE_MIN_SAMPLES:
             return None
-        resc, order = icp.canon(res)
-        if order is None and not res.is_contiguous():
-            return None                                            # not dense: canon copied it
+        order, dense = HipOps.dense_order(res)
+        if not dense:
+            return None
+        resc = res if order is None else res.permute(0, *order)
         cropc = tuple(crop) if order is None else tuple(crop[o - 1] for o in order)
         A0, A1, A2 = resc.shape[1:]
         planes = A0 - 2 * cropc[0]
-        if planes < 1 or ((planes + 15) // 16) * ((A1 * A2 + 63) // 64) > HipOps.PRUNE_MAX_SEGMENTS:
+        if planes < 1 or ((planes + 15) // 16) * ((A1 * A2 + 63) // 64) > HipOps.prune_max_segments():
             return None
         return resc, cropc
 
@@ -159,6 +193,17 @@ class HipOps:
     def kth(scores, ks):
         return icp.kth_axis0(scores, ks)
 
+    @staticmethod
+    def kth_planes(base, plane_stride, row_stride, planes, n, per, ks, out, out_rank_stride, out_plane_stride):
+        """Order statistics ``ks`` of ``planes`` score matrices [n, per] in ONE launch (``pre_kth_axis0_planes_f32``):
+        plane p starts ``p * plane_stride`` floats behind ``base``'s first element, its rows ``row_stride`` apart; rank j
+        of plane p goes to ``out`` at ``j * out_rank_stride + p * out_plane_stride`` floats."""
+        with torch.cuda.device(base.device):
+            _lib.check(_lib.load().pre_kth_axis0_planes_f32(_lib.ptr(base), plane_stride, row_stride, planes, n, per,
+                                                            _lib.iarr32([int(k) for k in ks]), len(ks), _lib.ptr(out),
+                                                            out_rank_stride, out_plane_stride, _lib.stream()),
+                       "pre_kth_axis0_planes_f32")
+
 
 def _ranks(n_total, alphas):
     return [icp.kth_index(n_total, n_total, a) for a in alphas]
@@ -179,15 +224,34 @@ class JointCalibration:
     PRUNE_GIVE_UP = 0.25
 
     def __init__(self, n_local, device, eps=0.0, group=None, ops=None, prune=True):
+        """``prune``: True / "adaptive" (bounds on the first slab, kept or dropped for the rest of the stream by what they
+        saved there: ONE host read of two device counters when the second slab arrives - and, in a group, one 16-byte
+        all-reduce of them, so that every rank takes the same route), "always" (no host read, no extra collective:
+        ``add_slab`` never synchronises and can be captured in a HIP graph), False / "never" (the full score pass)."""
         self.ops = ops or HipOps
-        self.prune = prune
+        if prune not in (True, False, "adaptive", "always", "never"):
+            raise ValueError(f"prune={prune!r}: True / 'adaptive', 'always', False / 'never'")
+        self.prune = prune not in (False, "never")
+        self.prune_checked = prune == "always"     # nothing left to decide
         self.prune_stats = None        # device [segments read, segments, samples swept whole] over the pruned slabs
-        self.prune_checked = False
         self.group, self.eps, self.n_local, self.device = group, eps, n_local, device
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
         self.n_total = n_local * self.world
         self.scores = self.ops.zeros_scores(n_local, device)
         self.modulation = []           # one [T_slab, X, Y] array per slab, in call order
+
+    def _keep_pruning(self):
+        """Were the bounds worth their segment maxima on the first pruned slab?  Decided ONCE per stream, when its second
+        slab arrives (a single-slab stream never synchronises for it), and by the WHOLE GROUP: the counters of all ranks
+        are summed (RCCL all-reduce of two int64) before the threshold is applied, so no rank can leave the pruned route
+        alone.  (The collectives that carry data - the moments all-reduce, the score all-gather - have sizes fixed by the
+        slab's shape and layout either way, see ``add_slab``; this keeps the ranks' kernels, and so their pace, alike.)"""
+        st = self.prune_stats[:2]
+        if self.group is not None:
+            st = st.clone()
+            torch.distributed.all_reduce(st, group=self.group)
+        read, total = (int(v) for v in st.tolist())                 # the stream's one host read
+        return not (total and read > self.PRUNE_GIVE_UP * total)
 
     def add_slab(self, res, crop=(1, 1, 1)):
         """``res``: UNCROPPED residual slab [n_local, T_slab, X, Y]; ``crop`` cells per side are excluded
@@ -197,27 +261,28 @@ class JointCalibration:
         per-segment maxima of |res| and the score pass reads only the segments that can still raise a sample's
         score - the same scores for the same modulation, bit for bit (``prune=False`` forces the full pass).  The
         route adapts to the data: a sample whose bounds prune little is flagged and takes the full pass, and a stream
-        whose first pruned slab read more than ``PRUNE_GIVE_UP`` of its segments takes the plain passes from its
-        second slab on."""
+        whose first pruned slab read more than ``PRUNE_GIVE_UP`` of its segments (summed over the group) takes the plain
+        passes from its second slab on.
+
+        Collectives issued per slab, in this order on every rank: [second slab of an adaptive stream only: all-reduce of
+        2 int64], all-reduce of the fp64 moments [2, cells reduced].  ``cells reduced`` follows from the slab's shape,
+        its memory layout and ``crop`` ALONE (the planes of the slowest memory axis inside its crop), never from the
+        route or from anything a rank measured: ranks may only be grouped if they stream slabs of the same shape and
+        layout, and then their collectives match whatever their data."""
         ops = self.ops
         M = res[0].numel() if hasattr(res[0], "numel") else res[0].size
         if self.prune and self.prune_stats is not None and not self.prune_checked:
-            # ONE host read per stream, when its SECOND slab arrives (a single-slab stream never synchronises for it):
-            # were the bounds worth their segment maxima on the first?  (Every rank reads its own counters; the
-            # decision only changes which LOCAL kernels run.)
             self.prune_checked = True
-            read, total, _ = (int(v) for v in self.prune_stats.tolist())
-            if total and read > self.PRUNE_GIVE_UP * total:
-                self.prune = False
+            self.prune = self._keep_pruning()
         view = ops.prune_view(res, crop) if self.prune and getattr(ops, "prune_view", None) else None
+        # the planes the moments cover: layout alone decides (the same on the pruned and on the plain route)
+        layout = getattr(ops, "interior_planes", None)
+        skip = layout(res, crop) if layout else 0
         if view is not None:
             resc, cropc = view                                           # cell axes in memory order
-            skip = cropc[0]                                              # planes of the slowest axis inside its crop only
-        else:
-            skip = crop[0] if (getattr(ops, "interior_t", False) and crop[0] > 0 and res.is_contiguous()
-                               and res.shape[1] > 2 * crop[0]) else 0
+            assert skip == cropc[0], (skip, cropc)                       # (prune_view only takes dense slabs)
         kw = {"skip_t": skip} if skip else {}
-        mom = ops.zeros_moments(M - 2 * skip * (M // (resc if view is not None else res).shape[1]), self.device)
+        mom = ops.zeros_moments(M - (2 * skip * self._plane_cells(res) if skip else 0), self.device)
         if view is not None:
             segmax = ops.add_moments_segmax(resc, mom, cropc)
         else:
@@ -234,6 +299,14 @@ class JointCalibration:
             ops.max_scores(res, mod, crop, self.scores)
         self.modulation.append(mod)
         return mod
+
+    @staticmethod
+    def _plane_cells(res):
+        """Cells of one plane of the slowest cell axis IN MEMORY of a dense [n, T, X, Y] slab."""
+        if res.dim() < 3:
+            return 0
+        slow = max(range(1, res.dim()), key=lambda k: (res.stride(k), -k))
+        return res[0].numel() // res.shape[slow]
 
     def score_pass_read_frac(self):
         """Share of the residual's segments the pruned score passes of this stream read (None: no pruned slab)."""
@@ -300,12 +373,27 @@ def _is_time_major(scores):
     return pitch >= per and (T == 1 or scores.stride(1) == n * pitch) and (n == 1 or T == 1 or pitch < scores.stride(1))
 
 
-def _marginal_planes(scores, alphas, group, ops, overlap):
-    """Sharded per-cell q-hat of a TIME-MAJOR score tensor [n_local, T, *rest]: no pack copy, one all-to-all per run of
-    ``world`` planes (plane t goes to rank t % world, which selects over all n_local * world samples of it), one
-    all-gather of the q-hat planes at the end.  Bytes on the wire per rank: (world-1)/world of its scores once
-    (4 B x n_local x cells), + nk/n_local of that for the q-hats.  Staging: ONE received plane of all samples
-    (4 B x n_local x world x cells per plane), twice with ``overlap``."""
+def _select_planes(ops, base, plane_stride, row_stride, planes, n, per, ks, out, out_rank_stride, out_plane_stride):
+    """All ``planes`` score matrices in one launch when the back end can (``kth_planes``), else plane by plane."""
+    if getattr(ops, "kth_planes", None):
+        ops.kth_planes(base, plane_stride, row_stride, planes, n, per, ks, out, out_rank_stride, out_plane_stride)
+        return
+    flat, oflat = base.reshape(-1) if base.is_contiguous() else base, out.reshape(-1)
+    for pl in range(planes):
+        rows = flat.as_strided((n, per), (row_stride, 1), flat.storage_offset() + pl * plane_stride)
+        q = ops.kth(rows, ks)                                                         # [nk, per]
+        oflat.as_strided((len(ks), per), (out_rank_stride, 1), out.storage_offset() + pl * out_plane_stride).copy_(q)
+
+
+def _marginal_planes(scores, alphas, group, ops, overlap, stage_bytes):
+    """Sharded per-cell q-hat of a TIME-MAJOR score tensor [n_local, T, *rest]: no pack copy.  Plane t goes to rank
+    t % world, which selects over all n_local * world samples of it; one all-gather of the q-hat planes at the end.
+    A RUN is ``p * world`` planes: p all-to-alls (one per plane a rank receives; each moves one plane of every sender,
+    4 B x n_local x cells, to every rank) and then ONE select launch over the p received planes - the tiles of all of
+    them in one grid, so the ragged last round of workgroups is paid once per run, not once per plane.  p = as many
+    planes as ``stage_bytes`` of receive staging hold (4 B x n_local x world x cells each; at least one; twice the
+    staging with ``overlap``).  Bytes on the wire per rank: (world-1)/world of its scores once, + nk/n_local of that
+    for the q-hats."""
     dist = torch.distributed
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n_local, T = scores.shape[0], scores.shape[1]
@@ -315,36 +403,48 @@ def _marginal_planes(scores, alphas, group, ops, overlap):
         per *= d
     ks = _ranks(n_local * world, alphas)          # raises before any collective if a level exceeds 1
     nk = len(alphas)
-    pitch = scores.stride(0) if n_local > 1 else per            # floats from one sample's plane to the next one's
+    # floats from one sample's plane to the next one's.  (A single local sample has no "next": its stride is whatever
+    # the view says; the planes then tell - they lie n_local * pitch apart.)
+    pitch = scores.stride(0) if n_local > 1 else (scores.stride(1) if T > 1 else per)
     blk = n_local * pitch                                       # one plane of all local samples, as it lies
     tm = scores.as_strided((T, blk), (blk, 1))                  # the memory as it lies: [T][n_local * pitch], no copy
-    runs = (T + world - 1) // world
+    own = (T + world - 1) // world                              # planes a rank owns at most (plane kk * world + rank)
+    p = max(1, min(own, int(stage_bytes) // (4 * world * blk)))
+    runs = (own + p - 1) // p
     nbuf = 2 if (overlap and runs > 1) else 1
-    recv = [tm.new_empty(world * blk) for _ in range(nbuf)]
-    q_own = tm.new_zeros(runs, nk, per)           # the q-hat planes this rank owns (plane k * world + rank), run by run
-    work = [None] * nbuf
+    recv = [tm.new_empty(p * world * blk) for _ in range(nbuf)]   # [p][world][n_local * pitch]
+    q_own = tm.new_zeros(own, nk, per)            # the q-hat planes this rank owns, in order
+    work = [[] for _ in range(nbuf)]
 
     def exchange(k, b):
-        t0 = k * world
-        pr = min(world, T - t0)                   # planes in this run: ranks >= pr receive nothing
-        send = tm[t0:t0 + pr].reshape(-1)         # contiguous: [pr][n_local * pitch]
-        in_split = [blk if r < pr else 0 for r in range(world)]
-        out_split = [blk if rank < pr else 0] * world
-        out = recv[b] if rank < pr else recv[b][:0]
-        return dist.all_to_all_single(out, send, out_split, in_split, group=group, async_op=nbuf > 1)
+        for j in range(p):
+            t0 = (k * p + j) * world
+            pr = min(world, T - t0)               # planes in this exchange: ranks >= pr receive nothing
+            if pr <= 0:
+                break
+            send = tm[t0:t0 + pr].reshape(-1)     # contiguous: [pr][n_local * pitch]
+            in_split = [blk if r < pr else 0 for r in range(world)]
+            out_split = [blk if rank < pr else 0] * world
+            dst = recv[b][j * world * blk:(j + 1) * world * blk]
+            out = dst if rank < pr else dst[:0]
+            w = dist.all_to_all_single(out, send, out_split, in_split, group=group, async_op=nbuf > 1)
+            if nbuf > 1:
+                work[b].append(w)
 
     def select(k):
         b = k % nbuf
-        if work[b] is not None:
-            work[b].wait()                        # the compute stream waits for run k's exchange
-            work[b] = None
-        if k * world + rank < T:
-            rows = recv[b].as_strided((world * n_local, per), (pitch, 1))        # (rows with the senders' pitch)
-            q_own[k] = ops.kth(rows, ks).reshape(nk, per)
+        for w in work[b]:
+            w.wait()                              # the compute stream waits for run k's exchanges
+        work[b] = []
+        kk0 = k * p
+        mine = sum(1 for j in range(p) if (kk0 + j) * world + rank < T)      # (the first `mine` of the run's p)
+        if mine:
+            _select_planes(ops, recv[b], world * blk, pitch, mine, world * n_local, per, ks,
+                           q_own[kk0:kk0 + mine], per, nk * per)
 
     for k in range(runs):
         b = k % nbuf
-        work[b] = exchange(k, b)
+        exchange(k, b)
         if nbuf > 1 and k > 0:
             select(k - 1)
         elif nbuf == 1:
@@ -353,8 +453,8 @@ def _marginal_planes(scores, alphas, group, ops, overlap):
         select(runs - 1)
     parts = [torch.empty_like(q_own) for _ in range(world)]
     dist.all_gather(parts, q_own, group=group)                   # nk * (planes owned) * per floats per rank
-    # parts[r][k, j] is q-hat j of plane k * world + r
-    q = torch.stack(parts, dim=1).reshape(runs * world, nk, per)[:T]          # [T, nk, per]
+    # parts[r][kk, j] is q-hat j of plane kk * world + r
+    q = torch.stack(parts, dim=1).reshape(own * world, nk, per)[:T]           # [T, nk, per]
     return q.transpose(0, 1).reshape((nk, T) + rest)
 
 
@@ -365,9 +465,10 @@ def marginal_qhat(scores, alphas, group=None, ops=None, stage_bytes=4 << 30, ove
     plane of a time-major one.  Sharded: all-to-all (batch-sharded -> cell-sharded), local select over all
     ``n_local * world`` samples, ONE all-gather of the result at the end.
 
-    A TIME-MAJOR tensor (:func:`time_major`: what a t-slab driver lets its residual kernel write) is exchanged where it
-    lies, plane by plane (``_marginal_planes``): no pack copy, no send staging.  Any other layout takes the cell-run
-    form below, which packs each run into a [world, n_local, cells-per-rank] send buffer first.
+    A TIME-MAJOR tensor (:func:`time_major`: what a slab driver lets its residual kernel write) is exchanged where it
+    lies, whole planes at a time (``_marginal_planes``): no pack copy, no send staging, and ONE select launch over all the
+    planes a run delivers (single rank: over all planes of the tensor).  Any other layout takes the cell-run form
+    below, which packs each run into a [world, n_local, cells-per-rank] send buffer first.
 
     The exchange runs over runs of cells sized so that one send and one receive staging buffer hold at most
     ``stage_bytes`` each (a C3 slab of scores is 56 GB; staging it whole next to the fields would not fit in HBM).
@@ -382,11 +483,15 @@ def marginal_qhat(scores, alphas, group=None, ops=None, stage_bytes=4 << 30, ove
     tmajor = _is_time_major(scores) and not scores.is_contiguous() and cells[0] > 1
     if world == 1:
         ks = _ranks(n_local, alphas)
-        if tmajor:                                # plane by plane: each [n_local, *rest] is contiguous
-            return torch.stack([ops.kth(scores[:, t], ks) for t in range(cells[0])], dim=1)
+        if tmajor:                                # every plane [n_local, *rest (+ pad)] where it lies, ONE launch
+            T, per = cells[0], scores[0, 0].numel()
+            out = scores.new_empty((len(ks),) + cells)
+            pitch = scores.stride(0) if n_local > 1 else per
+            _select_planes(ops, scores, scores.stride(1), pitch, T, n_local, per, ks, out, T * per, per)
+            return out
         return ops.kth(scores, ks)
     if tmajor:
-        return _marginal_planes(scores, alphas, group, ops, overlap)
+        return _marginal_planes(scores, alphas, group, ops, overlap, stage_bytes)
     if n_local * world > 0x7fffffff:
         raise ValueError(f"{n_local} x {world} calibration samples exceed the select's 32-bit sample count")
     flat = scores.reshape(n_local, -1)

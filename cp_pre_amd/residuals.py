@@ -183,13 +183,26 @@ class NavierStokes(_Residual2D):
             raise RuntimeError("halo_x: only the fused route reads the halo rows")
         return _finish(_on_device((u, v, p), composed), boundary, _CROP3, absolute, False)
 
+    _WALLS = {'top': 0, 'bottom': 1, 'left': 2, 'right': 3}
+
     def periodic_bc_residual(self, u, wall='right'):
-        """``Marginal/NS_Residuals_CP.py:468-478`` (edge differences; plain slicing)."""
-        def edges(u):
-            res = {'top': lambda: u[..., 0, :] - u[..., -1, :], 'bottom': lambda: u[..., -1, :] - u[..., 0, :],
-                   'left': lambda: u[..., :, 0] - u[..., :, -1], 'right': lambda: u[..., :, -1] - u[..., :, 0]}[wall]()
-            return res * self.dx
-        return _on_device((u,), edges)
+        """``Marginal/NS_Residuals_CP.py:468-478``: (one edge of every [Nx,Ny] plane minus the opposite one) * dx ->
+        ``u.shape[:-2] + (Ny,)`` for 'top' / 'bottom', ``+ (Nx,)`` for 'left' / 'right'.  One ``pre_edge_residual_f32``
+        launch on the view where it lies (any strides); an unknown wall raises KeyError as the reference's dict lookup
+        would."""
+        code = self._WALLS[wall]
+        if u.dim() < 2 or u.dtype != torch.float32:
+            raise RuntimeError("periodic_bc_residual: float32 field with at least the two plane axes")
+        d, origin = _dispatch.to_device(u)
+        lead = tuple(d.shape[:-2])
+        v = d.reshape((1,) * (4 - d.dim()) + tuple(d.shape)) if d.dim() < 4 else (d if d.dim() == 4 else d.reshape(-1, *d.shape[-3:]))
+        B, T, X, Y = v.shape
+        out = torch.empty(lead + ((Y,) if code < 2 else (X,)), dtype=torch.float32, device=d.device)
+        with torch.cuda.device(d.device):
+            f = _lib.field(v)
+            _lib.check(_lib.load().pre_edge_residual_f32(ctypes.byref(f), code, float(self.dx), B, T, X, Y, _lib.ptr(out),
+                                                         _lib.stream()), "pre_edge_residual_f32")
+        return _dispatch.from_device(out, origin)
 
 
 class PRE_NS(NavierStokes):

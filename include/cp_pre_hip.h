@@ -65,7 +65,9 @@ typedef struct {
     int64_t sB, sT, sX, sY;
 } pre_out_t;
 
-int pre_abi_version(void);     /* 7 (v7: PRE_FLAG_HALO_X) */
+#define PRE_ABI_VERSION 8
+int pre_abi_version(void);     /* == PRE_ABI_VERSION (v8: pre_kth_axis0_planes_f32, pre_joint_score_pruned_max_segments);
+                                  a binding checks it at load time: signatures may change between versions */
 
 /* ---- a4/a5/a6: ConvOperator.convolution ---------------------------------------------
  * Utils/ConvOps_2d.py:135-150  F.conv3d(field[:,None], K[None,None], padding=k//2)
@@ -160,6 +162,14 @@ int pre_spatial2d_linear2_bc_f32(const float *in0, const int64_t s0[3], const fl
                                  float ratio, const pre_bc_t *bc /*host*/,
                                  int64_t B, int64_t X, int64_t Y, int flags, void *stream);
 
+/* ---- a9: periodic_bc_residual(u, wall) ---------------------------------------------------
+ * Marginal/NS_Residuals_CP.py:468-478: the mismatch between two opposite edges of every [X,Y] plane, times dx (ABI v8):
+ *   wall 0 'top':  u[...,0,:] - u[...,-1,:]     1 'bottom': u[...,-1,:] - u[...,0,:]      -> out [B,T,Y] contiguous
+ *   wall 2 'left': u[...,:,0] - u[...,:,-1]     3 'right':  u[...,:,-1] - u[...,:,0]      -> out [B,T,X] contiguous
+ * u: any strided [B,T,X,Y] view; fp32 (a - b) * dx, the reference's own two roundings. */
+int pre_edge_residual_f32(const pre_field_t *u, int wall, float dx, int64_t B, int64_t T, int64_t X, int64_t Y, float *out,
+                          void *stream);
+
 /* ---- a10: marginal nonconformity score ------------------------------------------------
  * out = |a - b| (b may be NULL: |a|).  Marginal/Wave_Residuals_CP.py:219,280 */
 int pre_absdiff_f32(const float *a, const float *b, float *out, int64_t n, void *stream);
@@ -220,6 +230,9 @@ int pre_segmin_mod_f32(const float *mod, int64_t T, int64_t X, int64_t Y, int cr
 int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float *mod, const uint32_t *segmax,
                                const float *segmin, int64_t n, int64_t T, int64_t X, int64_t Y, int crop_x, int crop_y,
                                float *scores, uint32_t *flags, unsigned long long *stats, void *stream);
+/* The longest work list (TC*NS) pre_joint_score_pruned_f32 accepts on the CURRENT device - (LDS bytes a workgroup may
+ * hold - 256) / 4; gfx950: 40896 - so that a driver can choose its route before it pays for the segment maxima (ABI v8). */
+int64_t pre_joint_score_pruned_max_segments(void);
 /* pre_joint_score_f32 over the samples i with flags[i] != 0 only (the others' workgroups leave at once): the pass a
  * driver launches behind pre_joint_score_pruned_f32 for the samples it flagged (ABI v6). */
 int pre_joint_score_flagged_f32(const float *a, const float *b, const float *mod,
@@ -244,6 +257,15 @@ int pre_kth_axis0_f32(const float *scores, int64_t n, int64_t M, const int32_t *
  * the MI355X (profiles/r03/row_pitch.txt); a driver that owns the buffer pads its rows by 64 floats. */
 int pre_kth_axis0_strided_f32(const float *scores, int64_t row_stride, int64_t n, int64_t M, const int32_t *ks /*host*/, int nk,
                               float *out, void *stream);
+/* ... for `planes` independent score matrices in ONE launch (ABI v8): plane p = [n, M] rows at scores + p*plane_stride
+ * (rows row_stride apart), its results at out + p*out_plane_stride + j*out_rank_stride + cell.  What a driver that keeps a
+ * TIME-MAJOR residual slab ([T][n][plane (+pad)], the zero-copy send layout of the sharded marginal calibration) calls
+ * once per slab, or once per received run of planes, instead of once per plane: the tiles of all planes share one grid,
+ * so the ragged last round of workgroups happens once, not `planes` times (Marginal/NS_Residuals_CP.py:310-327 is one
+ * np.quantile over the whole [n, Nt, Nx, Ny] array).  planes = 1: pre_kth_axis0_strided_f32. */
+int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_stride, int64_t row_stride, int64_t planes, int64_t n, int64_t M,
+                             const int32_t *ks /*host*/, int nk, float *out, int64_t out_rank_stride, int64_t out_plane_stride,
+                             void *stream);
 
 /* ---- a14: emp_cov / emp_cov_joint / filter_sims_joint -----------------------------------
  * (Joint/Burgers_Residuals_CP.py:298-300; Tests/test_advection_inv_sampling_marginal.py:465)

@@ -4,6 +4,7 @@ size-independent properties of the hot path, through the same classes bench.py d
   C3 slab  [4096,10,512,512] x3 fields   NS momentum residual (Marginal/NS_Residuals_CP.py:231-240), joint + marginal CP
   C4 shard [1024,64,256,256] x6 fields   MHD induction residual (Marginal/MHD_Residuals_CP.py:259-268), joint CP
   C5 shard [8192,200,512]                Burgers residual (Joint/Burgers_Residuals_CP.py:182-187), joint + marginal CP
+  C5 whole [65536,200,512]               the same at its N = 1 size (27 GB in, 27 GB residual): the anchor of the 1 -> 8 curve
 
 Properties: the last samples of the big batch equal the same samples evaluated on their own (64-bit indexing, grid
 decomposition); |.| epilogue == abs of the signed result; the interior-plane fast paths equal the full path; q-hat is
@@ -161,3 +162,43 @@ def test_full_size_c5_shard(gpu):
         assert int((a <= qm[j]).sum(0).min()) >= icp.kth_index(B, B, alphas[j]) + 1
     col = torch.sort(a[:, 100, 257].contiguous()).values
     assert torch.equal(qm[:, 100, 257], col[[icp.kth_index(B, B, al) for al in alphas]])
+
+
+@pytest.mark.timeout(600)
+def test_full_size_c5_whole(gpu):
+    """BASELINE config 5 at its single-GPU size [65536,200,512] (Joint/Burgers_Residuals_CP.py:182-187,272-285): 65 536
+    calibration samples resident at once - the select's 32-bit-counter instantiation (n >= 65536), sample offsets
+    beyond 2^32 bytes, the branch-and-bound score pass over one 200 x 512 plane per sample."""
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    from cp_pre_amd.residuals import Burgers
+    B, T, X = 65536, 200, 512
+    alphas = _alphas()
+    u = torch.empty(B, T, X, device=gpu)
+    u.uniform_(0.5, 1.5, generator=torch.Generator(device=gpu).manual_seed(14))
+    bur = Burgers(2.0 / X, 1.25 / T, 0.002)
+    res = bur.residual(u, boundary=True)
+    assert res.shape == (B, T, X) and torch.isfinite(res[::4096]).all()
+    for b0 in (0, 32767, B - 3):                                            # (byte offsets 0, 13.4e9, 26.8e9)
+        assert torch.equal(res[b0:b0 + 3], bur.residual(u[b0:b0 + 3].clone(), boundary=True))
+    assert torch.equal(bur.residual(u[-5:]), res[-5:, 1:-1, 1:-1])
+    a = bur.residual(u, boundary=True, absolute=True)
+    for b0 in range(0, B, 8192):
+        assert torch.equal(a[b0:b0 + 8192], res[b0:b0 + 8192].abs())
+    del u
+    q, mod, sc = _check_joint(icp, pipeline, res.unsqueeze(1), (0, 1, 1), B, gpu)
+    m = mod[0, 1:-1, 1:-1]
+    for j in (0, 9):
+        cov = icp.emp_cov_joint([-(q[j] * m), q[j] * m], res[:, 1:-1, 1:-1])
+        assert cov >= (icp.kth_index(B, B, alphas[j]) + 1) / B - 2.0 / B
+    del res
+    qm = pipeline.marginal_qhat(a, alphas)                                  # per-cell q-hat over all 65 536 samples
+    assert qm.shape == (len(alphas), T, X) and (qm[:-1] >= qm[1:]).all()
+    for j in (0, 9):
+        inside = torch.zeros(T, X, dtype=torch.int32, device=gpu)
+        for b0 in range(0, B, 8192):
+            inside += (a[b0:b0 + 8192] <= qm[j]).sum(0, dtype=torch.int32)
+        assert int(inside.min()) >= icp.kth_index(B, B, alphas[j]) + 1
+    for (t, x) in ((0, 0), (100, 257), (199, 511)):
+        col = torch.sort(a[:, t, x].contiguous()).values
+        assert torch.equal(qm[:, t, x], col[[icp.kth_index(B, B, al) for al in alphas]])

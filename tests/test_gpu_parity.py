@@ -395,6 +395,38 @@ def test_residuals_match_reference_golden(gpu, golden, fused):
             assert rel_err(got.cpu().numpy(), ref) <= RES_TOL, (name, b, fused)
 
 
+def test_periodic_bc_residual_matches_reference_golden(gpu, golden):
+    """``NavierStokes.periodic_bc_residual`` (Marginal/NS_Residuals_CP.py:468-478) - one ``pre_edge_residual_f32`` launch
+    - against the outputs of the reference's own def on the same field (``residuals.npz`` ``ns_periodic_bc|*``, made by
+    executing it): all four walls, a device tensor and a CPU tensor (which comes home to the CPU), a strided
+    ``vars[:, i]`` view, the surrogate's Nt-fastest layout and a bare [Nx,Ny] plane.  (a - b) * dx in fp32 both sides:
+    bit for bit."""
+    from cp_pre_amd.residuals import NavierStokes
+    g = golden["residuals"]
+    dt, dx, dy = g["coef"].tolist()
+    v6 = torch.from_numpy(g["vars6"])
+    u_cpu = v6[:, 0]
+    walls = ("top", "bottom", "left", "right")
+    ns = NavierStokes(dt, dx, dy)
+    for wall in walls:
+        ref = g[f"ns_periodic_bc|{wall}"]
+        dev = ns.periodic_bc_residual(v6.to(gpu)[:, 0], wall=wall)          # strided vars[:, 0] view of [BS,6,Nt,Nx,Ny]
+        assert dev.is_cuda and tuple(dev.shape) == ref.shape
+        assert np.array_equal(dev.cpu().numpy(), ref), wall
+        home = ns.periodic_bc_residual(u_cpu, wall=wall)                    # CPU tensor in -> CPU tensor out
+        assert not home.is_cuda and np.array_equal(home.numpy(), ref), wall
+        nt_fast = u_cpu.permute(0, 2, 3, 1).contiguous().to(gpu).permute(0, 3, 1, 2)      # memory [BS,Nx,Ny,Nt]
+        assert not nt_fast.is_contiguous()
+        assert np.array_equal(ns.periodic_bc_residual(nt_fast, wall=wall).cpu().numpy(), ref), wall
+        plane = ns.periodic_bc_residual(u_cpu[1, 2].to(gpu), wall=wall)     # [Nx,Ny] -> [Ny] / [Nx]
+        assert np.array_equal(plane.cpu().numpy(), ref[1, 2]), wall
+        six = ns.periodic_bc_residual(v6.to(gpu), wall=wall)                # [BS,6,Nt,Nx,Ny]: every field at once
+        assert np.array_equal(six[:, 0].cpu().numpy(), ref), wall
+    assert ns.periodic_bc_residual(torch.empty(0, 4, 6, 8, device=gpu), wall="left").shape == (0, 4, 6)
+    with pytest.raises(KeyError):
+        ns.periodic_bc_residual(u_cpu.to(gpu), wall="front")
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_jorek_residuals_match_reference_golden(gpu, golden, fused, monkeypatch):
     """Reduced-MHD residuals (Marginal/JOREK_residuals_CP.py:207-243): fused single pass and operator-by-operator
@@ -1848,6 +1880,27 @@ def _sharded_worker(rank, world, port, n_local, shape, out_dir):
         tmp.copy_(mine.abs())
         for ov in (False, True):
             assert torch.equal(pipeline.marginal_qhat(tmp, alphas, group=dist.group.WORLD, overlap=ov), qm), ov
+        # bounded receive staging: runs of 2 planes per rank, one select launch per run (pre_kth_axis0_planes_f32)
+        two = 2 * 4 * n_local * world * (tmp.stride(0))
+        for ov in (False, True):
+            assert torch.equal(pipeline.marginal_qhat(tmp, alphas, group=dist.group.WORLD, overlap=ov, stage_bytes=two), qm), ov
+        # the surrogate's Nt-fastest layout (memory [n,X,Y,T]) over three slabs, rank 1's samples "wild" (a modulation
+        # nothing like the residual's scale: every sample flagged, read whole), rank 0's prunable: the ranks' own read
+        # fractions straddle PRUNE_GIVE_UP, the GROUP's decides for both, and the moments all-reduce has the same length
+        # on both routes (round-3 advice: rank-local decisions made it M on one rank, M - 2 planes on the other)
+        pw = torch.from_numpy(np.load(os.path.join(out_dir, "res_perm.npy")))[rank * n_local:(rank + 1) * n_local].to(dev)
+        jp = pipeline.JointCalibration(n_local, dev, group=dist.group.WORLD)
+        routes = []
+        for s in range(3):
+            slab = pw[:, 4 * s:4 * s + 6].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            assert not slab.is_contiguous() and pipeline.HipOps.interior_planes(slab, (1, 1, 1)) == 1
+            jp.add_slab(slab, crop=(1, 1, 1))
+            routes.append(bool(jp.prune))
+        qp = jp.finish(alphas)
+        mine_frac = jp.score_pass_read_frac()
+        np.save(os.path.join(out_dir, f"qp_{rank}.npy"), qp.cpu().numpy())
+        np.save(os.path.join(out_dir, f"sp_{rank}.npy"), jp.all_scores.cpu().numpy())
+        np.save(os.path.join(out_dir, f"routes_{rank}.npy"), np.array(routes + [mine_frac], dtype=np.float64))
         np.save(os.path.join(out_dir, f"q_{rank}.npy"), q.cpu().numpy())
         np.save(os.path.join(out_dir, f"qm_{rank}.npy"), qm.cpu().numpy())
     finally:
@@ -1884,6 +1937,59 @@ def test_marginal_qhat_rows_with_a_pitch(gpu, n):
         ns.residual_momentum(v, boundary=True, absolute=True, out=pad, skip_t_rim=True)
         assert torch.equal(pad, ref)
         assert torch.equal(pipeline.marginal_qhat(pad, [0.1, 0.5]), pipeline.marginal_qhat(ref, [0.1, 0.5]))
+
+
+@pytest.mark.parametrize("n", [40, 100, 200, 300, 500, 700, 1000, 1500, 2049, 5000, 66000])
+def test_multi_plane_select_one_launch(gpu, n):
+    """pre_kth_axis0_planes_f32: the per-cell select of several [n, M] score matrices in ONE launch (every regime of n)
+    equals one pre_kth_axis0_strided_f32 launch per plane, bit for bit - planes with a pitch between their rows and a
+    gap between the planes, a ragged last tile per plane (M % 64 != 0: a plane's last tile must not read its
+    neighbour's cells), NaN / tie / constant columns, results written with arbitrary rank and plane strides."""
+    from cp_pre_amd import _lib
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    lib = _lib.load()
+    g = torch.Generator(device=gpu).manual_seed(1000 + n)
+    for planes, M, pad, gap in ((5, 200, 8, 24), (3, 64, 0, 0), (7, 1, 3, 1)) if n < 60000 else ((3, 130, 6, 10),):
+        pitch = M + pad
+        ps = n * pitch + gap
+        buf = torch.randn(planes * ps, device=gpu, generator=g).abs_()
+        view = buf.as_strided((planes, n, M), (ps, pitch, 1))
+        view[:, : n // 2, 0] = 1.25                                          # ties
+        if M > 5:
+            view[1, n // 3, 5] = float("nan")
+            view[:, :, 3] = 0.5                                              # a constant column
+        if M > 70:
+            view[planes - 1, :, 65] *= 1e-30                                 # tiny values in the last plane only
+        ks = sorted({0, n // 2, n - 1} | {icp.kth_index(n, n, float(a)) for a in icp.ALPHA_LEVELS
+                                          if icp.quantile_level(n, float(a)) <= 1})[:10]
+        nk = len(ks)
+        want = torch.stack([icp.kth_axis0(view[p], ks) for p in range(planes)], dim=1)       # [nk, planes, M]
+        # (a) results as [nk, planes, M]; (b) as [planes, nk, M + 7] with a gap: q_own's layout in the sharded exchange
+        out_a = torch.full((nk, planes, M), -7.0, device=gpu)
+        out_b = torch.full((planes, nk, M + 7), -7.0, device=gpu)
+        kk = _lib.iarr32(ks)
+        with torch.cuda.device(gpu):
+            _lib.check(lib.pre_kth_axis0_planes_f32(_lib.ptr(buf), ps, pitch, planes, n, M, kk, nk, _lib.ptr(out_a), planes * M, M,
+                                                    _lib.stream()), "planes a")
+            _lib.check(lib.pre_kth_axis0_planes_f32(_lib.ptr(buf), ps, pitch, planes, n, M, kk, nk, _lib.ptr(out_b), M + 7,
+                                                    nk * (M + 7), _lib.stream()), "planes b")
+        f = lambda t: torch.nan_to_num(t, nan=-1.0)
+        assert torch.equal(f(out_a), f(want)), (n, planes, M)
+        assert torch.equal(f(out_b[:, :, :M]), f(want.transpose(0, 1))), (n, planes, M)
+        assert (out_b[:, :, M:] == -7.0).all()                               # nothing written beyond a plane's cells
+    # argument checks: planes that overlap their neighbours, rows shorter than M
+    one = torch.zeros(4 * 8, device=gpu)
+    out = torch.zeros(2 * 8, device=gpu)
+    k0 = _lib.iarr32([0])
+    assert lib.pre_kth_axis0_planes_f32(_lib.ptr(one), 4, 8, 2, 2, 8, k0, 1, _lib.ptr(out), 8, 8, None) == _lib.PRE_E_RANGE
+    assert lib.pre_kth_axis0_planes_f32(_lib.ptr(one), 16, 4, 2, 2, 8, k0, 1, _lib.ptr(out), 8, 8, None) == _lib.PRE_E_RANGE
+    assert lib.pre_kth_axis0_planes_f32(_lib.ptr(one), 16, 8, 0, 2, 8, k0, 1, _lib.ptr(out), 8, 8, None) == _lib.PRE_E_NULL
+    if n == 300:       # the time-major tensor of a slab driver: all planes in one launch == the contiguous copy's q-hat
+        tm = pipeline.time_major(n, (6, 10, 33), pad=64, device=gpu)
+        tm.copy_(torch.randn(n, 6, 10, 33, device=gpu, generator=g).abs_())
+        alphas = [0.1, 0.5, 0.9]
+        assert torch.equal(pipeline.marginal_qhat(tm, alphas), pipeline.marginal_qhat(tm.contiguous(), alphas))
 
 
 def test_time_major_residual_buffer_and_planewise_qhat(gpu):
@@ -1924,10 +2030,29 @@ def test_sharded_calibration_two_ranks_on_one_gpu(gpu, tmp_path):
     rng = np.random.default_rng(5)
     res = (rng.standard_normal((world * n_local,) + shape) * (1 + rng.random(shape))).astype(np.float32)
     np.save(tmp_path / "res.npy", res)
+    # permuted-layout stream [n, T=14, X=12, Y=64]: rank 0's half smooth in scale, rank 1's half with a per-cell scale
+    # that jumps by 1e4 between neighbouring cells (the group's modulation is then far above most of rank 0's cells and
+    # the bounds of every sample are useless on rank 1's: flagged, read whole)
+    shp = (14, 12, 64)
+    rp = rng.standard_normal((world * n_local,) + shp).astype(np.float32)
+    rp[n_local:] *= np.where(rng.random(shp) < 0.5, 1.0, 1e4).astype(np.float32)
+    np.save(tmp_path / "res_perm.npy", rp)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_sharded_worker, args=(world, port, n_local, shape, str(tmp_path)), nprocs=world, join=True)
+    # the permuted stream: same route on both ranks at every slab, same q-hat as one process on the whole batch
+    wp = torch.from_numpy(rp).to(gpu)
+    jw = pipeline.JointCalibration(world * n_local, gpu, prune=False)
+    for s in range(3):
+        jw.add_slab(wp[:, 4 * s:4 * s + 6].contiguous(), crop=(1, 1, 1))
+    qp_ref = jw.finish([0.1, 0.3, 0.5, 0.7, 0.9]).cpu().numpy()
+    r0, r1 = np.load(tmp_path / "routes_0.npy"), np.load(tmp_path / "routes_1.npy")
+    assert np.array_equal(r0[:3], r1[:3]), (r0, r1)                            # the group's decision, not each rank's
+    for r in range(world):
+        qp = np.load(tmp_path / f"qp_{r}.npy")
+        assert np.max(np.abs(qp - qp_ref) / np.abs(qp_ref)) <= 1e-6, (qp, qp_ref)
+        assert np.allclose(np.load(tmp_path / f"sp_{r}.npy"), jw.all_scores.cpu().numpy(), rtol=1e-5, atol=0.0)
     alphas = [0.1, 0.3, 0.5, 0.7, 0.9]
     whole = torch.from_numpy(res).to(gpu)
     jc = pipeline.JointCalibration(world * n_local, gpu, prune=False)
