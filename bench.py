@@ -31,6 +31,11 @@ process is one rank; launched bare with N > 1 it SPAWNS the N ranks itself (a fr
 the child's code; WORLD_SIZE != N is an error (exit 2).  --scaling weak (default): --batch samples per
 rank; strong: the --batch samples are split over the ranks.
 
+The default line (--config c3, joint, one GPU) also carries `secondary`: the other BASELINE configurations measured in
+the same process after the C3 joint job (whose number stays `value`) - C3 marginal on the same resident slab, C2, the C4
+and C5 per-GPU shards and C5 at its single-GPU size [65536,200,512] - 2 warm-up + 5 steps each, so that every config's
+number is one the driver's own run produced (--no-secondary skips them).
+
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (fused
 residual kernel, HIP events on its stream; `achieved` = SURVEY 8(d) bytes: 16 B x the interior
 cells one launch computes, halo planes NOT counted) and `cpu_baseline` (the CPU oracle = the
@@ -89,6 +94,8 @@ def parse():
     ap.add_argument("--plumbing-check", action="store_true",
                     help="initialise the process group, run one all-reduce, print the rank count and exit (no compute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default c3 joint line only: do not measure the other BASELINE configs after it")
     ap.add_argument("--no-prune", action="store_true",
                     help="joint mode: read the whole residual in the score pass instead of the branch-and-bound form")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
@@ -156,7 +163,8 @@ SYNTH = "synthetic smooth-plus-noise fields (sin*cos*cos mode + 0.01 N(0,1); U(0
 
 
 def run_secondary(args, cfg, dev, group, rank, world, par):
-    """c1/c2/c4/c5: whole per-rank tensor resident; one step = fused residual + calibration."""
+    """c1/c2/c4/c5: whole per-rank tensor resident; one step = fused residual + calibration.  Returns the JSON line
+    (rank 0; None elsewhere)."""
     from cp_pre_amd import inductive_cp as icp
     from cp_pre_amd import pipeline
     from cp_pre_amd import residuals as R
@@ -188,19 +196,24 @@ def run_secondary(args, cfg, dev, group, rank, world, par):
         crop, cells = (1, 1, 1), B * T * X * Y
     ev = []
     pruned = [False]
+    last_jc = [None]
 
     def step():
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
         res = evaluate()
         e1.record()
-        ev.append((e0, e1))
+        ev.append((e0, e1, e2))
         if args.mode == "joint":
             jc = pipeline.JointCalibration(B, dev, group=group, prune=not args.no_prune)
+            last_jc[0] = jc
             pruned[0] = jc.prune and pipeline.HipOps.can_prune(res, crop)
             jc.add_slab(res, crop=crop)
-            return jc.finish(alphas)
-        return pipeline.marginal_qhat(res, alphas, group=group)
+            q = jc.finish(alphas)
+        else:
+            q = pipeline.marginal_qhat(res, alphas, group=group)
+        e2.record()
+        return q
 
     def sync():
         torch.cuda.synchronize()
@@ -222,12 +235,18 @@ def run_secondary(args, cfg, dev, group, rank, world, par):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank == 0:
-        kms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        kms = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
+        cms = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev)            # calibration: everything after the residual kernel
         pmc = pmc_traffic(args)
         launch_bytes = cfg["bpc"] * cells
         achieved = launch_bytes / (kms * 1e-3) / 1e9
         shape = [B, T, X] + ([Y] if Y else [])
-        print(json.dumps({
+        calib = {"calibrate_ms": cms}
+        if args.mode == "marginal":         # the per-cell select reads the scores once, algorithmically (4 B per cell and pass)
+            calib["select_one_read_gbs"] = 4.0 * cells / (cms * 1e-3) / 1e9
+        elif last_jc[0] is not None and pruned[0]:
+            calib["score_pass_read_frac"] = last_jc[0].score_pass_read_frac()
+        return {
             "metric": "residual-cells/s (PRE eval+calibrate)", "value": cells * world * args.steps / elapsed,
             "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
@@ -238,7 +257,39 @@ def run_secondary(args, cfg, dev, group, rank, world, par):
             "roofline": {"bound": "hbm", "kernel": cfg["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                          "traffic_source": pmc["source"] if pmc else None, "avg_launch_ms": kms,
-                         "algorithmic_bytes_per_launch": launch_bytes}}), flush=True)
+                         "algorithmic_bytes_per_launch": launch_bytes},
+            **calib}
+    return None
+
+
+def secondary_entry(line):
+    """The compact form of a config's line inside the default line's `secondary` object."""
+    r = line["roofline"]
+    e = {"workload": line["config"]["workload"], "ms_per_step": line["ms_per_step"], "cells_per_s": line["value"],
+         "steps": line["steps"], "warmup": line["warmup"], "kernel": r["kernel"], "kernel_ms": r["avg_launch_ms"],
+         "achieved_gbs": r["achieved"], "frac": r["frac"], "traffic": r["traffic"]}
+    for k in ("calibrate_ms", "select_one_read_gbs", "score_pass_read_frac", "score_pass"):
+        if k in line:
+            e[k] = line[k]
+        elif k in line["config"]:
+            e[k] = line["config"][k]
+    return e
+
+
+def measure_others(dev):
+    """C2, the C4 / C5 per-GPU shards and C5 whole, one after the other (each frees its tensors on return)."""
+    found = {}
+    for key, name, batch in (("c2", "c2", None), ("c4_shard", "c4", None), ("c5_shard", "c5", None), ("c5_whole", "c5", 65536)):
+        cfg = CONFIGS[name]
+        shp = cfg["shape"]
+        a = argparse.Namespace(config=name, mode=cfg["mode"], batch=batch or shp[0], nt=shp[1], nx=shp[2],
+                               ny=shp[3] if len(shp) == 4 else 0, steps=5, warmup=2, no_prune=False, scaling="weak", slab=0,
+                               slab_axis="x")
+        title = cfg["title"] if batch is None else "C5 1D Burgers residual (Joint/Burgers_Residuals_CP.py) at its single-GPU size"
+        line = run_secondary(a, dict(cfg, title=title), dev, None, 0, 1, {})
+        found[key] = secondary_entry(line)
+        torch.cuda.empty_cache()
+    return found
 
 
 def pmc_traffic(args):
@@ -260,7 +311,21 @@ def pmc_traffic(args):
         w = d.get("workload", {})
         if all(w.get(k, "t" if k == "slab_axis" else None) == v for k, v in want.items()):
             best = d
+    # counters of ANOTHER kernel are not this run's traffic: the file records the hash of the kernel's source it was
+    # collected on (and the commit), and is ignored when the source has changed since
+    if best is not None and best.get("kernel_src_sha16") != kernel_src_sha16():
+        return None
     return best
+
+
+def kernel_src_sha16():
+    """sha256 (first 16 hex digits) of the source of the fused residual kernels (every config's dominant kernel is a
+    march_kernel of csrc/star_march.hip) - what ties a committed PMC summary to the code it was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("star_march.hip", "common.h"):
+        h.update(open(os.path.join(ROOT, "cp_pre_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def host_cores():
@@ -384,7 +449,9 @@ def main():
         return done()
 
     if args.config != "c3":
-        run_secondary(args, CONFIGS[args.config], dev, group, rank, world, par)
+        line = run_secondary(args, CONFIGS[args.config], dev, group, rank, world, par)
+        if line is not None:
+            print(json.dumps(line), flush=True)
         return done()
 
     from cp_pre_amd import inductive_cp as icp
@@ -454,48 +521,52 @@ def main():
         return (B, T, sl, Y) if xs else (B, sl, X, Y)
     plane = lambda sl: (sl * Y) if xs else (X * Y)           # cells of one time plane of the residual
     res_buf = torch.empty(B * (other * S + 64 * (T if xs else S)), dtype=torch.float32, device=dev)      # (room for either padded layout)
-    if args.mode == "marginal" and group is not None:
-        # time-major [planes][B][plane] seen as [B,planes,..]: plane t of all local samples is one contiguous block, the
-        # send block of the all-to-all that hands plane t to rank t % world (pipeline.marginal_qhat: no pack copy)
-        # (samples of a plane 64 floats further apart than a plane is long: profiles/r03/row_pitch.txt)
-        res_of = {sl: res_buf.as_strided(rshape(sl), (plane(sl) + 64, B * (plane(sl) + 64), Y, 1)) for sl in set(slabs)}
-    elif args.mode == "marginal":
-        # rows 64 floats further apart than they are long: a power-of-two distance between the rows of a cell's column
-        # (2^22 cells) costs the per-cell select ~10 % (pipeline.row_padded, profiles/r03/row_pitch.txt)
-        res_of = {sl: res_buf.as_strided(rshape(sl), (rshape(sl)[1] * plane(sl) + 64, plane(sl), Y, 1)) for sl in set(slabs)}
-    else:
-        res_of = {sl: res_buf[:B * rshape(sl)[1] * plane(sl)].view(rshape(sl)) for sl in set(slabs)}
+
+    def views(mode):
+        """The residual buffer as each slab thickness sees it."""
+        if mode == "marginal" and group is not None:
+            # time-major [planes][B][plane] seen as [B,planes,..]: plane t of all local samples is one contiguous block, the
+            # send block of the all-to-all that hands plane t to rank t % world (pipeline.marginal_qhat: no pack copy)
+            # (samples of a plane 64 floats further apart than a plane is long: profiles/r03/row_pitch.txt)
+            return {sl: res_buf.as_strided(rshape(sl), (plane(sl) + 64, B * (plane(sl) + 64), Y, 1)) for sl in set(slabs)}
+        if mode == "marginal":
+            # rows 64 floats further apart than they are long: a power-of-two distance between the rows of a cell's column
+            # (2^22 cells) costs the per-cell select ~10 % (pipeline.row_padded, profiles/r03/row_pitch.txt)
+            return {sl: res_buf.as_strided(rshape(sl), (rshape(sl)[1] * plane(sl) + 64, plane(sl), Y, 1)) for sl in set(slabs)}
+        return {sl: res_buf[:B * rshape(sl)[1] * plane(sl)].view(rshape(sl)) for sl in set(slabs)}
+    res_of = views(args.mode)
     # cells within `crop` of the slab's rim are excluded from the scores: the y rim always; x-slabs: the t rim (the
     # grid's own: every plane is computed, zero padding beyond, as the reference's conv3d has it), no rows (all own);
     # t-slabs: the x rim, no planes (all interior)
+    # (x-slabs score all their rows: the grid's rows 0 and X-1, which the reference's [...,1:-1,...] drops, stay in - a
+    # 2/X superset that costs the same; tests/test_gpu_parity.py::test_x_slab_stream_equals_whole_grid_calibration
+    # streams the cropped form)
     crop = (1, 0, 1) if xs else (0, 1, 1)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(n_slabs * (args.steps + args.warmup + 2))]          # (+2: the full-score-pass steps after the timed loop)
     ev_used = []
-
     last_jc = [None]
 
-    def step(k, prune=not args.no_prune):
-        jc = pipeline.JointCalibration(B, dev, group=group, prune=prune) if args.mode == "joint" else None
+    def step(k, prune=not args.no_prune, mode=args.mode, res_of=res_of):
+        jc = pipeline.JointCalibration(B, dev, group=group, prune=prune) if mode == "joint" else None
         last_jc[0] = jc
         q = None
         for s, sl in enumerate(slabs):
             res = res_of[sl]
-            e0, e1 = ev[k * n_slabs + s]
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record()
             if xs:
-                ns.residual_momentum(vars_[s:s + B, :, :, 1:sl + 1], boundary=True, absolute=(args.mode == "marginal"), out=res,
+                ns.residual_momentum(vars_[s:s + B, :, :, 1:sl + 1], boundary=True, absolute=(mode == "marginal"), out=res,
                                      halo_x=True)
             else:
-                ns.residual_momentum(vars_[s:s + B, :, :sl + 2], boundary=True, absolute=(args.mode == "marginal"), out=res,
+                ns.residual_momentum(vars_[s:s + B, :, :sl + 2], boundary=True, absolute=(mode == "marginal"), out=res,
                                      skip_t_rim=True)
             e1.record()
-            ev_used.append((k, sl, e0, e1))
             if jc is not None:
                 jc.add_slab(res, crop=crop)
             else:
                 q = pipeline.marginal_qhat(res, alphas, group=group)     # [10, *slab cells]
+            e2.record()
+            ev_used.append((k, sl, e0, e1, e2))
         return jc.finish(alphas) if jc is not None else q
 
     def sync():
@@ -538,7 +609,7 @@ def main():
             ms_full = float(tt.item())
 
     if rank == 0:
-        timed = [(sl, e0.elapsed_time(e1)) for (k, sl, e0, e1) in ev_used if args.warmup <= k < args.warmup + args.steps]     # ms, this rank
+        timed = [(sl, e0.elapsed_time(e1)) for (k, sl, e0, e1, _) in ev_used if args.warmup <= k < args.warmup + args.steps]     # ms, this rank
         kms = sum(d for _, d in timed) / len(timed)
         # 3 fields read + 1 residual written = 16 B per cell the launch COMPUTES (its interior
         # planes); the two halo planes each slab re-reads are overhead, reported apart
@@ -554,7 +625,7 @@ def main():
             "data": SYNTH + f"; one resident {'x' if xs else 't'}-slab, slab position s reads the batch window [s, s+B) of it",
             "config": {"workload": f"C3 2D Navier-Stokes momentum residual [{B},{args.nt},{X},{Y}] x3 fields per rank, "
                                    f"{args.mode} CP, 10 alpha levels; streamed as " +
-                                   (f"{n_slabs} x-slabs of {slabs} rows (+2 halo rows each), T whole" if xs else
+                                   (f"{n_slabs} x-slabs of {slabs} rows (+2 halo rows each; all {X} rows scored), T whole" if xs else
                                     f"{n_slabs} t-slabs of {slabs} interior planes (+2 halo planes each)"),
                        "mode": args.mode, "batch_per_rank": B, "slab_axis": args.slab_axis, "slab": args.slab, **par,
                        # the per-rank slab plan: resident bytes, and what the t-slab halo re-reads cost (strong scaling
@@ -562,7 +633,7 @@ def main():
                        "slab_plan": {"axis": args.slab_axis, "slabs": slabs,
                                      "resident_gb": round(resident_bytes(B, n_axis, args.slab, other) / 1e9, 1),
                                      "input_read_per_cell_computed": round(sum(sl + 2 for sl in slabs) / sum(slabs), 4)},
-                       "scaling_note": ("weak: every rank streams its own 4096-sample batch" if args.scaling == "weak" else
+                       "scaling_note": (f"weak: every rank streams its own {B}-sample batch" if args.scaling == "weak" else
                                         "strong: one calibration set split over the ranks (north_star's '>= 6x 1->8 GPUs' "
                                         "speaks of this curve)"),
                        # `value` is measured with the fields resident in HBM (contract); if the 3 fields came from host
@@ -584,6 +655,38 @@ def main():
                          "launches_timed": len(timed)},
             "qhat_first_last": [float(qhat.reshape(len(alphas), -1)[0, 0]), float(qhat.reshape(len(alphas), -1)[-1, 0])],
         }
+        if args.mode == "marginal":
+            sel = [e1.elapsed_time(e2) for (k, sl, _, e1, e2) in ev_used if args.warmup <= k < args.warmup + args.steps]
+            out["select_ms_per_slab"] = sum(sel) / len(sel)
+            out["select_one_read_gbs"] = 4.0 * B * S * other / (out["select_ms_per_slab"] * 1e-3) / 1e9
+        if world == 1 and args.mode == "joint" and group is None and not args.no_secondary and not args.no_prune:
+            # every other BASELINE config under the same clock: C3 marginal on the slab that is already resident, then
+            # (C3's buffers freed) C2, the C4 / C5 shards and C5 whole.  Not part of `value`.
+            sec = {}
+            mres, k0, n2 = views("marginal"), args.warmup + args.steps + 2, 2 + 5
+            for k in range(k0, k0 + 2):
+                step(k, mode="marginal", res_of=mres)
+            sync()
+            t2 = time.perf_counter()
+            for k in range(k0 + 2, k0 + n2):
+                step(k, mode="marginal", res_of=mres)
+            sync()
+            ms = 1e3 * (time.perf_counter() - t2) / 5
+            mt = [(sl, e0.elapsed_time(e1), e1.elapsed_time(e2)) for (k, sl, e0, e1, e2) in ev_used if k >= k0 + 2]
+            kms_m = sum(d for _, d, _ in mt) / len(mt)
+            sel_m = sum(d for _, _, d in mt) / len(mt)
+            ach = sum(16 * B * sl * other for sl, _, _ in mt) / len(mt) / (kms_m * 1e-3) / 1e9
+            sec["c3_marginal"] = {
+                "workload": out["config"]["workload"].replace("joint CP", "marginal CP (per-cell q-hat over the 4096 samples)"),
+                "ms_per_step": ms, "cells_per_s": cells_per_step / (ms * 1e-3), "steps": 5, "warmup": 2,
+                "kernel": "march_kernel<NSMomentum<0>,8,64>", "kernel_ms": kms_m, "achieved_gbs": ach, "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "select_ms_per_slab": sel_m,
+                "select_one_read_gbs": 4.0 * B * S * other / (sel_m * 1e-3) / 1e9}
+            del vars_, res_buf, res_of, mres
+            torch.cuda.empty_cache()
+            sec.update(measure_others(dev))
+            out["secondary"] = sec
+            vars_ = res_buf = res_of = None
         if world == 1 and not args.no_cpu_baseline:
             del vars_, res_buf, res_of
             torch.cuda.empty_cache()

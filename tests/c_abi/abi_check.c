@@ -2,7 +2,9 @@
  * Shows what a maintainer binding the library from another language sees, and checks each call
  * against plain C loops written here (the reference's arithmetic: zero-padded cross-correlation,
  * Utils/ConvOps_2d.py:149; the NS momentum expression, Marginal/NS_Residuals_CP.py:231-240; an order
- * statistic per cell; the streaming joint chain; MHD induction, JOREK continuity, Burgers and the 1-D stencil).
+ * statistic per cell; the streaming joint chain; MHD induction, JOREK continuity, Burgers and the 1-D stencil; the
+ * two-operator linear residual, the kernel gradient, the boundary-condition operators, the resident std, the coverage
+ * counts, the multi-plane select and the periodic-wall residual): every symbol of cp_pre_hip.h is called.
  * Built and run by tests/test_gpu_parity.py::test_c_abi_client.  Exit code 0 = all ok.
  *
  *   hipcc -x c tests/c_abi/abi_check.c -Iinclude -Lcp_pre_amd -lcp_pre_hip -Wl,-rpath,$PWD/cp_pre_amd -o abi_check
@@ -48,7 +50,7 @@ static int cmp_float(const void *a, const void *b) { const float x = *(const flo
 int main(void)
 {
     int failures = 0;
-    EXPECT(pre_abi_version() == 7, "pre_abi_version() == 7");
+    EXPECT(pre_abi_version() == PRE_ABI_VERSION && PRE_ABI_VERSION == 8, "pre_abi_version() == PRE_ABI_VERSION == 8");
 
     /* ---- the reference's kernels: kernel_3d(stencil, axis) with the stencil on slab 1 (Utils/ConvOps_2d.py:67-79) */
     float Kt[27] = {0}, Kx[27] = {0}, Ky[27] = {0}, Kl[27] = {0};
@@ -318,6 +320,185 @@ int main(void)
             want[((size_t)b * X + t) * Y + x] = dx * Dt + dt * c * Dx - nu * Dxx * c3;
         }
         EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-5, "pre_residual_burgers_f32 vs C loops (<= 1e-5)");
+    }
+
+    /* ---- a9: res = D_x(u) + ratio * D_y(v) (Marginal/NS_Residuals_CP.py:222-228) */
+    {
+        const float ratio = 0.75f;
+        int rc = pre_residual_linear2_f32(&fu, &fv, &fo, Kx, Ky, ratio, B, T, X, Y, 0, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        xcorr27(hu, Kx, tmp[0]); xcorr27(hv, Ky, tmp[1]);
+        for (int i = 0; i < N; ++i) want[i] = tmp[0][i] + ratio * tmp[1][i];
+        EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-5, "pre_residual_linear2_f32 vs C loops (<= 1e-5)");
+    }
+
+    /* ---- 8f rank 3: gradient of the stencil with respect to its dense 3x3x3 kernel (Physics_Informed/Wave_FNO_PI.py:202-228) */
+    {
+        double *dgk, hgk[27], wgk[27] = {0};
+        CHECK_HIP(hipMalloc((void **)&dgk, sizeof hgk));
+        CHECK_HIP(hipMemsetAsync(dgk, 0, sizeof hgk, st));
+        int rc = pre_stencil3d_wgrad_f32(&fu, &fv, 3, 3, 3, B, T, X, Y, dgk, st);       /* x = u, upstream gradient g = v */
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(hgk, dgk, sizeof hgk, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) for (int t = 0; t < T; ++t) for (int x = 0; x < X; ++x) for (int y = 0; y < Y; ++y)
+            for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) for (int d = 0; d < 3; ++d) {
+                const int tt = t + a - 1, xx = x + c - 1, yy = y + d - 1;
+                if (tt >= 0 && tt < T && xx >= 0 && xx < X && yy >= 0 && yy < Y)
+                    wgk[(a * 3 + c) * 3 + d] += (double)hv[((b * T + t) * X + x) * Y + y] * hu[((b * T + tt) * X + xx) * Y + yy];
+            }
+        double worst = 0;
+        for (int i = 0; i < 27; ++i) { const double e = fabs(hgk[i] - wgk[i]) / fabs(wgk[i]); if (e > worst) worst = e; }
+        EXPECT(rc == PRE_OK && worst <= 1e-9, "pre_stencil3d_wgrad_f32: 27 kernel gradients vs C loops (fp64 sums, <= 1e-9)");
+        EXPECT(pre_stencil3d_wgrad_f32(&fu, &fv, 5, 3, 3, B, T, X, Y, dgk, st) == PRE_E_UNSUPPORTED, "kernel extent 5 -> PRE_E_UNSUPPORTED");
+        hipFree(dgk);
+    }
+
+    /* ---- 8f rank 4: spatial operators on [BS, X, Y] planes with boundary conditions (Utils/ConvOps_Spatial.py:83-136 on a
+     * field padded by Utils/boundary_conditions.py:81-185): a 'same'-sized cross-correlation whose out-of-domain
+     * neighbours are wrapped (periodic), clamped (neumann), mirrored (symmetric) or a constant (dirichlet) */
+    {
+        enum { BS = B * T };
+        const int64_t st3[3] = {(int64_t)X * Y, Y, 1};
+        const float Kgx[9] = {0, -0.5f, 0, 0, 0, 0, 0, 0.5f, 0}, Kgy[9] = {0, 0, 0, -0.5f, 0, 0.5f, 0, 0, 0};   /* axes (Nx, Ny) */
+        const pre_bc_t bc = {{PRE_BC_PERIODIC, PRE_BC_PERIODIC, PRE_BC_REPLICATE, PRE_BC_CONSTANT}, {0.f, 0.f, 0.f, 0.25f}};
+        const pre_bc_t bc2 = {{PRE_BC_REFLECT, PRE_BC_CONSTANT, PRE_BC_PERIODIC, PRE_BC_PERIODIC}, {0.f, -1.5f, 0.f, 0.f}};
+#define AT(f, b, x, y, BC) ((y) < 0 ? ((BC).mode[0] == PRE_BC_CONSTANT ? (BC).value[0] : (f)[((b) * X + (x)) * Y + ((BC).mode[0] == PRE_BC_PERIODIC ? Y - 1 : (BC).mode[0] == PRE_BC_REFLECT ? 1 : 0)]) \
+                         : (y) >= Y ? ((BC).mode[1] == PRE_BC_CONSTANT ? (BC).value[1] : (f)[((b) * X + (x)) * Y + ((BC).mode[1] == PRE_BC_PERIODIC ? 0 : (BC).mode[1] == PRE_BC_REFLECT ? Y - 2 : Y - 1)]) \
+                         : (x) < 0 ? ((BC).mode[2] == PRE_BC_CONSTANT ? (BC).value[2] : (f)[((b) * X + ((BC).mode[2] == PRE_BC_PERIODIC ? X - 1 : (BC).mode[2] == PRE_BC_REFLECT ? 1 : 0)) * Y + (y)]) \
+                         : (x) >= X ? ((BC).mode[3] == PRE_BC_CONSTANT ? (BC).value[3] : (f)[((b) * X + ((BC).mode[3] == PRE_BC_PERIODIC ? 0 : (BC).mode[3] == PRE_BC_REFLECT ? X - 2 : X - 1)) * Y + (y)]) \
+                         : (f)[((b) * X + (x)) * Y + (y)])
+        int rc = pre_spatial2d_bc_f32(du, st3, dout, st3, Kgx, &bc, BS, X, Y, 0, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        for (int b = 0; b < BS; ++b) for (int x = 0; x < X; ++x) for (int y = 0; y < Y; ++y)
+            want[(b * X + x) * Y + y] = 0.5f * AT(hu, b, x + 1, y, bc) - 0.5f * AT(hu, b, x - 1, y, bc);
+        EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-6, "pre_spatial2d_bc_f32: d/dx with neumann top, dirichlet bottom vs C loops");
+        rc = pre_spatial2d_bc_f32(du, st3, dout, st3, Kgy, &bc2, BS, X, Y, 0, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        for (int b = 0; b < BS; ++b) for (int x = 0; x < X; ++x) for (int y = 0; y < Y; ++y)
+            want[(b * X + x) * Y + y] = 0.5f * AT(hu, b, x, y + 1, bc2) - 0.5f * AT(hu, b, x, y - 1, bc2);
+        EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-6, "pre_spatial2d_bc_f32: d/dy with symmetric left, dirichlet right vs C loops");
+        /* Divergence: D_x(u) + D_y(v); Curl: ratio -1 (Utils/VectorConvOps_Spatial.py:97-165) */
+        rc = pre_spatial2d_linear2_bc_f32(du, st3, dv, st3, dout, st3, Kgx, Kgy, -1.f, &bc, BS, X, Y, 0, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        for (int b = 0; b < BS; ++b) for (int x = 0; x < X; ++x) for (int y = 0; y < Y; ++y)
+            want[(b * X + x) * Y + y] = (0.5f * AT(hu, b, x + 1, y, bc) - 0.5f * AT(hu, b, x - 1, y, bc))
+                                        - (0.5f * AT(hv, b, x, y + 1, bc) - 0.5f * AT(hv, b, x, y - 1, bc));
+        EXPECT(rc == PRE_OK && rel_err(got, want, N) <= 1e-6, "pre_spatial2d_linear2_bc_f32: K0(u) - K1(v) with mixed boundaries vs C loops");
+#undef AT
+        const float Kdense[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        EXPECT(pre_spatial2d_bc_f32(du, st3, dout, st3, Kdense, &bc, BS, X, Y, 0, st) == PRE_E_UNSUPPORTED, "a corner tap -> PRE_E_UNSUPPORTED");
+    }
+
+    /* ---- a12 resident form: modulation_func = std over the batch axis, numpy's float32 order */
+    {
+        enum { n = B * T, M = X * Y };
+        float *dmod;
+        static float hmod[M], wmod[M];
+        CHECK_HIP(hipMalloc((void **)&dmod, sizeof hmod));
+        int rc = pre_std_axis0_f32(du, dv, n, M, 0.f, dmod, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(hmod, dmod, sizeof hmod, hipMemcpyDeviceToHost));
+        for (int c = 0; c < M; ++c) {
+            double s1 = 0, s2 = 0;
+            for (int i = 0; i < n; ++i) s1 += (double)hu[i * M + c] - hv[i * M + c];
+            for (int i = 0; i < n; ++i) { const double d = ((double)hu[i * M + c] - hv[i * M + c]) - s1 / n; s2 += d * d; }
+            wmod[c] = (float)sqrt(s2 / n);
+        }
+        EXPECT(rc == PRE_OK && rel_err(hmod, wmod, M) <= 1e-5, "pre_std_axis0_f32 vs C two-pass std (<= 1e-5)");
+        hipFree(dmod);
+    }
+
+    /* ---- a14: coverage counts against per-cell bounds (Joint/Burgers_Residuals_CP.py:298-300;
+     * Active_Learning/Advection_AL_Marginal.py:169-198) */
+    {
+        enum { n = B * T, M = X * Y };
+        static float hlo[M], hhi[M];
+        float *dlo, *dhi;
+        unsigned long long *dcount, hcount = 0, wcount = 0;
+        uint32_t *drow, hrow[n], hrow2[n], wrow[n], wrow2[n];
+        uint8_t *dins, hins[n], wins[n];
+        for (int c = 0; c < M; ++c) { hlo[c] = 0.5f + 0.2f * (float)(c % 3) * 0.1f; hhi[c] = 1.45f - 0.01f * (float)(c % 7); }
+        for (int c = 0; c < M; ++c) { hlo[c] = (c % 5 == 0) ? hu[2 * M + c] : hlo[c]; }         /* a bound that IS a sample: <= counts */
+        CHECK_HIP(hipMalloc((void **)&dlo, sizeof hlo)); CHECK_HIP(hipMalloc((void **)&dhi, sizeof hhi));
+        CHECK_HIP(hipMalloc((void **)&dcount, 8)); CHECK_HIP(hipMalloc((void **)&drow, sizeof hrow)); CHECK_HIP(hipMalloc((void **)&dins, sizeof hins));
+        CHECK_HIP(hipMemcpy(dlo, hlo, sizeof hlo, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dhi, hhi, sizeof hhi, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemsetAsync(dcount, 0, 8, st)); CHECK_HIP(hipMemsetAsync(drow, 0, sizeof hrow, st)); CHECK_HIP(hipMemsetAsync(dins, 1, sizeof hins, st));
+        int rc = pre_cov_count_f32(du, dlo, dhi, n, M, 0, dcount, st);
+        int rc2 = pre_cov_rowcount_f32(du, dlo, dhi, n, M, 0, 0, drow, st);
+        int rc3 = pre_cov_joint_f32(du, dlo, dhi, n, M, 0, dins, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(&hcount, dcount, 8, hipMemcpyDeviceToHost)); CHECK_HIP(hipMemcpy(hrow, drow, sizeof hrow, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(hins, dins, sizeof hins, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemsetAsync(drow, 0, sizeof hrow, st));
+        int rc4 = pre_cov_rowcount_f32(du, dlo, dhi, n, M, 0, 1, drow, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(hrow2, drow, sizeof hrow2, hipMemcpyDeviceToHost));
+        int same = 1;
+        for (int i = 0; i < n; ++i) {
+            wrow[i] = wrow2[i] = 0;
+            for (int c = 0; c < M; ++c) {
+                const float y = hu[i * M + c];
+                wrow[i] += (y >= hlo[c] && y <= hhi[c]);
+                wrow2[i] += (y <= hlo[c] || y >= hhi[c]);
+            }
+            wins[i] = wrow[i] == M;
+            wcount += wrow[i];
+            same &= hrow[i] == wrow[i] && hrow2[i] == wrow2[i] && hins[i] == wins[i];
+        }
+        EXPECT(rc == PRE_OK && hcount == wcount && wcount > 0 && wcount < (unsigned long long)n * M, "pre_cov_count_f32: cells inside [lo, hi], exact");
+        EXPECT(rc2 == PRE_OK && rc3 == PRE_OK && rc4 == PRE_OK && same, "pre_cov_rowcount_f32 (inside / outside) + pre_cov_joint_f32: per-sample counts and flags, exact");
+        hipFree(dlo); hipFree(dhi); hipFree(dcount); hipFree(drow); hipFree(dins);
+    }
+
+    /* ---- a11, several score matrices in one launch (ABI v8): the field as 3 planes of [6, M] scores */
+    {
+        enum { P = B, n = T, M = X * Y, NK = 2 };
+        int32_t ks[NK] = {n - 1, 1};
+        float *dq;
+        static float hq[P * NK * M], col[n];
+        CHECK_HIP(hipMalloc((void **)&dq, sizeof hq));
+        /* results as [plane][rank][cell] */
+        int rc = pre_kth_axis0_planes_f32(du, (int64_t)n * M, M, P, n, M, ks, NK, dq, M, (int64_t)NK * M, st);
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(hq, dq, sizeof hq, hipMemcpyDeviceToHost));
+        int exact = 1;
+        for (int p = 0; p < P; ++p) for (int c = 0; c < M; ++c) {
+            for (int i = 0; i < n; ++i) col[i] = hu[(p * n + i) * M + c];
+            qsort(col, n, sizeof(float), cmp_float);
+            for (int j = 0; j < NK; ++j) exact &= (hq[(p * NK + j) * M + c] == col[ks[j]]);
+        }
+        EXPECT(rc == PRE_OK && exact, "pre_kth_axis0_planes_f32: 3 planes in one launch, bit-exact vs qsort per cell");
+        EXPECT(pre_kth_axis0_planes_f32(du, M, M, P, n, M, ks, NK, dq, M, (int64_t)NK * M, st) == PRE_E_RANGE, "planes closer than their cells -> PRE_E_RANGE");
+        EXPECT(pre_joint_score_pruned_max_segments() >= (64 * 1024 - 256) / 4, "pre_joint_score_pruned_max_segments() >= 16320 (64 KiB of LDS)");
+        hipFree(dq);
+    }
+
+    /* ---- a9: periodic_bc_residual (Marginal/NS_Residuals_CP.py:468-478): opposite edges of every plane, times dx */
+    {
+        const float dx = 1.f / 64;
+        float *de;
+        static float he[B * T * Y], we[B * T * Y];
+        CHECK_HIP(hipMalloc((void **)&de, sizeof he));
+        int ok = 1;
+        for (int wall = 0; wall < 4; ++wall) {
+            const int L = wall < 2 ? Y : X;
+            int rc = pre_edge_residual_f32(&fu, wall, dx, B, T, X, Y, de, st);
+            CHECK_HIP(hipStreamSynchronize(st));
+            CHECK_HIP(hipMemcpy(he, de, sizeof he, hipMemcpyDeviceToHost));
+            for (int bt = 0; bt < B * T; ++bt) for (int i = 0; i < L; ++i) {
+                const float *pl = hu + (size_t)bt * X * Y;
+                const float top = pl[i], bottom = pl[(X - 1) * Y + i], left = pl[i * Y], right = pl[i * Y + Y - 1];
+                we[bt * L + i] = (wall == 0 ? top - bottom : wall == 1 ? bottom - top : wall == 2 ? left - right : right - left) * dx;
+            }
+            ok &= rc == PRE_OK && memcmp(he, we, (size_t)B * T * L * sizeof(float)) == 0;
+        }
+        EXPECT(ok, "pre_edge_residual_f32: all four walls, bit-exact vs C");
+        EXPECT(pre_edge_residual_f32(&fu, 4, dx, B, T, X, Y, de, st) == PRE_E_RANGE, "wall 4 -> PRE_E_RANGE");
+        hipFree(de);
     }
 
     CHECK_HIP(hipStreamDestroy(st));

@@ -131,6 +131,11 @@ def _build_c_client(out):
 def test_c99_client_compiles_and_links(tmp_path):
     _lib.load()                                     # the library must exist (built by __graft_entry__.build())
     assert os.path.exists(_build_c_client(tmp_path / "abi_check"))
+    # ... and calls every symbol the header declares (run on the GPU by test_gpu_parity.py::test_c_abi_client)
+    header = open(os.path.join(ROOT, "include", "cp_pre_hip.h")).read()
+    client = open(os.path.join(ROOT, "tests", "c_abi", "abi_check.c")).read()
+    declared = set(re.findall(r"\b(?:int|int64_t)\s+(pre_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) == 29 and not [d for d in declared if d + "(" not in client]
 
 
 def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
