@@ -198,6 +198,8 @@ class NavierStokes(_Residual2D):
         v = d.reshape((1,) * (4 - d.dim()) + tuple(d.shape)) if d.dim() < 4 else (d if d.dim() == 4 else d.reshape(-1, *d.shape[-3:]))
         B, T, X, Y = v.shape
         out = torch.empty(lead + ((Y,) if code < 2 else (X,)), dtype=torch.float32, device=d.device)
+        if out.numel() == 0:                                     # (an empty batch has no device memory to point at)
+            return _dispatch.from_device(out, origin)
         with torch.cuda.device(d.device):
             f = _lib.field(v)
             _lib.check(_lib.load().pre_edge_residual_f32(ctypes.byref(f), code, float(self.dx), B, T, X, Y, _lib.ptr(out),

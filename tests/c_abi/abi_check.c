@@ -50,6 +50,7 @@ static int cmp_float(const void *a, const void *b) { const float x = *(const flo
 int main(void)
 {
     int failures = 0;
+    setvbuf(stdout, NULL, _IONBF, 0);              /* a crash must not swallow the lines before it */
     EXPECT(pre_abi_version() == PRE_ABI_VERSION && PRE_ABI_VERSION == 8, "pre_abi_version() == PRE_ABI_VERSION == 8");
 
     /* ---- the reference's kernels: kernel_3d(stencil, axis) with the stencil on slab 1 (Utils/ConvOps_2d.py:67-79) */
@@ -349,7 +350,7 @@ int main(void)
             }
         double worst = 0;
         for (int i = 0; i < 27; ++i) { const double e = fabs(hgk[i] - wgk[i]) / fabs(wgk[i]); if (e > worst) worst = e; }
-        EXPECT(rc == PRE_OK && worst <= 1e-9, "pre_stencil3d_wgrad_f32: 27 kernel gradients vs C loops (fp64 sums, <= 1e-9)");
+        EXPECT(rc == PRE_OK && worst <= 1e-5, "pre_stencil3d_wgrad_f32: 27 kernel gradients vs C loops (fp32 partial sums per thread, fp64 across blocks: <= 1e-5)");
         EXPECT(pre_stencil3d_wgrad_f32(&fu, &fv, 5, 3, 3, B, T, X, Y, dgk, st) == PRE_E_UNSUPPORTED, "kernel extent 5 -> PRE_E_UNSUPPORTED");
         hipFree(dgk);
     }
@@ -472,7 +473,7 @@ int main(void)
             for (int j = 0; j < NK; ++j) exact &= (hq[(p * NK + j) * M + c] == col[ks[j]]);
         }
         EXPECT(rc == PRE_OK && exact, "pre_kth_axis0_planes_f32: 3 planes in one launch, bit-exact vs qsort per cell");
-        EXPECT(pre_kth_axis0_planes_f32(du, M, M, P, n, M, ks, NK, dq, M, (int64_t)NK * M, st) == PRE_E_RANGE, "planes closer than their cells -> PRE_E_RANGE");
+        EXPECT(pre_kth_axis0_planes_f32(du, M - 1, M, P, n, M, ks, NK, dq, M, (int64_t)NK * M, st) == PRE_E_RANGE, "planes closer than a row is long -> PRE_E_RANGE");
         EXPECT(pre_joint_score_pruned_max_segments() >= (64 * 1024 - 256) / 4, "pre_joint_score_pruned_max_segments() >= 16320 (64 KiB of LDS)");
         hipFree(dq);
     }
@@ -491,8 +492,8 @@ int main(void)
             CHECK_HIP(hipMemcpy(he, de, sizeof he, hipMemcpyDeviceToHost));
             for (int bt = 0; bt < B * T; ++bt) for (int i = 0; i < L; ++i) {
                 const float *pl = hu + (size_t)bt * X * Y;
-                const float top = pl[i], bottom = pl[(X - 1) * Y + i], left = pl[i * Y], right = pl[i * Y + Y - 1];
-                we[bt * L + i] = (wall == 0 ? top - bottom : wall == 1 ? bottom - top : wall == 2 ? left - right : right - left) * dx;
+                const float first = wall < 2 ? pl[i] : pl[i * Y], last = wall < 2 ? pl[(X - 1) * Y + i] : pl[i * Y + Y - 1];
+                we[bt * L + i] = ((wall == 0 || wall == 2) ? first - last : last - first) * dx;
             }
             ok &= rc == PRE_OK && memcmp(he, we, (size_t)B * T * L * sizeof(float)) == 0;
         }
