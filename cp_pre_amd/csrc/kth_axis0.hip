@@ -77,11 +77,29 @@ struct KAList { int nk; int k[KA_MAXK]; int o[KA_MAXK]; };    // ranks (ascendin
 // rows of a result OS apart): the tiles of all planes form ONE grid, tile t = (plane t / tpp, cells 64 (t % tpp) ...), so a
 // driver that holds a time-major residual slab (pipeline.time_major: [T][n][plane]) selects all its planes in one launch
 // instead of T launches that each end on a ragged round of workgroups.
-struct KAPlanes { long long tpp, PS, OS, OPS; };
-__device__ __forceinline__ void ka_locate(const KAPlanes &pl, long long tile, long long &plane, long long &c0)
+// (sp, sc: a persistent grid's step from one of its tiles to the next, grid = sp * tpp + sc, so that the loop advances
+// (plane, tile in plane) by additions: a 64-bit division per tile costs the register-tile kernels ~100 VALU instructions
+// of the ~1100 a tile of n = 130..512 rows takes - measured 8-11 %)
+struct KAPlanes { long long tpp, PS, OS, OPS; long long sp, sc; };
+__device__ __forceinline__ void ka_locate(const KAPlanes &pl, long long tile, long long &plane, long long &c0, int W = KA_W)
 {
-    plane = tile / pl.tpp;                 // (wave-uniform, once per tile)
-    c0 = (tile - plane * pl.tpp) * KA_W;
+    long long t;                           // tile within its plane (wave-uniform)
+    if (tile <= 0xffffffffLL) {            // tpp < 2^31 (host check): 32-bit division whenever the tile index allows
+        const unsigned int q = (unsigned int)tile / (unsigned int)pl.tpp;
+        plane = q;
+        t = (long long)((unsigned int)tile - q * (unsigned int)pl.tpp);
+    } else {
+        plane = tile / pl.tpp;
+        t = tile - plane * pl.tpp;
+    }
+    c0 = t * W;
+}
+// the tile one grid step behind (plane, c0)
+__device__ __forceinline__ void ka_advance(const KAPlanes &pl, long long &plane, long long &c0, int W = KA_W)
+{
+    plane += pl.sp;
+    c0 += pl.sc * W;
+    if (c0 >= pl.tpp * W) { c0 -= pl.tpp * W; ++plane; }
 }
 
 template <bool WIDE> struct Ctr {
@@ -760,12 +778,15 @@ __device__ __forceinline__ float kt_max3(float a, float b, float c) { float r; a
 
 // the narrowing after the first-digit sweep of the register-resident form (exact window: nothing below it, nothing in
 // the overflow row).  Same walks as ka_narrow_first, kept short in registers: the tile's 64 data registers are live.
-template <int LOG_NB1>
+// C32 (32-cell tiles): one 32-bit counter per cell and word instead of two 16-bit ones.  row0 = the count of histogram
+// row 0: the tile's padding rows and the cell's NaNs (nothing else maps there).
+template <int LOG_NB1, bool C32>
 __device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsigned int &myr, int &digit, unsigned int &count,
-                                          int lane, int wave)
+                                          unsigned int &row0, int lane, int wave)
 {
     constexpr int NB1 = 1 << LOG_NB1, GB = NB1 / KA_WAVES, GROUPS_AT = (NB1 + 1) * 32;
-    const int l31 = lane & 31, sh = 16 * (lane >> 5);
+    constexpr unsigned int MSK = C32 ? 0xffffffffu : 0xffffu;
+    const int l31 = lane & 31, sh = C32 ? 0 : 16 * (lane >> 5);
     // 16 groups of GB bins (rows 1 + d) are summed by all 1024 threads first; the two cells of a word are added
     // together (no carry: a sum is at most n < 65536) and taken apart at the end
     {
@@ -773,12 +794,14 @@ __device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsign
         const unsigned int *h = hist + (1 + wave * GB) * 32 + l31;
 #pragma unroll 4
         for (int u = 0; u < GB; ++u) gs += h[u * 32];
-        hist[GROUPS_AT + wave * 64 + lane] = (gs >> sh) & 0xffffu;
+        hist[GROUPS_AT + wave * 64 + lane] = (gs >> sh) & MSK;
     }
     __syncthreads();
     digit = 0;
     count = 0;
+    row0 = 0;
     if (state) {
+        row0 = (hist[l31] >> sh) & MSK;
         unsigned int run = 0, cum = 0;
         int g = 0;
 #pragma unroll 4
@@ -794,29 +817,30 @@ __device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsign
         int d = 0;
 #pragma unroll 4
         for (int u = 0; u < GB; ++u) {
-            run += (h[u * 32] >> sh) & 0xffffu;
+            run += (h[u * 32] >> sh) & MSK;
             const bool le = run <= myr;
             d += le;
             cum = le ? run : cum;
         }
         d = min(d, GB - 1);
         digit = g * GB + d;
-        count = (h[d * 32] >> sh) & 0xffffu;
+        count = (h[d * 32] >> sh) & MSK;
         myr -= cum;
     }
 }
 
-// element `myr` of the `count` (<= N) keys of list `slot` in ascending order (`keep` for count == 0); the sort is
-// ks_sort's in-register bitonic network, declared below
+// element `myr` of the `count` (<= N) entries of list `slot` of cell `cell` in ascending order (`keep` for count == 0).  The
+// lists hold the scores' raw bit patterns (the sweeping threads - all of them - do not pay for the key transform; the
+// owners - ten waves, a dozen entries - do); the sort is ks_sort's in-register bitonic network, declared below
 template <int N, int K> __device__ __forceinline__ void ks_sort(unsigned int (&v)[N]);
 template <int N, int LS>
 __device__ __forceinline__ unsigned int kt_pick(const unsigned int *hist, int slot, unsigned int count, unsigned int myr,
-                                                unsigned int keep, int lane)
+                                                unsigned int keep, int cell)
 {
     unsigned int c[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const unsigned int x = i < LS - 1 ? hist[ka_list<LS>(slot, i, lane)] : 0xffffffffu;
+        const unsigned int x = i < LS - 1 ? f2key(__uint_as_float(hist[ka_list<LS>(slot, i, cell)])) : 0xffffffffu;
         c[i] = (unsigned)i < count ? x : 0xffffffffu;
     }
     ks_sort<N, 2>(c);
@@ -826,37 +850,75 @@ __device__ __forceinline__ unsigned int kt_pick(const unsigned int *hist, int sl
     return ans;
 }
 
-template <int LOG_NB1, int R, int WGS>
+// C32: a tile is 32 cells wide and a wave reads TWO rows of it per load (lanes 0-31 row 2j, lanes 32-63 row 2j + 1, 128
+// bytes each), so R = 64 registers per thread hold n <= 2048 rows: the calibration sets between 1024 and 2048 samples are
+// read once too (the streaming form read them 2.13 times).  Half-width row segments cost DRAM efficiency (128 B: 0.7x,
+// tools/exp/colread.hip), but one read at 0.7 beats two at 1.  Everything per cell - window, histogram (a full 32-bit
+// counter per cell: the two half-waves of an instruction meet the LDS in different cycles), map, lists - is addressed by
+// cell = lane & 31; what a rank's owner computes it computes in both half-waves alike, and the lower one writes it.
+//
+// Rows beyond n: a thread's registers u >= its row count are set to NaN when the window is taken (their loads came back 0
+// through an empty descriptor), and from there on NOTHING tests a row again: the hardware min / max skip a NaN, a NaN's
+// histogram row is 0 (v_cvt_u32_f32), which no rank reads and no list wants.  Row 0 thereby counts padding + NaNs, so
+// "does the column hold a NaN" is one comparison per cell (row 0 != the tile's padding) instead of a test per element.
+// The last quarter of the registers is skipped as a block when no thread has a row in it (n <= 3/4 of the capacity).
+template <int LOG_NB1, int R, int WGS, bool C32>
 __global__ void __launch_bounds__(1024, 4 * WGS)
 kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, long long ntiles, const KAList kl,
                 float *__restrict__ out, const KAPlanes pl)
 {
     using Cfg = KTCfg<LOG_NB1, WGS>;
-    using C = Ctr<false>;
     constexpr int NB1 = Cfg::NB1, LS = Cfg::LS, CAP = Cfg::CAP;
+    constexpr int W = C32 ? 32 : 64;                  // cells per tile
+    constexpr int RPT = C32 ? 32 : KA_WAVES;          // rows between a thread's registers u and u + 1
+    constexpr int Q = R / 4, RLO = R / 2 + Q;         // registers [RLO, R): skipped when n <= RLO * RPT
+    constexpr int BATCH = Q % 8 == 0 ? 8 : Q % 6 == 0 ? 6 : 4;
+    static_assert(Q % 2 == 0 && RLO % BATCH == 0 && Q % BATCH == 0, "register blocks");
     __shared__ unsigned int lds[Cfg::TOTAL];
     unsigned int *hist = lds, *mapw = lds + Cfg::WORDS, *side = mapw + Cfg::MAP_WORDS;
     unsigned char *map = reinterpret_cast<unsigned char *>(mapw);
     unsigned int *win = side + Cfg::WIN_AT, *pub = side + Cfg::PUB_AT, *cnt = side + Cfg::CNT_AT, *flg = side + Cfg::FLG_AT;
     const int tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int nk = kl.nk;
+    const int S4 = (int)(S * 4);                       // (C32: the second row of a load, in bytes; host: S < 2^29)
+    const bool hiq = (n + RPT - 1) / RPT > RLO;        // some thread has a row in the last quarter (block-uniform)
+    const unsigned int pads = (unsigned)((hiq ? R : RLO) * RPT - n);       // padding rows per cell
 
     // one-time LDS state: empty byte map, zero list counters, empty window
     for (int i = tid0; i < Cfg::MAP_WORDS; i += 1024) mapw[i] = 0u;
     for (int i = tid0; i < Cfg::SIDE_WORDS; i += 1024) side[i] = i < 64 ? 0xffffffffu : 0u;
 
+    // records of the descriptor of register u (bytes readable from its base): `vb` of a row inside n, both rows of a C32 pair
+    auto records = [&](int wave, int u, int vb) __attribute__((always_inline)) -> int {
+        if constexpr (C32) {
+            const int k = n - (2 * wave + 32 * u);            // rows of the pair inside n (selects, not branches)
+            return (k > 0 ? vb : 0) + (k > 1 && vb != 0 ? S4 : 0);
+        } else {
+            return wave + KA_WAVES * u < n ? vb : 0;
+        }
+    };
+    // my byte offset inside a register's descriptor (C32: lanes beyond the tile's cells point nowhere)
+    auto lane_off = [&](int lane, int vb) __attribute__((always_inline)) -> int {
+        if constexpr (C32) {
+            const int cb4 = (lane & 31) * 4;
+            return cb4 < vb ? (lane >> 5) * S4 + cb4 : (int)0xfffffff0u;
+        } else {
+            return lane * 4;
+        }
+    };
+
     long long tile = blockIdx.x;
+    long long plane, c0;                   // of `tile`, advanced with it
+    ka_locate(pl, tile, plane, c0, W);
     float v[R];
     {
-        long long plane, c0;
-        ka_locate(pl, tile, plane, c0);
-        const int valid = (int)((M - c0) * 4 < 256 ? (M - c0) * 4 : 256);
-        const int nu = (n - wave0 + KA_WAVES - 1) / KA_WAVES;
-        const float *p = s + plane * pl.PS + c0 + (long long)wave0 * S;
+        const int vb = (int)((M - c0) * 4 < W * 4 ? (M - c0) * 4 : W * 4);
+        const float *p = s + plane * pl.PS + c0 + (long long)(C32 ? 2 * wave0 : wave0) * S;
+        const int loff = lane_off(tid0 & 63, vb);
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            v[u] = kt_row(p, u < nu ? valid : 0, (tid0 & 63) * 4);
-            p += (long long)KA_WAVES * S;
+            v[u] = (u < RLO || hiq) ? kt_row(p, records(wave0, u, vb), loff) : 0.f;
+            p += (long long)RPT * S;
         }
     }
     __syncthreads();
@@ -866,82 +928,101 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
         const int wave = kt_opq_s(wave0);
         const bool state = wave < nk;
         const unsigned int k0 = state ? (unsigned)kl.k[wave] : 0u;
-        const int nu0 = (n - wave + KA_WAVES - 1) / KA_WAVES;      // my rows below n (wave-uniform; host: R/2 < nu0 <= R)
 
         // ---- the cell's exact window; clear the histogram meanwhile
         {
-            const int lane = kt_lane(), nu = kt_opq_s(nu0);
-            // two rows per instruction (min3 / max3; "unordered" = either one a NaN); the rows beyond R/2 one by one under
-            // their scalar test
+            const int lane = kt_lane(), cell = C32 ? (lane & 31) : lane;
+            // registers beyond the thread's rows -> NaN (C32: the two half-waves differ by one row, a per-lane test)
+            const float qnan = __uint_as_float(0x7fc00000u);
+            auto pad = [&](int u) __attribute__((always_inline)) {
+                if constexpr (C32) v[u] = (2 * wave + (lane >> 5) + 32 * u < n) ? v[u] : qnan;
+                else v[u] = (kt_opq_s(wave) + KA_WAVES * u < n) ? v[u] : qnan;
+            };
+            // two rows per instruction (min3 / max3; the hardware's min / max return the other operand when one is a NaN)
             float mn = kt_min(v[0], v[1]), mx = kt_max(v[0], v[1]);
-            bool nanl = __builtin_isunordered(v[0], v[1]);
 #pragma unroll
             for (int u = 2; u < R / 2; u += 2) {
                 mn = kt_min3(mn, v[u], v[u + 1]);
                 mx = kt_max3(mx, v[u], v[u + 1]);
-                nanl |= __builtin_isunordered(v[u], v[u + 1]);
             }
 #pragma unroll
-            for (int u = R / 2; u < R; ++u)
-                if (u < nu) {
-                    mn = kt_min(mn, v[u]);
-                    mx = kt_max(mx, v[u]);
-                    nanl |= v[u] != v[u];
+            for (int u = R / 2; u < RLO; u += 2) {
+                pad(u);
+                pad(u + 1);
+                mn = kt_min3(mn, v[u], v[u + 1]);
+                mx = kt_max3(mx, v[u], v[u + 1]);
+            }
+            if (hiq) {
+#pragma unroll
+                for (int u = RLO; u < R; u += 2) {
+                    pad(u);
+                    pad(u + 1);
+                    mn = kt_min3(mn, v[u], v[u + 1]);
+                    mx = kt_max3(mx, v[u], v[u + 1]);
                 }
-            // (v_min / v_max return the other operand when one is a NaN; a column of NaNs only leaves a NaN, whose key is
-            // above every number's either way - such a cell is settled by its flag)
-            atomicMin(&win[lane], f2key(mn));
-            atomicMax(&win[64 + lane], f2key(mx));
-            if (nanl) win[128 + lane] = 1u;
+            }
+            // (a column of NaNs leaves a NaN, whose key is above every number's: "not a finite window" below)
+            atomicMin(&win[cell], f2key(mn));
+            atomicMax(&win[64 + cell], f2key(mx));
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
             for (int i = wave * 64 + lane; i < ((NB1 + 1) * 32) / 4; i += 1024) h4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();
         unsigned int kmin, kmax;
         float vlo, sf;
-        bool flat, badwin, nancell;
+        bool flat, badwin;
         {
-            const int lane = kt_lane();
-            kmin = win[lane];
-            kmax = win[64 + lane];
-            nancell = win[128 + lane] != 0u;
+            const int lane = kt_lane(), cell = C32 ? (lane & 31) : lane;
+            kmin = win[cell];
+            kmax = win[64 + cell];
             vlo = key2f(kmin);
             const float r = key2f(kmax) - vlo;
-            // a constant column (r == 0) or one with a NaN (whatever its other values): settled by the window alone
-            flat = !(r > 0.f) || nancell;
+            const bool finite_lo = fabsf(vlo) < __builtin_inff();
+            // a constant column (its numbers; NaNs are counted apart) is settled by the window alone
+            flat = r == 0.f && finite_lo;
             sf = ((float)(NB1 - 1) / r) * 0.999999f;
-            badwin = !flat && (!(r < __builtin_inff()) || !(fabsf(vlo) < __builtin_inff()) || !(sf < __builtin_inff()));
+            // (an infinite or all-NaN column has r = NaN: not flat, not finite)
+            badwin = !flat && (!(r < __builtin_inff()) || !finite_lo || !(sf < __builtin_inff()));
             if (flat || badwin) sf = 0.f;
         }
 
-        // ---- first digit: NB1 - 1 value-linear buckets over the window (rows 1 .. NB1-1; rows 0 and NB1 stay empty)
+        // ---- first digit: NB1 - 1 value-linear buckets over the window (rows 1 .. NB1-1; row 0: padding and NaNs)
         // (keeping the row numbers for the second sweep, two per register, was measured at R = 32 with one workgroup per
         // CU: no gain - the sweeps were latency-, not instruction-bound - and with two per CU there are no registers for it)
         {
-            const int lane = kt_lane(), nu = kt_opq_s(nu0);
-            const unsigned int inc = C::inc(lane);
+            const int lane = kt_lane();
+            const unsigned int inc = C32 ? 1u : Ctr<false>::inc(lane);
             char *hb = reinterpret_cast<char *>(hist + (lane & 31));
 #pragma unroll
-            for (int u = 0; u < R; ++u)
-                if (u < R / 2 || u < nu) {
+            for (int u = 0; u < RLO; ++u) {
+                const unsigned int row = kt_frow(v[u], sf, vlo);
+                atomicAdd(reinterpret_cast<unsigned int *>(hb + (row << 7)), inc);          // word row * 32 + (lane & 31)
+            }
+            if (hiq) {
+#pragma unroll
+                for (int u = RLO; u < R; ++u) {
                     const unsigned int row = kt_frow(v[u], sf, vlo);
-                    atomicAdd(reinterpret_cast<unsigned int *>(hb + (row << 7)), inc);      // word row * 32 + (lane & 31)
+                    atomicAdd(reinterpret_cast<unsigned int *>(hb + (row << 7)), inc);
                 }
+            }
         }
         __syncthreads();
         unsigned int myr = k0, count, fl;
         int digit;
-        bool open;
+        bool open, nancell;
         {
-            const int lane = kt_lane();
+            const int lane = kt_lane(), cell = C32 ? (lane & 31) : lane;
             if (wave == KA_WAVES - 1) {                              // (everyone has read the window)
-                win[lane] = 0xffffffffu;
-                win[64 + lane] = 0u;
-                win[128 + lane] = 0u;
+                win[cell] = 0xffffffffu;
+                win[64 + cell] = 0u;
             }
-            kt_narrow<LOG_NB1>(hist, state, myr, digit, count, lane, wave);
-            open = state && !flat;
-            const bool bad = open && badwin, many = open && count > (unsigned)CAP;
+            unsigned int row0;
+            kt_narrow<LOG_NB1, C32>(hist, state, myr, digit, count, row0, lane, wave);
+            // np.quantile: a NaN anywhere in the column makes every quantile of the cell NaN.  (Exact whenever the window is
+            // finite: then every number maps to a row >= 1; a tile with a cell whose window is not is redone anyway.)
+            nancell = state && row0 != pads;
+            open = state && !flat && !nancell;
+            const bool bad = state && badwin, many = open && count > (unsigned)CAP;
             if (state) pub[wave * 64 + lane] = open ? (unsigned)(digit + 1) : 0u;
             const unsigned int w = (__ballot(many) != 0 ? 1u : 0u) | (__ballot(bad) != 0 ? 2u : 0u);
             if (lane == 0) flg[wave] = w;
@@ -952,12 +1033,11 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             fl = __builtin_amdgcn_readfirstlane(fl);
         }
 
-        long long plane, c0, nplane, nc0;
-        ka_locate(pl, tile, plane, c0);
         const bool more = tile + gridDim.x < ntiles;               // (block-uniform)
-        ka_locate(pl, more ? tile + gridDim.x : tile, nplane, nc0);
-        const int nvalid = more ? (int)((M - nc0) * 4 < 256 ? (M - nc0) * 4 : 256) : 0;
-        const float *nbase = s + nplane * pl.PS + nc0 + (long long)wave * S;        // my first row of the next tile
+        long long nplane = plane, nc0 = c0;
+        ka_advance(pl, nplane, nc0, W);
+        const int nvb = more ? (int)((M - nc0) * 4 < W * 4 ? (M - nc0) * 4 : W * 4) : 0;
+        const float *nbase = s + nplane * pl.PS + nc0 + (long long)(C32 ? 2 * wave : wave) * S;   // my first row of the next tile
         float *outp = out + plane * pl.OPS;
 
         // ---- collect + pick (when every pair has its <= CAP candidates: ok, block-uniform).  The list of a rank = the
@@ -986,64 +1066,75 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             // one - in scratch memory, whose loads then queue behind the prefetch below and make every element wait)
             float sf2 = sf, vlo2 = vlo;
             asm volatile("" : "+v"(sf2), "+v"(vlo2));
-            const int lane = kt_lane(), nu = kt_opq_s(nu0);
+            const int lane = kt_lane(), cell = C32 ? (lane & 31) : lane;
+            const int nloff = lane_off(lane, nvb);
             const float *np = nbase;
             const unsigned char *mapl = map + lane;
-            char *cb = reinterpret_cast<char *>(cnt + lane) - 256;             // counter of list m - 1: cb + m * 256
-            char *lb = reinterpret_cast<char *>(hist + lane) - LS * 256;       // entry pos of list m - 1: lb + m * LS * 256 + pos * 256
-            // eight rows at a time: their map bytes are read together (one LDS latency per batch, not per element); an
-            // element that is wanted joins its list - a position below CAP always: the histogram counted the list's elements
+            char *cb = reinterpret_cast<char *>(cnt + cell) - 256;             // counter of list m - 1: cb + m * 256, in units of 256
+            char *lb = reinterpret_cast<char *>(hist + cell) - LS * 256;       // entry pos of list m - 1: lb + m * LS * 256 + pos * 256
+            // BATCH rows at a time: their map bytes are read together (one LDS latency per batch, not per element); an
+            // element that is wanted joins its list - a position below CAP always: the histogram counted the list's elements.
+            // No row is tested: padding and NaNs look up row 0 of the map, which - like the whole map of a tile that is not
+            // being finished - is zero.  (The product fits 24 bits: v_mad_u32_u24, not the quarter-rate 64-bit multiply-add
+            // that pointer arithmetic on a 32-bit row number compiles to.)
+            auto batch = [&](const int u0) __attribute__((always_inline)) {
+                int m[BATCH];
 #pragma unroll
-            for (int u0 = 0; u0 < R; u0 += 8) {
-                int m[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int u = u0 + i;
-                    const unsigned int row = kt_frow(v[u], sf2, vlo2);
-                    m[i] = ((u < R / 2 || u < nu) && ok) ? (int)mapl[row * KA_MAPROW] : 0;
+                for (int i = 0; i < BATCH; ++i) {
+                    const unsigned int row = kt_frow(v[u0 + i], sf2, vlo2);
+                    m[i] = (int)mapl[__umul24(row, (unsigned)KA_MAPROW)];
                 }
                 // (issuing the batch's returning atomics together before the stores was measured: eight more live registers,
                 // spills under the 64-register cap of the two-workgroup form - n = 512 1.21 -> 1.86 ms - and no gain with one)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < BATCH; ++i) {
                     const int u = u0 + i;
                     if (m[i]) {
-                        const unsigned int pos = atomicAdd(reinterpret_cast<unsigned int *>(cb + (m[i] << 8)), 1u);
-                        *reinterpret_cast<unsigned int *>(lb + m[i] * (LS * 256) + (pos << 8)) = f2key(v[u]);
+                        // (the fill counter counts in units of 256 bytes = one list entry across the cells; raw bits: the
+                        // owners transform the few they pick from)
+                        const unsigned int pos = atomicAdd(reinterpret_cast<unsigned int *>(cb + (m[i] << 8)), 256u);
+                        *reinterpret_cast<float *>(lb + (__umul24((unsigned)m[i], (unsigned)(LS * 256)) + pos)) = v[u];
                     }
                     // the next tile, row by row into the register just consumed.  An unconditional load - rows beyond n, or
                     // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
                     // being finished or not: no copy has to wait for it here, no second definition to reconcile
-                    v[u] = kt_row(np, (u < R / 2 || u < nu) ? nvalid : 0, lane * 4);
-                    np += (long long)KA_WAVES * S;
+                    v[u] = kt_row(np, records(wave, u, nvb), nloff);
+                    np += (long long)RPT * S;
                 }
+            };
+#pragma unroll
+            for (int u0 = 0; u0 < RLO; u0 += BATCH) batch(u0);
+            if (hiq) {
+#pragma unroll
+                for (int u0 = RLO; u0 < R; u0 += BATCH) batch(u0);
             }
         }
         lds_barrier();
         if (ok) {
-            const int lane = kt_lane();
+            const int lane = kt_lane(), cell = C32 ? (lane & 31) : lane;
             unsigned int ans = kmin;                                // flat: the column's one value
             if (wave < nk) {                                        // (whole waves: cmax is theirs)
                 // my rank among the <= CAP candidates of my list: all of them into registers at once (entries beyond my
                 // own count read as all ones), a sorting network, element myr
-                if (cmax <= 8) ans = kt_pick<8, LS>(hist, myslot, open ? count : 0u, myr, ans, lane);
-                else if (cmax <= 16) ans = kt_pick<16, LS>(hist, myslot, open ? count : 0u, myr, ans, lane);
-                else if constexpr (WGS == 1) ans = kt_pick<32, LS>(hist, myslot, open ? count : 0u, myr, ans, lane);
+                if (cmax <= 8) ans = kt_pick<8, LS>(hist, myslot, open ? count : 0u, myr, ans, cell);
+                else if (cmax <= 16) ans = kt_pick<16, LS>(hist, myslot, open ? count : 0u, myr, ans, cell);
+                else if constexpr (WGS == 1) ans = kt_pick<32, LS>(hist, myslot, open ? count : 0u, myr, ans, cell);
                 else if (open) {                                    // (no 32 registers to spare: count in place)
                     ans = 0xffffffffu;
                     for (int i = 0; i < (int)count; ++i) {
-                        const unsigned int ki = hist[ka_list<LS>(myslot, i, lane)];
+                        const unsigned int ki = f2key(__uint_as_float(hist[ka_list<LS>(myslot, i, cell)]));
                         unsigned int le = 0;
-                        for (int j = 0; j < (int)count; ++j) le += hist[ka_list<LS>(myslot, j, lane)] <= ki;
+                        for (int j = 0; j < (int)count; ++j) le += f2key(__uint_as_float(hist[ka_list<LS>(myslot, j, cell)])) <= ki;
                         if (le > myr) ans = min(ans, ki);
                     }
                 }
             }
-            const long long c = c0 + lane;
-            if (state && c < M) outp[(long long)kl.o[wave] * pl.OS + c] = nancell ? __uint_as_float(0x7fc00000u) : key2f(ans);
+            const long long c = c0 + cell;
+            if (state && c < M && (!C32 || lane < 32))
+                outp[(long long)kl.o[wave] * pl.OS + c] = nancell ? __uint_as_float(0x7fc00000u) : key2f(ans);
             if (first) {                                            // leave the map and the counters as they were found
                 map[myrow * KA_MAPROW + lane] = 0;
-                cnt[wave * 64 + lane] = 0u;
+                cnt[wave * 64 + cell] = 0u;
             }
         } else if (wave == 0 && kt_lane() == 0) {
             // not finished by the fast form (a bucket above CAP: ties, an outlier stretching the window; an infinite
@@ -1053,9 +1144,12 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             outp[(long long)kl.o[0] * pl.OS + c0] = __uint_as_float(KT_MARK);
         }
         lds_barrier();
+        plane = nplane;
+        c0 = nc0;
     }
     // ---- my own marked tiles, by the streaming form above: v[] is dead, its registers are free for it (64 marks per
-    // load, lane = one of my tiles; the result of a tile overwrites its mark)
+    // load, lane = one of my tiles; the result of a tile overwrites its mark).  (C32: the streaming form's 64 lanes see
+    // the row as ending with the tile's 32 cells.)
     __syncthreads();
     {
         const int lane = threadIdx.x & 63;
@@ -1066,17 +1160,19 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             const long long t = blockIdx.x + (ib + lane) * gridDim.x;
             bool mk = false;
             if (ib + lane < mine) {
-                const long long tp = t / pl.tpp;
-                mk = __float_as_uint(marks[tp * pl.OPS + (t - tp * pl.tpp) * KA_W]) == KT_MARK;
+                long long tp, tc0;
+                ka_locate(pl, t, tp, tc0, W);
+                mk = __float_as_uint(marks[tp * pl.OPS + tc0]) == KT_MARK;
             }
             unsigned long long todo = __ballot(mk);
 #pragma unroll 1
             while (todo) {
                 const int b = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                long long plane, c0;
-                ka_locate(pl, blockIdx.x + (ib + b) * gridDim.x, plane, c0);
-                ka_tile<9, false>(s + plane * pl.PS, n, M, S, c0, kl, 1, out + plane * pl.OPS, pl.OS, lds);
+                long long mp, mc0;
+                ka_locate(pl, blockIdx.x + (ib + b) * gridDim.x, mp, mc0, W);
+                const long long mend = mc0 + W < M ? mc0 + W : M;
+                ka_tile<9, false>(s + mp * pl.PS, n, mend, S, mc0, kl, 1, out + mp * pl.OPS, pl.OS, lds);
                 __syncthreads();
             }
         }
@@ -1220,10 +1316,12 @@ int launch_kth(const float *scores, int n, long long M, long long S, const int32
     return PRE_OK;
 }
 
-template <int LOG_NB1, int R, int WGS>
+template <int LOG_NB1, int R, int WGS, bool C32 = false>
 int launch_kth_tile(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out,
-                    const KAPlanes &pl, long long planes, hipStream_t st)
+                    const KAPlanes &pl0, long long planes, hipStream_t st)
 {
+    KAPlanes pl = pl0;
+    if (C32) pl.tpp = (M + 31) / 32;
     const long long tiles = pl.tpp * planes;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -1233,7 +1331,10 @@ int launch_kth_tile(const float *scores, int n, long long M, long long S, const 
         KAList kl;
         kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
         for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
-        hipLaunchKernelGGL((kth_tile_kernel<LOG_NB1, R, WGS>), dim3((unsigned)grid), dim3(1024), 0, st, scores, n, M, S, tiles, kl, out, pl);
+        KAPlanes pg = pl;
+        pg.sp = grid / pl.tpp;
+        pg.sc = grid % pl.tpp;
+        hipLaunchKernelGGL((kth_tile_kernel<LOG_NB1, R, WGS, C32>), dim3((unsigned)grid), dim3(1024), 0, st, scores, n, M, S, tiles, kl, out, pg);
         PRE_LAUNCH_CHECK();
     }
     return PRE_OK;
@@ -1255,6 +1356,7 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     pl.PS = (long long)plane_stride;
     pl.OS = (long long)out_rank_stride;
     pl.OPS = (long long)out_plane_stride;
+    pl.sp = pl.sc = 0;                     // (set by the persistent launcher)
     if (pl.tpp > 0x7fffffffLL || planes > 0x7fffffffLL || pl.tpp * planes > (1LL << 40)) return PRE_E_SHAPE;
     // the kernels want ascending ranks (their slots rely on it): sort here, each result goes to its caller's row
     int32_t sk[64], rows[64];
@@ -1280,6 +1382,11 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     if (n <= 1024) return launch_kth_tile<9, 64, 1>(KA_ARGS);
     // 16-bit counters hold n < 65536; 1024 first-digit buckets (one workgroup per CU) pay off once 512 buckets
     // would leave more than CAP elements per bucket (n above ~2000)
+    // 1024 < n <= 2048: 32-cell tiles, two rows per load, still in registers and read once (S < 2^29: the second row of a
+    // load is addressed by a 32-bit byte offset)
+#ifndef KA_NO_C32
+    if (n <= 2048 && S < (1LL << 29)) return launch_kth_tile<9, 64, 1, true>(KA_ARGS);
+#endif
     if (n >= 65536) return launch_kth<9, true>(KA_ARGS);
     if (n > 2048) return launch_kth<10, false>(KA_ARGS);
     return launch_kth<9, false>(KA_ARGS);
