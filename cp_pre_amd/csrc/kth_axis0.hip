@@ -418,6 +418,9 @@ __device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok,
     // re-reads only the others - 2.06 reads of the scores become 1.88 at n = 4096 (the kernel is HBM-bound there)
     constexpr int KEEP = (Cfg::BYTEMAP && !WIDE) ? KA_KEEP : 0;
     static_assert(KEEP * KA_WAVES <= 2048 || KEEP == 0, "the kept rows must exist for every n the instantiation serves");
+    static_assert(KEEP % U == 0, "the kept rows are loaded in whole batches of U");
+    // (80 of the 256 rows a thread has at n = 4096: 119 of the 128 registers a thread of a 16-wave workgroup may hold; 88
+    // would still fit - 125 - but is not a whole number of load batches, and 96 spills)
     float kept[KEEP ? KEEP : 1];
     auto count1 = [&](float v) __attribute__((always_inline)) {
         nan |= __ballot(v != v);
@@ -831,8 +834,8 @@ __device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsign
 
 // element `myr` of the `count` (<= N) entries of list `slot` of cell `cell` in ascending order (`keep` for count == 0).  The
 // lists hold the scores' raw bit patterns (the sweeping threads - all of them - do not pay for the key transform; the
-// owners - ten waves, a dozen entries - do); the sort is ks_sort's in-register bitonic network, declared below
-template <int N, int K> __device__ __forceinline__ void ks_sort(unsigned int (&v)[N]);
+// owners - ten waves, a dozen entries - do); the sort is ks_sort's in-register network, declared below
+template <int N, int P, int NW> __device__ __forceinline__ void ks_sort(unsigned int (&v)[NW]);
 template <int N, int LS>
 __device__ __forceinline__ unsigned int kt_pick(const unsigned int *hist, int slot, unsigned int count, unsigned int myr,
                                                 unsigned int keep, int cell)
@@ -843,10 +846,14 @@ __device__ __forceinline__ unsigned int kt_pick(const unsigned int *hist, int sl
         const unsigned int x = i < LS - 1 ? f2key(__uint_as_float(hist[ka_list<LS>(slot, i, cell)])) : 0xffffffffu;
         c[i] = (unsigned)i < count ? x : 0xffffffffu;
     }
-    ks_sort<N, 2>(c);
+    ks_sort<N, 1, N>(c);
+    // (an empty list - a constant column, settled by its window - keeps `keep` whatever its rank: without the guard a rank
+    // below N picked the padding, and the cell came out NaN whenever no other cell of its tile sent the tile to the
+    // streaming form: latent since round 3, found by tools/exp/smalln_probe.py)
+    const unsigned int sel = count ? myr : 0u;
     unsigned int ans = count ? c[0] : keep;
 #pragma unroll
-    for (int i = 1; i < N; ++i) ans = myr == (unsigned)i ? c[i] : ans;
+    for (int i = 1; i < N; ++i) ans = sel == (unsigned)i ? c[i] : ans;
     return ans;
 }
 
@@ -884,9 +891,13 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     const bool hiq = (n + RPT - 1) / RPT > RLO;        // some thread has a row in the last quarter (block-uniform)
     const unsigned int pads = (unsigned)((hiq ? R : RLO) * RPT - n);       // padding rows per cell
 
-    // one-time LDS state: empty byte map, zero list counters, empty window
+    // one-time LDS state: empty byte map, empty window, list fill "counters" = the byte offset (from `hist`) of the next
+    // free entry of list j of cell c, entry i of which lies at ((j * LS + i) * 64 + c) * 4
     for (int i = tid0; i < Cfg::MAP_WORDS; i += 1024) mapw[i] = 0u;
-    for (int i = tid0; i < Cfg::SIDE_WORDS; i += 1024) side[i] = i < 64 ? 0xffffffffu : 0u;
+    for (int i = tid0; i < Cfg::SIDE_WORDS; i += 1024) {
+        const int k = i - Cfg::CNT_AT;
+        side[i] = i < 64 ? 0xffffffffu : (k >= 0 && k < KA_MAXK * 64) ? (unsigned)(((k >> 6) * LS * 64 + (k & 63)) * 4) : 0u;
+    }
 
     // records of the descriptor of register u (bytes readable from its base): `vb` of a row inside n, both rows of a C32 pair
     auto records = [&](int wave, int u, int vb) __attribute__((always_inline)) -> int {
@@ -1070,19 +1081,20 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             const int nloff = lane_off(lane, nvb);
             const float *np = nbase;
             const unsigned char *mapl = map + lane;
-            char *cb = reinterpret_cast<char *>(cnt + cell) - 256;             // counter of list m - 1: cb + m * 256, in units of 256
-            char *lb = reinterpret_cast<char *>(hist + cell) - LS * 256;       // entry pos of list m - 1: lb + m * LS * 256 + pos * 256
+            char *cb = reinterpret_cast<char *>(cnt + cell) - 256;             // fill pointer of list m - 1 of my cell: cb + m * 256
+            char *lb = reinterpret_cast<char *>(hist);
             // BATCH rows at a time: their map bytes are read together (one LDS latency per batch, not per element); an
             // element that is wanted joins its list - a position below CAP always: the histogram counted the list's elements.
             // No row is tested: padding and NaNs look up row 0 of the map, which - like the whole map of a tile that is not
             // being finished - is zero.  (The product fits 24 bits: v_mad_u32_u24, not the quarter-rate 64-bit multiply-add
             // that pointer arithmetic on a 32-bit row number compiles to.)
             auto batch = [&](const int u0) __attribute__((always_inline)) {
-                int m[BATCH];
+                unsigned int m[BATCH];
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) {
                     const unsigned int row = kt_frow(v[u0 + i], sf2, vlo2);
-                    m[i] = (int)mapl[__umul24(row, (unsigned)KA_MAPROW)];
+                    m[i] = mapl[__umul24(row, (unsigned)KA_MAPROW)];
+                    asm volatile("" : "+v"(m[i]));                 // (a full register: no 16-bit re-masking at the test)
                 }
                 // (issuing the batch's returning atomics together before the stores was measured: eight more live registers,
                 // spills under the 64-register cap of the two-workgroup form - n = 512 1.21 -> 1.86 ms - and no gain with one)
@@ -1090,10 +1102,11 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
                 for (int i = 0; i < BATCH; ++i) {
                     const int u = u0 + i;
                     if (m[i]) {
-                        // (the fill counter counts in units of 256 bytes = one list entry across the cells; raw bits: the
-                        // owners transform the few they pick from)
+                        // (the list's fill pointer IS the byte offset of its next free entry, 256 bytes = one entry across
+                        // the cells further each time: nothing to multiply; raw bits: the owners transform the few they
+                        // pick from)
                         const unsigned int pos = atomicAdd(reinterpret_cast<unsigned int *>(cb + (m[i] << 8)), 256u);
-                        *reinterpret_cast<float *>(lb + (__umul24((unsigned)m[i], (unsigned)(LS * 256)) + pos)) = v[u];
+                        *reinterpret_cast<float *>(lb + pos) = v[u];
                     }
                     // the next tile, row by row into the register just consumed.  An unconditional load - rows beyond n, or
                     // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
@@ -1134,7 +1147,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
                 outp[(long long)kl.o[wave] * pl.OS + c] = nancell ? __uint_as_float(0x7fc00000u) : key2f(ans);
             if (first) {                                            // leave the map and the counters as they were found
                 map[myrow * KA_MAPROW + lane] = 0;
-                cnt[wave * 64 + cell] = 0u;
+                cnt[wave * 64 + cell] = (unsigned)((wave * LS * 64 + cell) * 4);
             }
         } else if (wave == 0 && kt_lane() == 0) {
             // not finished by the fast form (a bucket above CAP: ties, an outlier stretching the window; an infinite
@@ -1181,43 +1194,48 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
 
 // ---- small calibration sets (n <= 128; the reference scripts use n_cal = 100 and 1000): the whole column of a
 // cell fits in ITS LANE's registers.  One wave = 64 adjacent cells, lane = cell: n coalesced row loads (256 B
-// each, all issued before the first is used), keys padded with all ones to N = 64 / 128, a fully unrolled bitonic
-// network of v_min_u32 / v_max_u32 on the register array (N/4 log2(N) (log2(N)+1) compare-exchanges: 672 / 1792),
+// each, all issued before the first is used), keys padded with all ones to N = 64 / 128, a fully unrolled sorting
+// network of v_min_u32 / v_max_u32 on the register array (Batcher's odd-even merge sort: 543 / 1471 compare-exchanges),
 // and the requested ranks - wave-uniform - are read with register-relative addressing.  (N = 256 was measured too:
 // 256 registers per lane leave one wave per SIMD: 1.73 ms against 1.93 ms for the radix form on [256, 2.6M], for
 // 40 s more compile time - not instantiated.)  No LDS, no barrier, no atomics, one read
 // of the scores; the radix machinery above spends ~1500 instructions per thread on per-tile set-up alone, which at
 // n = 100 is 6 elements per thread.
-// one compare-exchange stage (partner distance J inside sorted runs of length K), fully unrolled; the stages are
-// chained by template recursion because the optimizer refuses to unroll the triple loop nest as a whole
-template <int N, int K, int J>
-__device__ __forceinline__ void ks_stage(unsigned int (&v)[N])
+// The network is Batcher's odd-even merge sort: 19 / 63 / 191 / 543 / 1471 compare-exchanges for N = 8 / 16 / 32 / 64 / 128
+// (the bitonic network of rounds 1-3: 24 / 80 / 240 / 672 / 1792), every one ascending.  One stage = the exchanges with
+// partner distance K while runs of length 2P are being merged, fully unrolled; the stages are chained by template
+// recursion because the optimizer refuses to unroll the loop nest as a whole.
+// NW <= N wires: the network for N = 2^k inputs WITHOUT the exchanges that touch a wire >= NW.  Those wires would hold the
+// padding (all ones, the largest key), every exchange is ascending, so none of them would ever move anything: what is left
+// sorts NW inputs (n = 100 in 104 wires: 1157 exchanges of the 1471).
+template <int N, int P, int K, int NW>
+__device__ __forceinline__ void ks_stage(unsigned int (&v)[NW])
 {
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int l = i ^ J;
-        if (l > i) {
-            // (as asm: left as umin / umax, LLVM's n-ary reassociation pass spends minutes on the 1792-exchange network)
+    for (int x = 0; x < NW; ++x) {
+        const int y = x - K % P;
+        if (y >= 0 && y % (2 * K) < K && x + K < NW && x / (2 * P) == (x + K) / (2 * P)) {
+            // (as asm: left as umin / umax, LLVM's n-ary reassociation pass spends minutes on a 1471-exchange network)
             unsigned int lo, hi;
-            asm("v_min_u32 %0, %1, %2" : "=v"(lo) : "v"(v[i]), "v"(v[l]));
-            asm("v_max_u32 %0, %1, %2" : "=v"(hi) : "v"(v[i]), "v"(v[l]));
-            const bool asc = (i & K) == 0;
-            v[i] = asc ? lo : hi;
-            v[l] = asc ? hi : lo;
+            asm("v_min_u32 %0, %1, %2" : "=v"(lo) : "v"(v[x]), "v"(v[x + K]));
+            asm("v_max_u32 %0, %1, %2" : "=v"(hi) : "v"(v[x]), "v"(v[x + K]));
+            v[x] = lo;
+            v[x + K] = hi;
         }
     }
 }
-template <int N, int K, int J>
-__device__ __forceinline__ void ks_merge(unsigned int (&v)[N])
+template <int N, int P, int K, int NW>
+__device__ __forceinline__ void ks_merge(unsigned int (&v)[NW])
 {
-    ks_stage<N, K, J>(v);
-    if constexpr (J > 1) ks_merge<N, K, J / 2>(v);
+    ks_stage<N, P, K, NW>(v);
+    if constexpr (K > 1) ks_merge<N, P, K / 2, NW>(v);
 }
-template <int N, int K>
-__device__ __forceinline__ void ks_sort(unsigned int (&v)[N])
+// (second parameter: the run length merged first; callers start at 1)
+template <int N, int P, int NW = N>
+__device__ __forceinline__ void ks_sort(unsigned int (&v)[NW])
 {
-    ks_merge<N, K, K / 2>(v);
-    if constexpr (K < N) ks_sort<N, 2 * K>(v);
+    ks_merge<N, P, P, NW>(v);
+    if constexpr (2 * P < N) ks_sort<N, 2 * P, NW>(v);
 }
 // v[k] for a wave-uniform k: the registers are viewed as 32-wide vectors, whose dynamic extract with a uniform index
 // lowers to register-relative addressing (s_set_gpr_idx / v_movrels) - a handful of instructions per rank instead
@@ -1228,16 +1246,17 @@ __device__ __forceinline__ unsigned int ks_take(const unsigned int (&v)[N], int 
 {
     unsigned int r = 0u;
 #pragma unroll
-    for (int g = 0; g < N / 32; ++g)
+    for (int g = 0; g < (N + 31) / 32; ++g)
         if ((k >> 5) == g) {                                      // wave-uniform
             ks_u32x32 x;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) x[i] = v[32 * g + i];
+            for (int i = 0; i < 32; ++i) x[i] = 32 * g + i < N ? v[32 * g + i] : 0u;
             r = x[k & 31];
         }
     return r;
 }
 
+// N = the registers (wires) of a lane: n rounded up to a multiple of 8
 template <int N>
 __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict__ s, int n, long long M, long long S, const KAList kl,
                                                        float *__restrict__ out, const KAPlanes pl, long long ntiles)
@@ -1266,7 +1285,7 @@ __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict_
     unsigned int v[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = i < n ? f2key(raw[i]) : 0xffffffffu;
-    ks_sort<N, 2>(v);
+    ks_sort<(N <= 8 ? 8 : N <= 16 ? 16 : N <= 32 ? 32 : N <= 64 ? 64 : 128), 1, N>(v);
     // np.quantile: a NaN in the column makes every quantile of the cell NaN.  Sorted by key, positive NaNs sit above
     // +inf at the top of the n real entries and negative ones below -inf at the bottom
     const bool nan = ks_take<N>(v, n - 1) > 0xff800000u || v[0] < 0x007fffffu;
@@ -1371,8 +1390,27 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     hipStream_t st = as_stream(stream);
     const long long P = (long long)planes;
 #define KA_ARGS scores, (int)n, (long long)M, S, ks, rows, nk, out, pl, P, st
-    if (n <= 64) return launch_kth_small<64>(KA_ARGS);
-    if (n <= 128) return launch_kth_small<128>(KA_ARGS);
+    // n <= 128: the column sorted in its lane's registers, one instantiation per 8 rows (its network has the exchanges of
+    // its own wires only)
+    switch ((n + 7) / 8) {
+    case 1: return launch_kth_small<8>(KA_ARGS);
+    case 2: return launch_kth_small<16>(KA_ARGS);
+    case 3: return launch_kth_small<24>(KA_ARGS);
+    case 4: return launch_kth_small<32>(KA_ARGS);
+    case 5: return launch_kth_small<40>(KA_ARGS);
+    case 6: return launch_kth_small<48>(KA_ARGS);
+    case 7: return launch_kth_small<56>(KA_ARGS);
+    case 8: return launch_kth_small<64>(KA_ARGS);
+    case 9: return launch_kth_small<72>(KA_ARGS);
+    case 10: return launch_kth_small<80>(KA_ARGS);
+    case 11: return launch_kth_small<88>(KA_ARGS);
+    case 12: return launch_kth_small<96>(KA_ARGS);
+    case 13: return launch_kth_small<104>(KA_ARGS);
+    case 14: return launch_kth_small<112>(KA_ARGS);
+    case 15: return launch_kth_small<120>(KA_ARGS);
+    case 16: return launch_kth_small<128>(KA_ARGS);
+    default: break;
+    }
     // 128 < n <= 1024: the tile in registers, read once (16, 24, 32 rows per thread: two workgroups per CU; 48, 64: one).
     // Every instantiation serves R/2 < rows per thread <= R (its first R/2 rows need no "is this row below n" test)
     if (n <= 256) return launch_kth_tile<8, 16, 2>(KA_ARGS);

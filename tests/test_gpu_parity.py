@@ -1992,6 +1992,36 @@ def test_multi_plane_select_one_launch(gpu, n):
         assert torch.equal(pipeline.marginal_qhat(tm, alphas), pipeline.marginal_qhat(tm.contiguous(), alphas))
 
 
+@pytest.mark.parametrize("n", [20, 100, 130, 200, 256, 300, 512, 700, 1000, 1500, 2048, 3000])
+def test_constant_and_nan_columns_alone_in_their_tile(gpu, n):
+    """A constant column (settled by its window: an empty candidate list) and a column with one NaN, each in a tile whose
+    other cells are ordinary - so that nothing sends the tile to the streaming form - with SMALL ranks among the requested
+    ones: a rank below the pick's network size used to select the padding of the empty list (NaN instead of the constant;
+    latent in round 3, whose tests always had a tie column in the same tile).  Also +-inf columns, an all-NaN column, a
+    column of -0.0 / +0.0, every register-tile regime and both neighbours of it."""
+    from cp_pre_amd import inductive_cp as icp
+    g = torch.Generator(device=gpu).manual_seed(7000 + n)
+    M = 64 * 9 + 17
+    s = torch.randn(n, M, device=gpu, generator=g).abs_()
+    s[:, 5] = 1.0                                  # tile 0: constant
+    s[n // 3, 70] = float("nan")                   # tile 1: one NaN
+    s[:, 130] = float("inf")                       # tile 2: a column of +inf
+    s[:, 200] = float("nan")                       # tile 3: a column of NaN
+    s[:, 260] = -2.5                               # tile 4: constant, negative
+    s[:, 330] = 0.0
+    s[::2, 330] = -0.0                             # tile 5: zeros of both signs (equal keys apart, equal values)
+    s[n // 2, 390] = float("-inf")                 # tile 6: one -inf
+    s[:, 450] = 3e38
+    s[0, 450] = -3e38                              # tile 7: a window whose width overflows fp32
+    ks = sorted({0, 1, min(7, n - 1), min(13, n - 1), n // 2, n - 2, n - 1})
+    got = icp.kth_axis0(s, ks)
+    want = torch.sort(s, dim=0).values[ks]
+    nanmask = torch.isnan(s).any(dim=0)            # np.quantile: a NaN anywhere -> every quantile of the cell is NaN
+    assert torch.isnan(got[:, nanmask]).all(), n
+    ok = ~nanmask
+    assert torch.equal(got[:, ok], want[:, ok]), (n, (got[:, ok] != want[:, ok]).nonzero()[:5].tolist())
+
+
 def test_time_major_residual_buffer_and_planewise_qhat(gpu):
     """The t-slab driver's residual buffer for sharded marginal CP: memory [T][B][X][Y] handed to the fused kernel as
     an interior-plane ``out`` view [B,T-2,X,Y] (any batch / time strides over dense planes).  Same numbers as the

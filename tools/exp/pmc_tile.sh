@@ -5,7 +5,7 @@ n=$1; M=$2; tag=${3:-tile}
 P=$R/gpurun_out/pmc_$tag
 rm -rf "$P"; mkdir -p "$P"
 cd /tmp && export TMPDIR=/tmp
-for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   g=$(echo $grp | tr ' ' '_' | cut -c1-40)
   timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$P/$g" -o x -- python3 $R/tools/exp/tile_probe.py $n $M 1 > "$P/$g.log" 2>&1
 done
