@@ -1285,7 +1285,7 @@ __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict_
     unsigned int v[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = i < n ? f2key(raw[i]) : 0xffffffffu;
-    ks_sort<(N <= 8 ? 8 : N <= 16 ? 16 : N <= 32 ? 32 : N <= 64 ? 64 : 128), 1, N>(v);
+    ks_sort<(N <= 8 ? 8 : N <= 16 ? 16 : N <= 32 ? 32 : N <= 64 ? 64 : N <= 128 ? 128 : 256), 1, N>(v);
     // np.quantile: a NaN in the column makes every quantile of the cell NaN.  Sorted by key, positive NaNs sit above
     // +inf at the top of the n real entries and negative ones below -inf at the bottom
     const bool nan = ks_take<N>(v, n - 1) > 0xff800000u || v[0] < 0x007fffffu;
@@ -1409,6 +1409,11 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     case 14: return launch_kth_small<112>(KA_ARGS);
     case 15: return launch_kth_small<120>(KA_ARGS);
     case 16: return launch_kth_small<128>(KA_ARGS);
+    case 17: return launch_kth_small<136>(KA_ARGS);
+    case 18: return launch_kth_small<144>(KA_ARGS);
+    case 19: return launch_kth_small<152>(KA_ARGS);
+    case 20: return launch_kth_small<160>(KA_ARGS);
+    case 21: return launch_kth_small<168>(KA_ARGS);
     default: break;
     }
     // 128 < n <= 1024: the tile in registers, read once (16, 24, 32 rows per thread: two workgroups per CU; 48, 64: one).

@@ -30,7 +30,7 @@ def bench_line(log):
     return lines[-1].strip() if lines else "(bench line not captured)"
 
 
-CMDS = {"trace": ("c3_joint", "--steps 3 --warmup 1"), "trace_m": ("c3_marginal", "--steps 2 --warmup 1 --mode marginal"),
+CMDS = {"trace": ("c3_joint", "--no-secondary --steps 3 --warmup 1"), "trace_m": ("c3_marginal", "--no-secondary --steps 2 --warmup 1 --mode marginal"),
         "trace_c2": ("c2", "--config c2 --steps 3 --warmup 1"), "trace_c4": ("c4", "--config c4 --steps 3 --warmup 1"),
         "trace_c5": ("c5", "--config c5 --steps 3 --warmup 1")}
 for src, (tag, cmd) in CMDS.items():
@@ -67,6 +67,11 @@ OURS = ("march_kernel", "moments_kernel", "moments_segmax_kernel", "joint_score_
 sys.path.insert(0, os.getcwd())
 import bench                                             # split_slabs / CONFIGS: the workloads the passes ran
 
+import subprocess
+try:        # the commit the counters were collected at (bench.py ignores the file once the kernel source differs from it)
+    HEAD = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], text=True).strip()
+except Exception:
+    HEAD = None
 SRC_NOTE = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 gfx950 correction"
 
 
@@ -93,7 +98,8 @@ def hbm_report(tag, fetch_src, write_src, kernel, cmd, workload, alg_bytes, halo
         if halo_bytes:
             o.write(f", {(f+w)/halo_bytes:.4f} x (algorithmic + slab halo)")
         o.write("\n")
-    json.dump({"workload": workload, "kernel": kernel, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w,
+    json.dump({"workload": workload, "kernel": kernel, "head": HEAD, "kernel_src_sha16": bench.kernel_src_sha16(),
+               "fetch_bytes_per_launch": f, "write_bytes_per_launch": w,
                "traffic_bytes_per_launch": f + w, "algorithmic_bytes_per_launch": alg_bytes,
                "source": f"{out}/pmc_hbm_{tag}.txt ({SRC_NOTE})"}, open(f"{out}/pmc_hbm_{tag}.json", "w"), indent=1)
 

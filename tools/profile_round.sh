@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
 #   gpurun --timeout 1100 -- 'bash tools/profile_round.sh'
-# then   python tools/distill_profiles.py r02   turns gpurun_out/prof/* into profiles/r01/*.
+# then   python tools/distill_profiles.py r04   turns gpurun_out/prof/* into profiles/r04/*.
 # Trace and counter passes are separate runs (PMC is never combined with other trace domains).
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -13,7 +13,7 @@ run() {  # tag, rocprof args..., -- bench args
     echo "== $tag" >&2
     timeout -k 10 500 rocprofv3 "$@" > "$P/bench_$tag.log" 2>&1
 }
-B="python3 $R/bench.py --no-cpu-baseline"
+B="python3 $R/bench.py --no-cpu-baseline --no-secondary"
 run trace    --kernel-trace --stats --output-format csv -d "$P/trace"   -- $B --steps 3 --warmup 1
 run trace_m  --kernel-trace --stats --output-format csv -d "$P/trace_m" -- $B --steps 2 --warmup 1 --mode marginal
 run fetch    --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch" -- $B --steps 1 --warmup 0
