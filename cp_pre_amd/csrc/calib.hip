@@ -482,17 +482,43 @@ __global__ void __launch_bounds__(64) segmin_kernel(const float *__restrict__ mo
     if (threadIdx.x == 0) segmin[(long long)tc * nseg + seg] = bad ? 0.f : m;
 }
 
+// WAVE: many samples with short lists (C5: 65 536 samples of one 200 x 512 plane = 1600 segments each) - one WAVE per
+// sample, four samples per workgroup: no wave waits at a barrier for the others' global loads, and the workgroup adds its
+// four samples' statistics with ONE global atomic per counter (a block per sample put 2 x 65 536 atomics on one cache line:
+// 1.05 ms of the kernel's 1.8, tools/exp/c5_stats_probe.py).  Otherwise a block of 4-16 waves per sample shares the list.
+template <bool WAVE>
 __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *__restrict__ res, long long row_stride,
                                                                   const float *__restrict__ mod,
                                                                   const unsigned int *__restrict__ segmax,
-                                                                  const float *__restrict__ segmin, int T, int X, int Y, int cx,
+                                                                  const float *__restrict__ segmin, int n, int T, int X, int Y, int cx,
                                                                   int cy, int per_chunk, int total, float *__restrict__ scores,
                                                                   unsigned int *__restrict__ flags,
                                                                   unsigned long long *__restrict__ stats)
 {
-    extern __shared__ unsigned int work[];                        // `total` = TC * X * nseg segment ids
-    __shared__ unsigned int red[16], redi[16], nwork, sbest;
-    const int smp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    extern __shared__ unsigned int work_all[];                    // `total` = TC * X * nseg segment ids (WAVE: per wave)
+    __shared__ unsigned int red[16], redi[16], nwork_[4], sbest_[4], blk_read, blk_flagged;
+    const int lane = threadIdx.x & 63;
+    const int wave = WAVE ? 0 : (int)(threadIdx.x >> 6), nwaves = WAVE ? 1 : (int)(blockDim.x >> 6);
+    const int mywave = (int)(threadIdx.x >> 6);                   // (WAVE: which of the block's samples)
+    const int tid = WAVE ? lane : (int)threadIdx.x, nthreads = WAVE ? 64 : (int)blockDim.x;
+    const int smp = WAVE ? (int)blockIdx.x * 4 + mywave : (int)blockIdx.x;
+    unsigned int *work = work_all + (WAVE ? mywave * total : 0);
+    unsigned int &nwork = nwork_[WAVE ? mywave : 0], &sbest = sbest_[WAVE ? mywave : 0];
+    // a workgroup-wide rendezvous where the waves of a block share a sample; within ONE wave the LDS is in order already
+    auto sync = [&]() __attribute__((always_inline)) {
+        if constexpr (WAVE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
+    if (WAVE && threadIdx.x == 0) { blk_read = 0u; blk_flagged = 0u; }
+    if (WAVE) __syncthreads();
+    unsigned int my_read = 0u, my_flagged = 0u;                   // this sample's statistics (WAVE: added up per block)
+    do {                                                          // (one trip; `break` = this sample is done)
+    if (WAVE && smp >= n) break;
     const float *pr = res + smp * row_stride;
     const unsigned int *pm = segmax + (long long)smp * total;
     const long long plane = (long long)X * Y;
@@ -537,7 +563,7 @@ __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *_
 
     // (1) the segment with the largest bound: evaluated first, so that most of the others never are
     unsigned int bb = 0u, bj = 0u;
-    for (int j = tid; j < total; j += blockDim.x) {
+    for (int j = tid; j < total; j += nthreads) {
         const unsigned int b = bound(j);
         if (b > bb) { bb = b; bj = (unsigned)j; }
     }
@@ -546,32 +572,32 @@ __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *_
         const unsigned int ob = (unsigned int)__shfl_xor((int)bb, o), oj = (unsigned int)__shfl_xor((int)bj, o);
         if (ob > bb || (ob == bb && oj < bj)) { bb = ob; bj = oj; }
     }
-    if (lane == 0) { red[wave] = bb; redi[wave] = bj; }
+    if (!WAVE && lane == 0) { red[wave] = bb; redi[wave] = bj; }
     if (tid == 0) nwork = 0u;
-    __syncthreads();
-    bb = red[0], bj = redi[0];                                    // (every thread the same)
-    for (int w = 1; w < nwaves; ++w)
-        if (red[w] > bb || (red[w] == bb && redi[w] < bj)) { bb = red[w]; bj = redi[w]; }
+    sync();
+    if (!WAVE) {
+        bb = red[0], bj = redi[0];                                // (every thread the same)
+        for (int w = 1; w < nwaves; ++w)
+            if (red[w] > bb || (red[w] == bb && redi[w] < bj)) { bb = red[w]; bj = redi[w]; }
+    }
     unsigned int best = __float_as_uint(scores[smp]);            // earlier slabs (non-negative or NaN: orders as uint)
-    if (bb == 0u) {                                               // nothing scored in this slab (block-uniform)
-        if (stats && tid == 0) atomicAdd(&stats[1], (unsigned long long)total);
+    if (bb == 0u) {                                               // nothing scored in this slab (block- / wave-uniform)
         if (flags && tid == 0) flags[smp] = 0u;
-        return;
+        break;
     }
     if (bb > best) best = max(best, evaluate((int)bj));          // (every wave evaluates it: no exchange needed)
     // (2) every other segment that can still beat it
-    for (int j = tid; j < total; j += blockDim.x)
+    for (int j = tid; j < total; j += nthreads)
         if ((unsigned)j != bj && bound(j) > best) work[atomicAdd(&nwork, 1u)] = (unsigned)j;
     if (tid == 0) sbest = best;
-    __syncthreads();
+    sync();
     // the waves share the list; the best score so far is shared through LDS (it only grows, and skipping a segment
     // whose bound does not exceed ANY score already seen is always safe)
     const unsigned int nw = nwork;
-    if (stats && tid == 0) {                                      // [0] += segments read, [1] += segments, [2] += samples swept whole
+    {                                                             // [0] += segments read, [2] += samples swept whole (at the end)
         const bool giveup = flags && 4u * nw > (unsigned)total;
-        atomicAdd(&stats[0], (unsigned long long)(giveup ? (unsigned)total : nw + 1u));
-        atomicAdd(&stats[1], (unsigned long long)total);
-        if (giveup) atomicAdd(&stats[2], 1ull);
+        my_read = giveup ? (unsigned)total : nw + 1u;
+        my_flagged = giveup ? 1u : 0u;
     }
     if (flags) {
         // The bounds do not prune this sample when more than a quarter of its segments would be read, 8 KB at a time (a
@@ -581,7 +607,7 @@ __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *_
         if (tid == 0) flags[smp] = giveup ? 1u : 0u;
         if (giveup) {
             if (tid == 0) atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, best);
-            return;
+            break;
         }
     }
     for (unsigned int i = wave; i < nw; i += nwaves) {
@@ -592,8 +618,24 @@ __global__ void __launch_bounds__(1024) joint_score_pruned_kernel(const float *_
             if (v > best) { best = v; if (lane == 0) atomicMax(&sbest, v); }
         }
     }
-    __syncthreads();
+    sync();
     if (tid == 0) atomicMax(reinterpret_cast<unsigned int *>(scores) + smp, max(best, sbest));
+    } while (false);
+    // statistics: [1] (segments: total per sample, whatever happened to it) once per launch, [0] / [2] once per block
+    if (!stats) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long)n * (unsigned long long)total);
+    if constexpr (WAVE) {
+        if (lane == 0 && my_read) atomicAdd(&blk_read, my_read);
+        if (lane == 0 && my_flagged) atomicAdd(&blk_flagged, my_flagged);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (blk_read) atomicAdd(&stats[0], (unsigned long long)blk_read);
+            if (blk_flagged) atomicAdd(&stats[2], (unsigned long long)blk_flagged);
+        }
+    } else if (threadIdx.x == 0) {
+        if (my_read) atomicAdd(&stats[0], (unsigned long long)my_read);
+        if (my_flagged) atomicAdd(&stats[2], 1ull);
+    }
 }
 
 // ------------------------------------------------------------------ scalar k-th (radix select)
@@ -962,16 +1004,24 @@ int pre_joint_score_pruned_f32(const float *res, int64_t row_stride, const float
     const int lds_max = pruned_lds_max();
     if (total * 4 + 256 > lds_max) return PRE_E_UNSUPPORTED;
     if (total * 4 + 256 > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(joint_score_pruned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(joint_score_pruned_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds_max - 256) != hipSuccess) {
             (void)hipGetLastError();
             return PRE_E_UNSUPPORTED;
         }
     }
     // a block per sample: few samples get more waves each to work through their lists
+    // (many samples with short lists: a wave per sample, four samples per block - see the kernel)
+    if (n >= 4096 && total <= 2048) {
+        hipLaunchKernelGGL(joint_score_pruned_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)total * 16,
+                           as_stream(stream), res, (long long)row_stride, mod, segmax, segmin, (int)n, (int)T, (int)X, (int)Y, crop_x,
+                           crop_y, (int)nseg, (int)total, scores, flags, stats);
+        PRE_LAUNCH_CHECK();
+        return PRE_OK;
+    }
     const int threads = n >= 2048 ? 256 : n >= 512 ? 512 : 1024;
-    hipLaunchKernelGGL(joint_score_pruned_kernel, dim3((unsigned)n), dim3(threads), (size_t)total * 4, as_stream(stream), res,
-                       (long long)row_stride, mod, segmax, segmin, (int)T, (int)X, (int)Y, crop_x, crop_y, (int)nseg, (int)total,
+    hipLaunchKernelGGL(joint_score_pruned_kernel<false>, dim3((unsigned)n), dim3(threads), (size_t)total * 4, as_stream(stream), res,
+                       (long long)row_stride, mod, segmax, segmin, (int)n, (int)T, (int)X, (int)Y, crop_x, crop_y, (int)nseg, (int)total,
                        scores, flags, stats);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
