@@ -94,6 +94,9 @@ __global__ void __launch_bounds__(256) moments_kernel(const float *__restrict__ 
 // maximum is a wave reduction and one store.  Per cell and split the samples are added in ascending order, as
 // moments_kernel does (the split counts differ, so the fp64 sums agree up to the order of the additions).
 constexpr int MS_TMAX = 16;
+#ifndef MS_STAGE
+#define MS_STAGE 1
+#endif
 // TCH planes x US samples in flight per thread (16 loads either way): <16,1> for slabs of many planes, <4,4> and
 // <1,16> when the tensor has only a few (C5 arrives as [n,1,Nt,Nx]).  A segment always spans MS_TMAX planes:
 // chunk tc = blockIdx.z covers planes [tc*MS_TMAX, ...) and for TCH < MS_TMAX there is one chunk.
@@ -113,16 +116,45 @@ __device__ __forceinline__ unsigned int wave_max_u32_to_lane63(unsigned int v)
     return v;
 }
 
+// the value lane (l ^ O) holds, O in {1, 2, 4, 8}, by DPP (VALU) instead of ds_bpermute: the wave reductions of the
+// few-plane moments pass were bound by the LDS pipe's crossbar (one bpermute per element and wave: moments + maxima 6.1 ms
+// on C5's 26.8 GB against 4.8 for the plain moments)
+template <int O>
+__device__ __forceinline__ unsigned int dpp_xor(unsigned int x)
+{
+    if constexpr (O == 1) return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+    else if constexpr (O == 2) return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    else if constexpr (O == 8) return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true);  // row_ror:8
+    else {
+        // O == 4: banks 0, 2 of a row (lanes with bit 2 clear) read 4 lanes up, banks 1, 3 read 4 lanes down
+        const int t = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0x5, false);                                 // row_shl:4
+        return (unsigned int)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xf, 0xa, false);                         // row_shr:4
+    }
+}
+
+// Wave maxima of US samples at once.  Step `width`: lanes with that bit clear keep samples [0, H), the others [H, 2H), and
+// each takes its partner's maxima of the samples it keeps.  Widths 32 and 16 are gfx950's v_permlane32_swap /
+// v_permlane16_swap: ONE swap of (m[k], m[H+k]) puts, in the lanes that keep sample k, the partner's m[k] next to their
+// own, and likewise for H+k in the other lanes - one swap and one max per pair of samples; widths 8 and 4 are DPP row moves.
+typedef unsigned int ms_u32x2 __attribute__((ext_vector_type(2)));
 template <int US, int H>
 __device__ __forceinline__ void ms_butterfly(unsigned int (&m)[US], int lane)
 {
     if constexpr (H >= 1) {
         constexpr int width = 64 * H / US;                        // 32 for the first step
-        const bool up = lane & width;
 #pragma unroll
         for (int k = 0; k < H; ++k) {
-            const unsigned int mine = up ? m[H + k] : m[k], send = up ? m[k] : m[H + k];
-            m[k] = max(mine, (unsigned int)__shfl_xor((int)send, width));
+            if constexpr (width == 32) {
+                const ms_u32x2 r = __builtin_amdgcn_permlane32_swap(m[k], m[H + k], false, false);
+                m[k] = max(r.x, r.y);
+            } else if constexpr (width == 16) {
+                const ms_u32x2 r = __builtin_amdgcn_permlane16_swap(m[k], m[H + k], false, false);
+                m[k] = max(r.x, r.y);
+            } else {
+                const bool up = lane & width;
+                const unsigned int mine = up ? m[H + k] : m[k], send = up ? m[k] : m[H + k];
+                m[k] = max(mine, dpp_xor<width>(send));
+            }
         }
         ms_butterfly<US, H / 2>(m, lane);
     }
@@ -151,9 +183,14 @@ __device__ __forceinline__ void ms_load(const float *__restrict__ au, unsigned i
             v[u][t] = ms_cell(au + ((i + u) * row_stride + (FULL || TCH == 1 || t < nt ? t : nt - 1) * plane), c, (unsigned int)plane * 4u);
 }
 
+// `stage` (US == 16, a 1024-thread block = 16 adjacent segments): the maxima of a trip's 16 samples x 16 segments go
+// through LDS and leave as 64 contiguous bytes per sample.  A wave storing ONE word per sample writes 4 bytes for every
+// 256 it reads, each into a different 64-byte sector of segmax [n][segments]: on single-plane data (C5) that was a quarter
+// more HBM traffic than the scores themselves (moments + maxima 6.1 ms against 4.8 for the plain moments).
+struct MsStage { unsigned int (*m)[17]; unsigned int *row0; long long nseg_left; };    // LDS [segment][sample], this block's first segment of sample 0
 template <int TCH, int US, bool FULL>
 __device__ __forceinline__ void ms_use(const float (&v)[US][TCH], int i, int nt, bool scored, double (&s)[TCH], double (&q)[TCH],
-                                       unsigned int *__restrict__ seg, long long seg_stride)
+                                       unsigned int *__restrict__ seg, long long seg_stride, const MsStage *stage = nullptr)
 {
     unsigned int m[US];
 #pragma unroll
@@ -184,13 +221,22 @@ __device__ __forceinline__ void ms_use(const float (&v)[US][TCH], int i, int nt,
         // launch of the same run: 0.254 with shuffles and a branch around every load; 0.233 with DPP, branch-free
         // loads and sums, and the next sample's loads issued before this one is summed; the plain moments pass: 0.218)
         m[0] = wave_max_u32_to_lane63(m[0]);
-        if (lane == 63) seg[i * seg_stride] = m[0];
+        if (lane == 63 && seg) seg[i * seg_stride] = m[0];          // (seg == nullptr: a wave wholly past the plane)
     } else {
         ms_butterfly<US, US / 2>(m, lane);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-            if (o < 64 / US) m[0] = max(m[0], (unsigned int)__shfl_xor((int)m[0], o));
-        if ((lane & (64 / US - 1)) == 0) seg[(i + lane / (64 / US)) * seg_stride] = m[0];
+        if constexpr (64 / US > 8) m[0] = max(m[0], dpp_xor<8>(m[0]));
+        if constexpr (64 / US > 4) m[0] = max(m[0], dpp_xor<4>(m[0]));
+        m[0] = max(m[0], dpp_xor<2>(m[0]));
+        m[0] = max(m[0], dpp_xor<1>(m[0]));
+        if (US == 16 && stage) {
+            if ((lane & 3) == 0) stage->m[threadIdx.x >> 6][lane >> 2] = m[0];
+            __syncthreads();
+            if (threadIdx.x < 256) {
+                const int smp = (int)(threadIdx.x >> 4), sg = (int)(threadIdx.x & 15);
+                if (sg < stage->nseg_left) stage->row0[(i + smp) * seg_stride + sg] = stage->m[sg][smp];
+            }
+            __syncthreads();
+        } else if ((lane & (64 / US - 1)) == 0) seg[(i + lane / (64 / US)) * seg_stride] = m[0];
     }
 }
 
@@ -198,7 +244,7 @@ __device__ __forceinline__ void ms_use(const float (&v)[US][TCH], int i, int nt,
 template <int TCH, int US, bool FULL>
 __device__ __forceinline__ void ms_samples(const float *__restrict__ au, unsigned int c, long long row_stride, long long plane, int i0, int i1,
                                            int nt, bool scored, double (&s)[TCH], double (&q)[TCH], unsigned int *__restrict__ seg,
-                                           long long seg_stride)
+                                           long long seg_stride, const MsStage *stage = nullptr)
 {
     int i = i0;
     if constexpr (US == 1) {
@@ -218,10 +264,10 @@ __device__ __forceinline__ void ms_samples(const float *__restrict__ au, unsigne
         if (i + US <= i1) ms_load<TCH, US, FULL>(au, c, row_stride, plane, i, nt, v);
         for (; i + US <= i1; i += 2 * US) {
             ms_load<TCH, US, FULL>(au, c, row_stride, plane, min(i + US, ilast), nt, w);
-            ms_use<TCH, US, FULL>(v, i, nt, scored, s, q, seg, seg_stride);
+            ms_use<TCH, US, FULL>(v, i, nt, scored, s, q, seg, seg_stride, stage);
             if (i + 2 * US > i1) { i += US; break; }
             ms_load<TCH, US, FULL>(au, c, row_stride, plane, min(i + 2 * US, ilast), nt, v);
-            ms_use<TCH, US, FULL>(w, i + US, nt, scored, s, q, seg, seg_stride);
+            ms_use<TCH, US, FULL>(w, i + US, nt, scored, s, q, seg, seg_stride, stage);
         }
         for (; i < i1; ++i) {
             ms_load<TCH, 1, FULL>(au, c, row_stride, plane, i, nt, v1);
@@ -230,15 +276,18 @@ __device__ __forceinline__ void ms_samples(const float *__restrict__ au, unsigne
     }
 }
 
+// (US == 16, single-plane data: 1024-thread blocks = 16 adjacent segments, whose maxima leave through LDS - see MsStage;
+// every wave of such a block stays for the barriers, a wave wholly past the plane re-reads the last cell and counts nowhere)
 template <int TCH, int US>
-__global__ void __launch_bounds__(256) moments_segmax_kernel(const float *__restrict__ a, long long row_stride, int n, int T, int X,
+__global__ void __launch_bounds__(US == 16 && MS_STAGE ? 1024 : 256)
+moments_segmax_kernel(const float *__restrict__ a, long long row_stride, int n, int T, int X,
                                                              int Y, int cx, int cy, int rows_per_split, double *__restrict__ sum,
                                                              double *__restrict__ sumsq, unsigned int *__restrict__ segmax)
 {
     // a segment = 64 consecutive cells of the flattened (x, y) plane x 16 planes (it may straddle rows: a bound needs no
     // geometry); lanes past the plane's last cell re-read it and count nowhere
     const long long plane = (long long)X * Y, cl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if ((cl & ~63LL) >= plane) return;                                                     // a wave wholly past the plane
+    if (!(US == 16 && MS_STAGE) && (cl & ~63LL) >= plane) return;                                         // a wave wholly past the plane
     const bool live = cl < plane;
     const long long c = live ? cl : plane - 1;
     const int x = (int)(c / Y), y = (int)(c - (long long)x * Y);
@@ -253,8 +302,13 @@ __global__ void __launch_bounds__(256) moments_segmax_kernel(const float *__rest
 #pragma unroll
     for (int t = 0; t < TCH; ++t) s[t] = q[t] = 0.0;
     const unsigned int cb = (unsigned int)c * 4u;                                           // (X * Y <= 2^30: checked by the host)
-    if (nt == TCH) ms_samples<TCH, US, true>(au, cb, row_stride, plane, i0, i1, nt, scored, s, q, seg, seg_stride);
-    else ms_samples<TCH, US, false>(au, cb, row_stride, plane, i0, i1, nt, scored, s, q, seg, seg_stride);
+    __shared__ unsigned int stage_m[US == 16 ? 16 : 1][17];
+    MsStage st{stage_m, segmax + (long long)tc * nseg + (long long)blockIdx.x * (blockDim.x >> 6),
+               nseg - (long long)blockIdx.x * (blockDim.x >> 6)};
+    const MsStage *stage = (US == 16 && MS_STAGE) ? &st : nullptr;
+    if (US == 16 && MS_STAGE && (cl & ~63LL) >= plane) seg = nullptr;     // (a wave wholly past the plane stays for the barriers but stores nothing)
+    if (nt == TCH) ms_samples<TCH, US, true>(au, cb, row_stride, plane, i0, i1, nt, scored, s, q, seg, seg_stride, stage);
+    else ms_samples<TCH, US, false>(au, cb, row_stride, plane, i0, i1, nt, scored, s, q, seg, seg_stride, stage);
     sum += (long long)t0 * plane + c;
     sumsq += (long long)t0 * plane + c;
 #pragma unroll
@@ -883,18 +937,19 @@ int pre_moments_segmax_f64(const float *a, int64_t row_stride, int64_t n, int64_
 {
     if (!a || !sum || !sumsq || !segmax || n <= 0 || T <= 0 || X <= 0 || Y <= 0) return PRE_E_NULL;
     if (crop_x < 0 || crop_y < 0 || row_stride < T * X * Y) return PRE_E_RANGE;
-    const long long bx = (X * Y + 255) / 256, TC = (T + MS_TMAX - 1) / MS_TMAX;
+    const int us = T == 1 ? 16 : T <= 4 ? 4 : 1;
+    const int bt = (us == 16 && MS_STAGE) ? 1024 : 256;                                // (single-plane data: 16 segments per block, see MsStage)
+    const long long bx = (X * Y + bt - 1) / bt, TC = (T + MS_TMAX - 1) / MS_TMAX;
     if (n > 0x7fffffff || bx > 0x7fffffffLL || TC > 65535 || T > 0x7fffffff) return PRE_E_SHAPE;
     if (X * Y >= (1LL << 30)) return PRE_E_SHAPE;                        // (a lane's cell is a 32-bit BYTE offset from the plane's base)
-    const int us = T == 1 ? 16 : T <= 4 ? 4 : 1;
     long long splits = 1;
     const long long want = us > 1 ? 2048 : 1024;          // (the few-plane forms run 8 waves per SIMD)
-    while (bx * TC * splits < want && splits * 32 * us < n) splits *= 2;
+    while (bx * (bt / 256) * TC * splits < want && splits * 32 * us < n) splits *= 2;
     const int rows = (int)((n + splits - 1) / splits);
     splits = (n + rows - 1) / rows;
     const dim3 grid((unsigned)bx, (unsigned)splits, (unsigned)TC);
 #define PRE_MS_LAUNCH(TCH, US)                                                                                                \
-    hipLaunchKernelGGL((moments_segmax_kernel<TCH, US>), grid, dim3(256), 0, as_stream(stream), a, (long long)row_stride, (int)n,    \
+    hipLaunchKernelGGL((moments_segmax_kernel<TCH, US>), grid, dim3(bt), 0, as_stream(stream), a, (long long)row_stride, (int)n,    \
                        (int)T, (int)X, (int)Y, crop_x, crop_y, rows, sum, sumsq, segmax)
     if (us == 16) PRE_MS_LAUNCH(1, 16);
     else if (us == 4) PRE_MS_LAUNCH(4, 4);
