@@ -759,6 +759,17 @@ __device__ __forceinline__ float kt_row(const float *p, int valid, int loff)
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, valid, 0x00020000);
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, loff, 0, 0));
 }
+// ... at `soff` bytes behind p: the scalar offset operand of the load.  A group of rows then shares ONE descriptor base: per
+// row the 64-bit base advance and re-masking of the descriptor (three scalar instructions of the eleven a row of the
+// collect sweep cost, in a phase that issues two scalar instructions per vector one) become one 32-bit add.  On gfx9 /
+// CDNA the range check is (lane offset >= num_records - scalar offset) - the scalar offset DOES count (measured: with
+// num_records = `valid` every row but a group's first came back 0) - so the descriptor's extent is valid + soff: the lanes
+// beyond `valid` bytes of the row still read 0, and a row beyond n (valid == 0) reads nothing at all.
+__device__ __forceinline__ float kt_row_s(const float *p, int valid, int loff, int soff)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, valid ? valid + soff : 0, 0x00020000);
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, loff, soff, 0));
+}
 
 // (loop-invariant values derived from the lane / wave index - LDS addresses for every phase, 64 row offsets, 64
 // comparisons u < nu - are otherwise all hoisted out of the tile loop and kept live next to the 64 data registers:
@@ -880,7 +891,8 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     constexpr int RPT = C32 ? 32 : KA_WAVES;          // rows between a thread's registers u and u + 1
     constexpr int Q = R / 4, RLO = R / 2 + Q;         // registers [RLO, R): skipped when n <= RLO * RPT
     constexpr int BATCH = Q % 8 == 0 ? 8 : Q % 6 == 0 ? 6 : 4;
-    static_assert(Q % 2 == 0 && RLO % BATCH == 0 && Q % BATCH == 0, "register blocks");
+    constexpr int GRP = BATCH == 6 ? 3 : 4;           // rows that share a descriptor base (host: (GRP - 1) rows' stride < 2^32 bytes)
+    static_assert(Q % 2 == 0 && RLO % BATCH == 0 && Q % BATCH == 0 && BATCH % GRP == 0, "register blocks");
     __shared__ unsigned int lds[Cfg::TOTAL];
     unsigned int *hist = lds, *mapw = lds + Cfg::WORDS, *side = mapw + Cfg::MAP_WORDS;
     unsigned char *map = reinterpret_cast<unsigned char *>(mapw);
@@ -888,6 +900,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     const int tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int nk = kl.nk;
     const int S4 = (int)(S * 4);                       // (C32: the second row of a load, in bytes; host: S < 2^29)
+    const int step4 = (int)(S * 4 * RPT);              // bytes from a thread's register u to u + 1 (host: 3 of them < 2^32)
     const bool hiq = (n + RPT - 1) / RPT > RLO;        // some thread has a row in the last quarter (block-uniform)
     const unsigned int pads = (unsigned)((hiq ? R : RLO) * RPT - n);       // padding rows per cell
 
@@ -900,12 +913,15 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     }
 
     // records of the descriptor of register u (bytes readable from its base): `vb` of a row inside n, both rows of a C32 pair
+    // (a thread's first R/2 registers are always rows of the tile: the host sends only R/2 < rows per thread <= R here)
     auto records = [&](int wave, int u, int vb) __attribute__((always_inline)) -> int {
         if constexpr (C32) {
-            const int k = n - (2 * wave + 32 * u);            // rows of the pair inside n (selects, not branches)
+            if (u < R / 2) return vb != 0 ? S4 + vb : 0;
+            const int k = n - 2 * wave - 32 * u;              // rows of the pair inside n (selects, not branches)
             return (k > 0 ? vb : 0) + (k > 1 && vb != 0 ? S4 : 0);
         } else {
-            return wave + KA_WAVES * u < n ? vb : 0;
+            if (u < R / 2) return vb;
+            return n - wave > KA_WAVES * u ? vb : 0;
         }
     };
     // my byte offset inside a register's descriptor (C32: lanes beyond the tile's cells point nowhere)
@@ -1094,8 +1110,15 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
                 for (int i = 0; i < BATCH; ++i) {
                     const unsigned int row = kt_frow(v[u0 + i], sf2, vlo2);
                     m[i] = mapl[__umul24(row, (unsigned)KA_MAPROW)];
-                    asm volatile("" : "+v"(m[i]));                 // (a full register: no 16-bit re-masking at the test)
                 }
+                // (full registers from here on: no 16-bit re-masking at the tests.  AFTER the batch's loads are issued - the
+                // same barrier inside the loop above made every map read wait for the one before it)
+                if constexpr (BATCH == 8)
+                    asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]));
+                else if constexpr (BATCH == 6)
+                    asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]));
+                else
+                    asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]));
                 // (issuing the batch's returning atomics together before the stores was measured: eight more live registers,
                 // spills under the 64-register cap of the two-workgroup form - n = 512 1.21 -> 1.86 ms - and no gain with one)
 #pragma unroll
@@ -1111,8 +1134,8 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
                     // the next tile, row by row into the register just consumed.  An unconditional load - rows beyond n, or
                     // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
                     // being finished or not: no copy has to wait for it here, no second definition to reconcile
-                    v[u] = kt_row(np, records(wave, u, nvb), nloff);
-                    np += (long long)RPT * S;
+                    v[u] = kt_row_s(np, records(wave, u, nvb), nloff, (i % GRP) * step4);
+                    if (i % GRP == GRP - 1) np += (long long)GRP * RPT * S;
                 }
             };
 #pragma unroll
@@ -1418,17 +1441,20 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     }
     // 128 < n <= 1024: the tile in registers, read once (16, 24, 32 rows per thread: two workgroups per CU; 48, 64: one).
     // Every instantiation serves R/2 < rows per thread <= R (its first R/2 rows need no "is this row below n" test)
-    if (n <= 256) return launch_kth_tile<8, 16, 2>(KA_ARGS);
-    if (n <= 384) return launch_kth_tile<8, 24, 2>(KA_ARGS);
-    if (n <= 512) return launch_kth_tile<8, 32, 2>(KA_ARGS);
-    if (n <= 768) return launch_kth_tile<9, 48, 1>(KA_ARGS);
-    if (n <= 1024) return launch_kth_tile<9, 64, 1>(KA_ARGS);
+    // (rows up to three register steps apart share a descriptor base and are told apart by a 32-bit scalar byte offset: 48 S x 4
+    // bytes < 2^32, i.e. rows of up to 22 M cells; beyond, the streaming form)
+    const bool tile_ok = S * 192 < (1LL << 32);
+    if (n <= 256 && tile_ok) return launch_kth_tile<8, 16, 2>(KA_ARGS);
+    if (n <= 384 && tile_ok) return launch_kth_tile<8, 24, 2>(KA_ARGS);
+    if (n <= 512 && tile_ok) return launch_kth_tile<8, 32, 2>(KA_ARGS);
+    if (n <= 768 && tile_ok) return launch_kth_tile<9, 48, 1>(KA_ARGS);
+    if (n <= 1024 && tile_ok) return launch_kth_tile<9, 64, 1>(KA_ARGS);
     // 16-bit counters hold n < 65536; 1024 first-digit buckets (one workgroup per CU) pay off once 512 buckets
     // would leave more than CAP elements per bucket (n above ~2000)
     // 1024 < n <= 2048: 32-cell tiles, two rows per load, still in registers and read once (S < 2^29: the second row of a
     // load is addressed by a 32-bit byte offset)
 #ifndef KA_NO_C32
-    if (n <= 2048 && S < (1LL << 29)) return launch_kth_tile<9, 64, 1, true>(KA_ARGS);
+    if (n <= 2048 && S * 384 < (1LL << 32)) return launch_kth_tile<9, 64, 1, true>(KA_ARGS);     // (... 96 S x 4 bytes: 11 M cells)
 #endif
     if (n >= 65536) return launch_kth<9, true>(KA_ARGS);
     if (n > 2048) return launch_kth<10, false>(KA_ARGS);
