@@ -69,6 +69,9 @@ namespace {
 #ifndef KA_KEEP
 #define KA_KEEP 80
 #endif
+#ifndef KA_KEEP_BIG
+#define KA_KEEP_BIG 80        // rows kept by the 47-entry-list instantiation
+#endif
 constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16, KA_MAPROW = 68;
 constexpr int KA_LATE_WORDS = KA_MAXK * 64 * 32;          // later sweeps (and up to 31-entry collect lists): 80 KiB
 constexpr int KA_FLAGS_AT = 1008;                         // per-wave flags (words 640..1023 are never used otherwise)
@@ -112,7 +115,13 @@ template <bool WIDE> struct Ctr {
     }
 };
 
-template <int LOG_NB1, bool WIDE>
+// LSX > 0: lists of LSX - 1 entries instead of 31 - room for them by the bitmap form of the table even with one workgroup
+// per CU.  <10, false, 48> serves 4096 < n <= 9216: at n = 8192 (a C4 / C5 calibration set per cell once the shards of
+// 8 ranks meet) the 1024 value-linear buckets hold 8 elements on average and ~22 where a bell-shaped score distribution
+// is densest - over the 31-entry cap in some (cell, rank) of most tiles, which used to send the whole range to the
+// general form's sample + 3-4 sweeps; 47 entries hold them (P(Poisson(22) > 47) ~ 1e-6) and the tile is done in sample +
+// 2 sweeps, minus the rows kept in registers.
+template <int LOG_NB1, bool WIDE, int LSX = 0>
 struct KACfg {
     static constexpr int NB1 = 1 << LOG_NB1, CW = WIDE ? 64 : 32;
     static constexpr int FIRST_WORDS = (NB1 + 1) * CW + KA_WAVES * 64;       // first-digit histogram + group sums
@@ -124,11 +133,11 @@ struct KACfg {
     //   one workgroup per CU (31-entry lists): room for a byte per (row, cell) holding slot + 1 - five instructions
     //     less per element (measured at n = 4096: 3.60 vs 3.77 ms) at the price of 2-way bank conflicts inside a quad
     //     of lanes, which nothing waits for.
-    static constexpr bool BYTEMAP = WG_PER_CU == 1;
+    static constexpr bool BYTEMAP = WG_PER_CU == 1 && LSX == 0;
     // (byte map rows are KA_MAPROW = 68 bytes apart, not 64: with 16-word rows the 32 lanes an LDS cycle serves fall on
     // 16 of the 32 banks whatever rows they look up - measured 34 % of the LDS cycles lost to conflicts; 17 words spread them)
     static constexpr int BM_WORDS = BYTEMAP ? (NB1 + 1) * (KA_MAPROW / 4) : ((NB1 + 1 + 15) / 16) * 64;
-    static constexpr int LS = WG_PER_CU == 2 ? 28 : 32, CAP = LS - 1;
+    static constexpr int LS = LSX > 0 ? LSX : WG_PER_CU == 2 ? 28 : 32, CAP = LS - 1;
     static constexpr int BM_AT = KA_MAXK * LS * 64;
     static constexpr int COLLECT_WORDS = BM_AT + BM_WORDS;
     static constexpr int W1 = FIRST_WORDS > COLLECT_WORDS ? FIRST_WORDS : COLLECT_WORDS;
@@ -400,13 +409,13 @@ __device__ __forceinline__ unsigned int ka_pick(const unsigned int *hist, int my
 // KEY of the thread's (cell, rank).  Returns false when some pair has more than CAP elements in its bucket, a
 // rank lies outside its window, the window is not finite, or the tile holds a NaN: nothing is kept, the caller
 // runs the general form; *below reports whether a rank lay outside its window.
-template <int LOG_NB1, bool WIDE>
+template <int LOG_NB1, bool WIDE, int LSX = 0>
 __device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok, int n, long long M, int nk, float sf, float vlo,
                                         unsigned int *hist, unsigned int k0, unsigned int &ans, bool &below, int lane,
                                         int wave, int tid)
 {
     using C = Ctr<WIDE>;
-    using Cfg = KACfg<LOG_NB1, WIDE>;
+    using Cfg = KACfg<LOG_NB1, WIDE, LSX>;
     constexpr int NB1 = 1 << LOG_NB1, U = Cfg::U, LS = Cfg::LS, CAP = Cfg::CAP;
     const bool state = wave < nk;
     for (int i = tid; i < (NB1 + 1) * C::CW; i += 1024) hist[i] = 0u;
@@ -416,7 +425,7 @@ __device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok,
     // KEEP: where one workgroup has the CU to itself (1024 buckets: n > 2048, 256 rows per thread at n = 4096) there are
     // ~60 registers to spare: the first KEEP rows of every thread stay in them after this sweep, and the collect sweep
     // re-reads only the others - 2.06 reads of the scores become 1.88 at n = 4096 (the kernel is HBM-bound there)
-    constexpr int KEEP = (Cfg::BYTEMAP && !WIDE) ? KA_KEEP : 0;
+    constexpr int KEEP = (Cfg::WG_PER_CU == 1 && !WIDE) ? (LSX ? KA_KEEP_BIG : KA_KEEP) : 0;
     static_assert(KEEP * KA_WAVES <= 2048 || KEEP == 0, "the kept rows must exist for every n the instantiation serves");
     static_assert(KEEP % U == 0, "the kept rows are loaded in whole batches of U");
     // (80 of the 256 rows a thread has at n = 4096: 119 of the 128 registers a thread of a 16-wave workgroup may hold; 88
@@ -488,7 +497,7 @@ __device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok,
         __syncthreads();
         if (state) atomicOr(myword, (unsigned)(myslot - __popc(*myword & ((1u << (myrow & 15)) - 1u))) << 16);
         __syncthreads();
-        ka_sweep<U>(col, cok, n, M, wave, [&](float v) __attribute__((always_inline)) {
+        auto collect = [&](float v) __attribute__((always_inline)) {
             const int row = ka_frow<NB1>(v, sf, vlo);
             const unsigned int w = hist[Cfg::BM_AT + (row >> 4) * 64 + lane], bit = (unsigned)row & 15u;
             if ((w >> bit) & 1u) {
@@ -496,7 +505,14 @@ __device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok,
                 const unsigned int pos = atomicAdd(&hist[ka_list<LS>(slot, CAP, lane)], 1u);
                 if (pos < (unsigned)CAP) hist[ka_list<LS>(slot, (int)pos, lane)] = f2key(v);   // (always: the histogram counted them)
             }
-        });
+        };
+        if constexpr (KEEP > 0) {
+            if (cok) {
+#pragma unroll
+                for (int u = 0; u < KEEP; ++u) collect(kept[u]);
+            }
+        }
+        ka_sweep<U>(col, cok, n, M, wave, collect, KEEP);
     }
     __syncthreads();
     if (state) ans = ka_pick<LS>(hist, myslot, true, myr, lane);
@@ -627,11 +643,11 @@ __device__ __forceinline__ void ka_collect(const Src &src, int nk, int known,
 }
 
 // one tile (64 cells from c0) of the streaming form, all phases, by the whole workgroup
-template <int LOG_NB1, bool WIDE>
+template <int LOG_NB1, bool WIDE, int LSX = 0>
 __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long long M, long long S, long long c0, const KAList &kl,
                                         int fast, float *__restrict__ out, long long OS, unsigned int *hist)
 {
-    using Cfg = KACfg<LOG_NB1, WIDE>;
+    using Cfg = KACfg<LOG_NB1, WIDE, LSX>;
     constexpr int U = Cfg::U, BITS = Cfg::BITS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = kl.nk;
@@ -648,7 +664,7 @@ __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long
     bool outside = false;
     if (fast) {
         unsigned int key = 0u;
-        if (ka_fast<LOG_NB1, WIDE>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid)) {
+        if (ka_fast<LOG_NB1, WIDE, LSX>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid)) {
             if (state && cok) out[(long long)kl.o[wave] * OS + c] = key2f(key);
             return;
         }
@@ -688,15 +704,15 @@ __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long
     if (state && cok) out[(long long)kl.o[wave] * OS + c] = hist[lane] ? __uint_as_float(0x7fc00000u) : key2f(myp + klo);
 }
 
-template <int LOG_NB1, bool WIDE>
-__global__ void __launch_bounds__(1024, (4 * KACfg<LOG_NB1, WIDE>::WG_PER_CU))
+template <int LOG_NB1, bool WIDE, int LSX = 0>
+__global__ void __launch_bounds__(1024, (4 * KACfg<LOG_NB1, WIDE, LSX>::WG_PER_CU))
 kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long S, long long tile0, const KAList kl, int fast,
                  float *__restrict__ out, const KAPlanes pl)
 {
-    __shared__ unsigned int hist[KACfg<LOG_NB1, WIDE>::WORDS];
+    __shared__ unsigned int hist[KACfg<LOG_NB1, WIDE, LSX>::WORDS];
     long long plane, c0;
     ka_locate(pl, tile0 + blockIdx.x, plane, c0);
-    ka_tile<LOG_NB1, WIDE>(s + plane * pl.PS, n, M, S, c0, kl, fast, out + plane * pl.OPS, pl.OS, hist);
+    ka_tile<LOG_NB1, WIDE, LSX>(s + plane * pl.PS, n, M, S, c0, kl, fast, out + plane * pl.OPS, pl.OS, hist);
 }
 
 // ---- 128 < n <= 1024: the tile lives in REGISTERS ---------------------------------------------------------------
@@ -1336,7 +1352,7 @@ int launch_kth_small(const float *scores, int n, long long M, long long S, const
     return PRE_OK;
 }
 
-template <int LOG_NB1, bool WIDE>
+template <int LOG_NB1, bool WIDE, int LSX = 0>
 int launch_kth(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out,
                const KAPlanes &pl, long long planes, hipStream_t st)
 {
@@ -1349,9 +1365,9 @@ int launch_kth(const float *scores, int n, long long M, long long S, const int32
         for (long long t0 = 0; t0 < tiles; t0 += per_launch) {
             const long long nt = tiles - t0 < per_launch ? tiles - t0 : per_launch;
             // the fast first digit pays while a full bucket holds well under CAP elements (n <= ~6 NB1 on
-            // bell-shaped scores); beyond that it would be a wasted sweep
-            hipLaunchKernelGGL((kth_axis0_kernel<LOG_NB1, WIDE>), dim3((unsigned)nt), dim3(1024), 0, st, scores, n, M, S, t0, kl,
-                               n <= 6 * (1 << LOG_NB1) ? 1 : 0, out, pl);
+            // bell-shaped scores with 31-entry lists, 9 NB1 with 47); beyond that it would be a wasted sweep
+            hipLaunchKernelGGL((kth_axis0_kernel<LOG_NB1, WIDE, LSX>), dim3((unsigned)nt), dim3(1024), 0, st, scores, n, M, S, t0, kl,
+                               n <= (LSX ? 9 : 6) * (1 << LOG_NB1) ? 1 : 0, out, pl);
             PRE_LAUNCH_CHECK();
         }
     }
@@ -1457,6 +1473,7 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     if (n <= 2048 && S * 384 < (1LL << 32)) return launch_kth_tile<9, 64, 1, true>(KA_ARGS);     // (... 96 S x 4 bytes: 11 M cells)
 #endif
     if (n >= 65536) return launch_kth<9, true>(KA_ARGS);
+    if (n > 4096 && n <= 9216) return launch_kth<10, false, 48>(KA_ARGS);      // (measured: ahead of the 31-entry form from n = 4608 on, 2-3 % behind it at n <= 4096)
     if (n > 2048) return launch_kth<10, false>(KA_ARGS);
     return launch_kth<9, false>(KA_ARGS);
 #undef KA_ARGS
