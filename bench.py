@@ -32,8 +32,8 @@ the child's code; WORLD_SIZE != N is an error (exit 2).  --scaling weak (default
 rank; strong: the --batch samples are split over the ranks.
 
 The default line (--config c3, joint, one GPU) also carries `secondary`: the other BASELINE configurations measured in
-the same process after the C3 joint job (whose number stays `value`) - C3 marginal on the same resident slab, C2, the C4
-and C5 per-GPU shards and C5 at its single-GPU size [65536,200,512] - 2 warm-up + 5 steps each, so that every config's
+the same process after the C3 joint job (whose number stays `value`) - C3 marginal on the same resident slab, C1, C2, the
+C4 and C5 per-GPU shards and C5 at its single-GPU size [65536,200,512] - 2 warm-up + 5 steps each, so that every config's
 number is one the driver's own run produced (--no-secondary skips them).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (fused
@@ -277,9 +277,11 @@ def secondary_entry(line):
 
 
 def measure_others(dev):
-    """C2, the C4 / C5 per-GPU shards and C5 whole, one after the other (each frees its tensors on return)."""
+    """C1 (the reference's own CPU-sized case: launch-bound here), C2, the C4 / C5 per-GPU shards and C5 whole, one after the
+    other (each frees its tensors on return)."""
     found = {}
-    for key, name, batch in (("c2", "c2", None), ("c4_shard", "c4", None), ("c5_shard", "c5", None), ("c5_whole", "c5", 65536)):
+    for key, name, batch in (("c1", "c1", None), ("c2", "c2", None), ("c4_shard", "c4", None), ("c5_shard", "c5", None),
+                             ("c5_whole", "c5", 65536)):
         cfg = CONFIGS[name]
         shp = cfg["shape"]
         a = argparse.Namespace(config=name, mode=cfg["mode"], batch=batch or shp[0], nt=shp[1], nx=shp[2],

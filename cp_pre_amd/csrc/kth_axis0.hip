@@ -4,11 +4,14 @@
 //
 // Bound: HBM.  Algorithmic traffic 4 B per element per sweep; the point of the design is FEW sweeps.
 //
-// Three regimes by n (pre_kth_axis0_f32 at the end of the file):
-//   n <= 128         kth_small_kernel: a cell's column in its lane's registers, bitonic network, one read;
-//   128 < n <= 1024  kth_tile_kernel: a persistent workgroup keeps the 64-cell tile in registers (16, 32 or 64 rows per
-//                    thread), exact window, every sweep out of registers, next tile prefetched in place: one read;
-//   n > 1024         kth_axis0_kernel, the STREAMING form described next: sample + 2 sweeps on typical data.
+// Regimes by n (pre_kth_axis0_planes_f32 at the end of the file; every one exact, one launch, no workspace):
+//   n <= 168          kth_small_kernel: a cell's column in its lane's registers, Batcher network pruned to its rows, one read;
+//   168 < n <= 240    kth_pair_kernel: two lanes per cell, half the column each, one cross-lane merge step, one read;
+//   .. <= 1024        kth_tile_kernel: a persistent workgroup keeps the 64-cell tile in registers (16 .. 64 rows per
+//                     thread), exact window, every sweep out of registers, next tile prefetched in place: one read;
+//   1024 < n <= 2048  the same on 32-cell tiles, two rows per load: one read;
+//   n > 2048          kth_axis0_kernel, the STREAMING form described next: sample + 2 sweeps on typical data
+//                     (31-entry lists to n = 4096, 47-entry lists to 9216, the general radix form beyond).
 //
 // A 1024-thread workgroup owns 64 adjacent cells (256 B of every sample row - narrower column tiles lose DRAM
 // efficiency fast: 128 B -> 0.7x, 64 B -> 0.3x, tools/exp/colread.hip).  lane = cell everywhere, one wave = one
@@ -1280,6 +1283,7 @@ __device__ __forceinline__ void ks_sort(unsigned int (&v)[NW])
 // lowers to register-relative addressing (s_set_gpr_idx / v_movrels) - a handful of instructions per rank instead
 // of a compare-and-select per register
 typedef unsigned int ks_u32x32 __attribute__((ext_vector_type(32)));
+typedef unsigned int ms_u32x2_k __attribute__((ext_vector_type(2)));
 template <int N>
 __device__ __forceinline__ unsigned int ks_take(const unsigned int (&v)[N], int k)
 {
@@ -1334,6 +1338,110 @@ __global__ void __launch_bounds__(256) kth_small_kernel(const float *__restrict_
         const unsigned int r = ks_take<N>(v, kl.k[j]);
         if (cok) out[(long long)kl.o[j] * pl.OS + c] = nan ? __uint_as_float(0x7fc00000u) : key2f(r);
     }
+}
+
+// ---- 168 < n <= 240: TWO lanes per cell, each sorting half the column in its registers (round 2 had this shape with
+// bitonic networks; round 3 replaced it by the 16-row register tiles, 2.3-3.0 TB/s; with the pruned Batcher networks it is
+// back).  A wave = 32 cells, lane l and l + 32 the two halves of cell l & 31 (a load reads two 128-byte runs, n0 rows
+// apart).  The lower lane sorts rows [0, n0) ascending; the upper lane rows [n0, n) ascending in the COMPLEMENTED key domain,
+// i.e. descending - so that register i of the pair holds A_i and B_(last - i), the partners of the first step of a
+// bitonic merge, and one exchange (v_permlane32_swap) per register gives both lanes "own" and "partner".  After
+// r_i = min(own_i, ~partner_i) - the same expression in both lanes' own domains - the lower lane holds the smaller half of
+// the union and the upper lane the larger half (complemented), each a bitonic sequence that a pruned bitonic merge sorts
+// descending.  Padding: wires >= NW are virtual; lower-lane padding is +inf, upper-lane padding -inf (complemented: the
+// maximum of its domain, as the ascending network wants), which the rank arithmetic at the end counts off.
+template <int NW, int J>
+__device__ __forceinline__ void kp_merge_desc(unsigned int (&v)[NW])
+{
+#pragma unroll
+    for (int x = 0; x < NW; ++x)
+        if ((x & J) == 0 && x + J < NW) {                        // (a partner >= NW is a virtual minimum: the exchange would move nothing)
+            unsigned int lo, hi;
+            asm("v_min_u32 %0, %1, %2" : "=v"(lo) : "v"(v[x]), "v"(v[x + J]));
+            asm("v_max_u32 %0, %1, %2" : "=v"(hi) : "v"(v[x]), "v"(v[x + J]));
+            v[x] = hi;
+            v[x + J] = lo;
+        }
+    if constexpr (J > 1) kp_merge_desc<NW, J / 2>(v);
+}
+
+template <int NW>
+__global__ void __launch_bounds__(256) kth_pair_kernel(const float *__restrict__ s, int n, long long M, long long S, const KAList kl,
+                                                      float *__restrict__ out, const KAPlanes pl, long long ntiles)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;            // whole wave beyond the last tile
+    long long plane, c0;
+    ka_locate(pl, tile, plane, c0, 32);
+    const int cell = lane & 31, h = lane >> 5;
+    const long long c = c0 + cell;
+    s += plane * pl.PS;
+    out += plane * pl.OPS;
+    const bool cok = c < M;
+    const int n0 = (n + 1) / 2;                                   // rows of the lower lane; the upper lane has n - n0 (n0 or n0 - 1)
+    const int nmine = h ? n - n0 : n0;
+    const unsigned int hm = h ? 0xffffffffu : 0u;                 // the upper lane works on complemented keys
+    // all row loads first (cf. kth_small_kernel): register i = row i of the lower half and row n0 + i of the upper half
+    const int vb = (int)((M - c0) * 4 < 128 ? (M - c0) * 4 : 128);
+    const int hoff = (int)((long long)n0 * S * 4);                // (host: < 2^31)
+    const int loff = cell * 4 < vb ? h * hoff + cell * 4 : (int)0xfffffff0u;
+    const float *p = s + c0;
+    float raw[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int rec = i < n - n0 ? hoff + vb : i < n0 ? vb : 0;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, rec, 0x00020000);
+        raw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, loff, 0, 0));
+        p += (i + 1 < n0) ? S : 0;
+    }
+    unsigned int v[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) v[i] = i < nmine ? f2key(raw[i]) ^ hm : 0xffffffffu;
+    ks_sort<128, 1, NW>(v);
+    // first step of the bitonic merge across the lane pair, then each lane's half sorted descending in its own domain
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const ms_u32x2_k r = __builtin_amdgcn_permlane32_swap(v[i], v[i], false, false);     // .x: the lower lane's, .y: the upper lane's
+        unsigned int a = r.x ^ hm, b = r.y ^ ~hm;                 // lower: (own, ~partner); upper: (~partner, own)
+        asm("v_min_u32 %0, %1, %2" : "=v"(v[i]) : "v"(a), "v"(b));
+    }
+    kp_merge_desc<NW, 64>(v);
+    // Ascending order of the union of 256 logical values: the lower lane's virtual -inf wires, its registers from NW - 1
+    // down to 0, the upper lane's registers 0 .. NW - 1 (complemented), its virtual +inf wires.  The upper lane's pU padding
+    // rows (-inf) lie at the bottom of the lower lane's registers: rank k of the column is position k + pU of the registers.
+    const int pU = NW - (n - n0);
+    // np.quantile: a NaN in the column makes every quantile of the cell NaN: the smallest score (lower lane) a negative NaN
+    // or the largest (upper lane, position n0 - 1 + NW - NW) a positive one
+    const unsigned int klow = ks_take<NW>(v, NW - 1 - pU), khigh = ~ks_take<NW>(v, n0 - 1);
+    const unsigned long long nb = __ballot(h ? khigh > 0xff800000u : klow < 0x007fffffu);
+    const bool nan = ((nb >> cell) | (nb >> (cell + 32))) & 1ull;
+#pragma unroll
+    for (int j = 0; j < KA_MAXK; ++j) {
+        if (j >= kl.nk) break;                                    // wave-uniform
+        const int u = kl.k[j] + pU;                               // (wave-uniform)
+        const bool upper = u >= NW;
+        const unsigned int r = upper ? ~ks_take<NW>(v, u - NW) : ks_take<NW>(v, NW - 1 - u);
+        if (cok && (h != 0) == upper) out[(long long)kl.o[j] * pl.OS + c] = nan ? __uint_as_float(0x7fc00000u) : key2f(r);
+    }
+}
+
+template <int NW>
+int launch_kth_pair(const float *scores, int n, long long M, long long S, const int32_t *ks, const int32_t *rows, int nk, float *out,
+                    const KAPlanes &pl0, long long planes, hipStream_t st)
+{
+    KAPlanes pl = pl0;
+    pl.tpp = (M + 31) / 32;
+    const long long tiles = pl.tpp * planes, blocks = (tiles + 3) / 4;
+    if (blocks > 0x7fffffffLL) return PRE_E_SHAPE;
+    for (int j0 = 0; j0 < nk; j0 += KA_MAXK) {
+        KAList kl;
+        kl.nk = (nk - j0) < KA_MAXK ? (nk - j0) : KA_MAXK;
+        for (int j = 0; j < KA_MAXK; ++j) { kl.k[j] = j < kl.nk ? ks[j0 + j] : 0; kl.o[j] = j < kl.nk ? rows[j0 + j] : 0; }
+        hipLaunchKernelGGL((kth_pair_kernel<NW>), dim3((unsigned)blocks), dim3(256), 0, st, scores, n, M, S, kl, out, pl, tiles);
+        PRE_LAUNCH_CHECK();
+    }
+    return PRE_OK;
 }
 
 template <int N>
@@ -1454,6 +1562,19 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     case 20: return launch_kth_small<160>(KA_ARGS);
     case 21: return launch_kth_small<168>(KA_ARGS);
     default: break;
+    }
+    // 168 < n <= 240: two lanes per cell, half the column each (the second half of a load is addressed by a 32-bit byte
+    // offset: n0 rows < 2^31 bytes).  (Measured against the 16-row register tiles: 3.6 vs 2.3 TB/s at n = 170, 3.2 vs 2.4 at
+    // 200, 3.05 vs ~2.7 at 230; at 256 - 128 wires, 198 registers, two waves per SIMD - 2.86 vs 2.98: the tiles keep 241-256.)
+    if (n <= 240 && (long long)((n + 1) / 2) * S * 4 < (1LL << 31)) {
+        switch (((n + 1) / 2 + 7) / 8) {
+        case 11: return launch_kth_pair<88>(KA_ARGS);
+        case 12: return launch_kth_pair<96>(KA_ARGS);
+        case 13: return launch_kth_pair<104>(KA_ARGS);
+        case 14: return launch_kth_pair<112>(KA_ARGS);
+        case 15: return launch_kth_pair<120>(KA_ARGS);
+        default: break;
+        }
     }
     // 128 < n <= 1024: the tile in registers, read once (16, 24, 32 rows per thread: two workgroups per CU; 48, 64: one).
     // Every instantiation serves R/2 < rows per thread <= R (its first R/2 rows need no "is this row below n" test)

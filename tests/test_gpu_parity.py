@@ -1992,7 +1992,7 @@ def test_multi_plane_select_one_launch(gpu, n):
         assert torch.equal(pipeline.marginal_qhat(tm, alphas), pipeline.marginal_qhat(tm.contiguous(), alphas))
 
 
-@pytest.mark.parametrize("n", [20, 100, 130, 200, 256, 300, 512, 700, 1000, 1500, 2048, 3000, 7000, 8192, 9216, 9217])
+@pytest.mark.parametrize("n", [20, 100, 130, 168, 169, 170, 183, 200, 255, 256, 257, 300, 512, 700, 1000, 1500, 2048, 3000, 7000, 8192, 9216, 9217])
 def test_constant_and_nan_columns_alone_in_their_tile(gpu, n):
     """A constant column (settled by its window: an empty candidate list) and a column with one NaN, each in a tile whose
     other cells are ordinary - so that nothing sends the tile to the streaming form - with SMALL ranks among the requested
