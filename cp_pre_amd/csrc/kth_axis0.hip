@@ -800,10 +800,12 @@ __device__ __forceinline__ float kt_row(const float *p, int valid, int loff)
 // CDNA the range check is (lane offset >= num_records - scalar offset) - the scalar offset DOES count (measured: with
 // num_records = `valid` every row but a group's first came back 0) - so the descriptor's extent is valid + soff: the lanes
 // beyond `valid` bytes of the row still read 0, and a row beyond n (valid == 0) reads nothing at all.
-__device__ __forceinline__ float kt_row_s(const float *p, int valid, int loff, int soff)
+__device__ __forceinline__ float kt_row_s(const float *p, int valid, int loff, unsigned int soff)
 {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, valid ? valid + soff : 0, 0x00020000);
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, loff, soff, 0));
+    // (unsigned 32-bit arithmetic: the host keeps the largest offset + extent below 2^32, not below 2^31)
+    const unsigned int extent = valid ? (unsigned int)valid + soff : 0u;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)extent, 0x00020000);
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, loff, (int)soff, 0));
 }
 
 // (loop-invariant values derived from the lane / wave index - LDS addresses for every phase, 64 row offsets, 64
@@ -935,7 +937,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     const int tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int nk = kl.nk;
     const int S4 = (int)(S * 4);                       // (C32: the second row of a load, in bytes; host: S < 2^29)
-    const int step4 = (int)(S * 4 * RPT);              // bytes from a thread's register u to u + 1 (host: 3 of them < 2^32)
+    const unsigned int step4 = (unsigned int)(S * 4 * RPT);      // bytes from a thread's register u to u + 1 (host: 3 of them + a row pair < 2^32)
     const bool hiq = (n + RPT - 1) / RPT > RLO;        // some thread has a row in the last quarter (block-uniform)
     const unsigned int pads = (unsigned)((hiq ? R : RLO) * RPT - n);       // padding rows per cell
 
@@ -1169,7 +1171,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
                     // the next tile, row by row into the register just consumed.  An unconditional load - rows beyond n, or
                     // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
                     // being finished or not: no copy has to wait for it here, no second definition to reconcile
-                    v[u] = kt_row_s(np, records(wave, u, nvb), nloff, (i % GRP) * step4);
+                    v[u] = kt_row_s(np, records(wave, u, nvb), nloff, (unsigned int)(i % GRP) * step4);
                     if (i % GRP == GRP - 1) np += (long long)GRP * RPT * S;
                 }
             };
@@ -1596,7 +1598,7 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     // Every instantiation serves R/2 < rows per thread <= R (its first R/2 rows need no "is this row below n" test)
     // (rows up to three register steps apart share a descriptor base and are told apart by a 32-bit scalar byte offset: 48 S x 4
     // bytes < 2^32, i.e. rows of up to 22 M cells; beyond, the streaming form)
-    const bool tile_ok = S * 192 < (1LL << 32);
+    const bool tile_ok = S * 192 + 256 < (1LL << 32);
     if (n <= 256 && tile_ok) return launch_kth_tile<8, 16, 2>(KA_ARGS);
     if (n <= 384 && tile_ok) return launch_kth_tile<8, 24, 2>(KA_ARGS);
     if (n <= 512 && tile_ok) return launch_kth_tile<8, 32, 2>(KA_ARGS);
@@ -1607,7 +1609,7 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     // 1024 < n <= 2048: 32-cell tiles, two rows per load, still in registers and read once (S < 2^29: the second row of a
     // load is addressed by a 32-bit byte offset)
 #ifndef KA_NO_C32
-    if (n <= 2048 && S * 384 < (1LL << 32)) return launch_kth_tile<9, 64, 1, true>(KA_ARGS);     // (... 96 S x 4 bytes: 11 M cells)
+    if (n <= 2048 && S * 388 + 128 < (1LL << 32)) return launch_kth_tile<9, 64, 1, true>(KA_ARGS);     // (... 96 S x 4 bytes + a row pair: 11 M cells)
 #endif
     if (n >= 65536) return launch_kth<9, true>(KA_ARGS);
     if (n > 4096 && n <= 9216) return launch_kth<10, false, 48>(KA_ARGS);      // (measured: ahead of the 31-entry form from n = 4608 on, 2-3 % behind it at n <= 4096)

@@ -2022,6 +2022,27 @@ def test_constant_and_nan_columns_alone_in_their_tile(gpu, n):
     assert torch.equal(got[:, ok], want[:, ok]), (n, (got[:, ok] != want[:, ok]).nonzero()[:5].tolist())
 
 
+@pytest.mark.parametrize("n,S", [(300, 20_000_000), (300, 23_000_000), (1100, 10_000_000), (1100, 11_500_000),
+                                 (200, 5_000_000), (200, 5_600_000), (512, 21_000_000)])
+def test_select_rows_many_megabytes_apart(gpu, n, S):
+    """Rows 20-92 MB apart (a [n, M] view of a buffer whose rows are S floats long): the register forms address a group
+    of rows by 32-bit scalar byte offsets from one descriptor base (up to 3 x 16 rows x S x 4 B, unsigned: beyond 2^31
+    here) and the two-lane / 32-cell forms the second half of a load by a 32-bit lane offset; past their limits (the
+    second S of each pair) the dispatch must fall back to a form without them.  Bit-exact against the select of a
+    contiguous copy either way."""
+    from cp_pre_amd import inductive_cp as icp
+    M = 200
+    g = torch.Generator(device=gpu).manual_seed(n + S % 1000)
+    buf = torch.empty(n * S, device=gpu)
+    view = buf.as_strided((n, M), (S, 1))
+    view.copy_(torch.randn(n, M, device=gpu, generator=g).abs_())
+    view[:, 7] = 2.0
+    ks = sorted({0, n // 2, n - 1} | {icp.kth_index(n, n, float(a)) for a in icp.ALPHA_LEVELS if icp.quantile_level(n, float(a)) <= 1})[:10]
+    got = icp.kth_axis0(view, ks)
+    want = torch.sort(view.contiguous(), dim=0).values[ks]
+    assert torch.equal(got, want), (n, S)
+
+
 def test_time_major_residual_buffer_and_planewise_qhat(gpu):
     """The t-slab driver's residual buffer for sharded marginal CP: memory [T][B][X][Y] handed to the fused kernel as
     an interior-plane ``out`` view [B,T-2,X,Y] (any batch / time strides over dense planes).  Same numbers as the
