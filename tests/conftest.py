@@ -16,7 +16,20 @@ def pytest_configure(config):
     # a fresh checkout has no built libraries (they are git-ignored): build them once (hipcc cross-compiles
     # for gfx950 without a GPU, ~35 s); an existing build is left alone
     libs = [os.path.join(ROOT, "cp_pre_amd", n) for n in ("libcp_pre_hip.so", "libcp_pre_fft.so")]
-    if not all(os.path.exists(f) for f in libs + [os.path.join(ROOT, "oracle", "liboracle.so")]):
+    stale = not all(os.path.exists(f) for f in libs + [os.path.join(ROOT, "oracle", "liboracle.so")])
+    if not stale:
+        # ... or holds a library of another ABI version (a tree that was built before the header changed): rebuild rather than
+        # fail every test on the binding's load-time check
+        import ctypes
+        import re
+        want = int(re.search(r"#define\s+PRE_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "cp_pre_hip.h")).read()).group(1))
+        try:
+            import torch  # noqa: F401  (the library binds to the HIP runtime torch loads)
+            have = ctypes.CDLL(libs[0]).pre_abi_version()
+        except Exception:
+            have = -1
+        stale = have != want
+    if stale:
         import __graft_entry__
         __graft_entry__.build()
 

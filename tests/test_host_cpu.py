@@ -138,6 +138,13 @@ def test_c99_client_compiles_and_links(tmp_path):
     assert len(declared) == 29 and not [d for d in declared if d + "(" not in client]
 
 
+def test_graft_build_entry_point():
+    """The driver's "does it build" check (`__graft_entry__.build()`: make + load + version assertions) must pass on an
+    already-built tree too - round 4 bumped the ABI and left a literal 7 in it, which nothing here exercised."""
+    import __graft_entry__
+    assert __graft_entry__.build() is None
+
+
 def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
     """No silent fallback when libcp_pre_hip.so / libcp_pre_fft.so are absent: loading raises ImportError."""
     monkeypatch.setattr(_lib, "_lib", None)
