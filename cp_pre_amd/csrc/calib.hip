@@ -943,7 +943,9 @@ int pre_moments_segmax_f64(const float *a, int64_t row_stride, int64_t n, int64_
     if (n > 0x7fffffff || bx > 0x7fffffffLL || TC > 65535 || T > 0x7fffffff) return PRE_E_SHAPE;
     if (X * Y >= (1LL << 30)) return PRE_E_SHAPE;                        // (a lane's cell is a 32-bit BYTE offset from the plane's base)
     long long splits = 1;
-    const long long want = us > 1 ? 2048 : 1024;          // (the few-plane forms run 8 waves per SIMD)
+    // (the few-plane forms run 8 waves per SIMD; the 1024-thread form one block per CU at a time: enough splits of the batch axis
+    // that the last, partial round of blocks is a small share - 800 blocks on 256 CUs were 3.1 rounds, the fourth a quarter full)
+    const long long want = us == 16 ? 16384 : us > 1 ? 2048 : 1024;
     while (bx * (bt / 256) * TC * splits < want && splits * 32 * us < n) splits *= 2;
     const int rows = (int)((n + splits - 1) / splits);
     splits = (n + rows - 1) / rows;
