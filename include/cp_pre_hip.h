@@ -241,9 +241,10 @@ int pre_joint_score_flagged_f32(const float *a, const float *b, const float *mod
 
 /* ---- a11: calibrate(scores, n, alpha) ---------------------------------------------------
  * (Neural_PDE.UQ.inductive_cp, absent; call sites Marginal/Wave_Residuals_CP.py:288,
- * Joint/Burgers_Residuals_CP.py:283).  Exact order statistics on the order-preserving uint32 image of fp32 (n <= 256:
- * the cell's column sorted in registers; above: sample-guided bucket / MSD radix select); result is bit-for-bit an
- * input value.
+ * Joint/Burgers_Residuals_CP.py:283).  Exact order statistics on the order-preserving uint32 image of fp32 (n <= 240:
+ * the cell's column sorted in the registers of one or two lanes; <= 2048: the tile held in a workgroup's registers, bucket
+ * select over its exact value window; above: sample-guided bucket / MSD radix select streaming the rows twice or more -
+ * the scores are read once for every n <= 2048); result is bit-for-bit an input value.
  * ks: host array of 0-based sorted ranks (the caller derives them from alpha).
  * pre_kth_f32:       scores[N]            -> out[nk]; any NaN score makes every result NaN (np.quantile)
  * pre_kth_axis0_f32: scores[n, M] contiguous -> out[nk, M]   (per-cell over the batch axis),
