@@ -1479,6 +1479,43 @@ def test_marginal_step_is_hip_graph_capturable(gpu):
     assert torch.equal(q, step())
 
 
+def test_joint_stream_is_hip_graph_capturable_with_a_fixed_route(gpu, monkeypatch):
+    """``JointCalibration(prune="always")`` (and ``"never"``) never reads a device counter on the host: a two-slab
+    stream - Burgers residual, moments + segment maxima, branch-and-bound score with its flagged pass, scalar q-hats -
+    records into a HIP graph and replays on new data with the result of an eager run.  (The default, adaptive policy
+    synchronises once, when the second slab arrives: it is refused by the capture, which is what the option is for.)"""
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    from cp_pre_amd import residuals as R
+    monkeypatch.setattr(pipeline.HipOps, "PRUNE_MIN_CELLS", 0)
+    monkeypatch.setattr(pipeline.HipOps, "PRUNE_MIN_SAMPLES", 0)
+    alphas = [0.1, 0.5, 0.9]
+    g = torch.Generator().manual_seed(31)
+    u = (torch.rand(300, 2, 40, 128, generator=g) + 0.5).to(gpu)            # two "slabs" of [300, 40, 128]
+    op = R.Burgers(2.0 / 128, 1.25 / 40, 0.002)
+
+    def step(policy):
+        jc = pipeline.JointCalibration(300, gpu, prune=policy)
+        for sl in range(2):
+            jc.add_slab(op.residual(u[:, sl], boundary=True).unsqueeze(1), crop=(0, 1, 1))
+        return jc.finish(alphas)
+
+    for policy in ("always", "never"):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step(policy)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            q = step(policy)
+        u.copy_((torch.rand(300, 2, 40, 128, generator=g) + 0.5).to(gpu))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(q, step(policy)), policy
+    assert torch.allclose(step("always"), step("never"), rtol=1e-6, atol=0.0)
+
+
 def test_c_abi_client(gpu, tmp_path):
     """tests/c_abi/abi_check.c: a C99 program (gcc, HIP runtime only) drives the library and checks stencil,
     fused NS residual, |a-b| and per-cell order statistics against its own C loops, plus the error codes."""
