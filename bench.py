@@ -5,15 +5,19 @@ Workload (BASELINE.json configs[2], the one the north_star target is quoted on):
 Navier-Stokes momentum residual of (u, v, p) on [4096, 64, 512, 512] fp32 per rank, followed
 by conformal calibration over the 4096 samples at the reference's 10 alpha levels.
 
-One field of that shape is 275 GB, so the tensor is streamed as t-slabs: --slab S interior planes
-(default: 16 -> 4 slabs if the 301 GB resident set fits the free HBM, else 13 -> 13,13,13,13,12) + the 2 halo
-planes their stencils read; the three input slabs [B,S+2,512,512] (232 GB at S = 16) and the residual buffer
-[B,S,512,512] (69 GB: interior planes only, PRE_FLAG_OUT_INTERIOR_T) are resident in HBM before the timed region.  Synthetic data: one resident
-slab of B + n_slabs - 1 samples stands in for the slab positions, slab position s reading the batch
-window [s, s + B) of it (825 GB of distinct input cannot be resident; the arithmetic and traffic per
-slab do not depend on the values).  One STEP = the whole [4096,64,512,512] job = n_slabs passes of
+One field of that shape is 275 GB, so the tensor is streamed as SLABS, all 4096 samples of a slab at a time (a per-cell
+std / quantile needs every sample of its cell).  Default: x-slabs (--slab-axis x) - the T axis whole (the kernel marches
+along it with the planes in registers) and the reference's interior rows 1 .. Nx-2 (Marginal/NS_Residuals_CP.py:240 crops
+rows 0 and Nx-1) cut into runs of --slab rows (default: the thickest whose resident set fits the free HBM: 128 -> 128, 128,
+127, 127), each read with the row before and the row after it (PRE_FLAG_HALO_X: real rows of the grid, 2 rows re-read per
+128).  The three input slabs [B,64,S+2,512] (209 GB at S = 128) and the residual buffer [B,64,S,512] (69 GB) are resident
+in HBM before the timed region.  (--slab-axis t: t-slabs of --slab planes + 2 halo planes, rounds 1-2.)  Synthetic data:
+one resident slab of B + n_slabs - 1 samples stands in for the slab positions, slab position s reading the batch window
+[s, s + B) of it (825 GB of distinct input cannot be resident; the arithmetic and traffic per slab do not depend on the
+values).  One STEP = the whole [4096,64,512,512] job = n_slabs passes of
     fused NS-momentum residual (one HIP launch)  ->  calibration on the resident residual slab
-and the final q-hat selection.  cells/step = 4096*64*512*512 (uncropped grid).
+and the final q-hat selection.  cells/step = the cells the launches COMPUTE: 4096*64*510*512 (x-slabs: the reference's rows
+0 and 511 exist only to be cropped and are not computed; the t and y rims are computed and cropped as in the reference).
 
 --mode joint (default; Joint/NS_Residuals_CP.py recipe): per-cell moments -> modulation ->
     per-sample max|r|/sigma -> scalar q-hat x 10.  N>1: batch-sharded, weak scaling, one RCCL
@@ -23,7 +27,8 @@ and the final q-hat selection.  cells/step = 4096*64*512*512 (uncropped grid, SU
 
 --config c1|c2|c4|c5 run the other BASELINE.json configurations (per-rank shard sizes, whole
 tensor resident, no slabs); they are secondary measurements quoted in DESIGN.md, not the
-contract line.  Default: c3.
+contract line.  Default: c3.  --equation continuity|momentum|energy|induction|gauss: which of C4's five MHD residuals
+(Marginal/MHD_Residuals_CP.py:225-278; default induction, the script's own default :323).
 
 --gpus N: one process per GPU.  Launched by the driver under torch.distributed.run (WORLD_SIZE set) the
 process is one rank; launched bare with N > 1 it SPAWNS the N ranks itself (a fresh
@@ -32,9 +37,12 @@ the child's code; WORLD_SIZE != N is an error (exit 2).  --scaling weak (default
 rank; strong: the --batch samples are split over the ranks.
 
 The default line (--config c3, joint, one GPU) also carries `secondary`: the other BASELINE configurations measured in
-the same process after the C3 joint job (whose number stays `value`) - C3 marginal on the same resident slab, C1, C2, the
-C4 and C5 per-GPU shards and C5 at its single-GPU size [65536,200,512] - 2 warm-up + 5 steps each, so that every config's
-number is one the driver's own run produced (--no-secondary skips them).
+the same process after the C3 joint job (whose number stays `value`) - C3 marginal on the same resident slab, the per-rank
+job of the strong-scaled 8-GPU curve ([512,64,512,512] x3 whole grid, joint and marginal, through a one-rank RCCL group), C1,
+C2, the C4 shard for each of its five equations, the C5 shard and C5 at its single-GPU size [65536,200,512] - 2 warm-up + 5
+steps each, so that every config's number is one the driver's own run produced (--no-secondary skips them) - and `parity`:
+after the timed region two samples of the last slab are re-evaluated by the CPU oracle (the checker, never the thing
+measured) and compared with what the HIP kernel left in the residual buffer; above 1e-5 the process exits non-zero.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (fused
 residual kernel, HIP events on its stream; `achieved` = SURVEY 8(d) bytes: 16 B x the interior
@@ -54,6 +62,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+RES_TOL = 1e-5                 # north_star: residuals within 1e-5 rel fp32 of the reference ConvOperator arithmetic
 
 
 # BASELINE.json configs: per-rank shapes (C4/C5 are quoted sharded over 8 GPUs), the fused kernel
@@ -71,10 +80,29 @@ CONFIGS = {
                title="C5 1D Burgers residual (Joint/Burgers_Residuals_CP.py), 65536/8 samples per rank"),
 }
 
+# C4's five equations (Marginal/MHD_Residuals_CP.py:225-278): fields read, algorithmic bytes per cell = 4 (F + 1) (SURVEY
+# 8d), the kernel that evaluates each.  The script's default is induction (:323); SURVEY Appendix A sizes C4 on the
+# six-field ones.
+MHD_EQUATIONS = {
+    "continuity": dict(bpc=16, kernel="march_kernel<MHDContinuity<0>,8,64>", lines="225-231"),
+    "momentum": dict(bpc=28, kernel="march_kernel<MHDMomentum<0>,8,64>", lines="234-243"),
+    "energy": dict(bpc=28, kernel="march_kernel<MHDEnergy<0>,8,64>", lines="247-256"),
+    "induction": dict(bpc=20, kernel="march_kernel<MHDInduction<0>,8,64>", lines="259-268"),
+    "gauss": dict(bpc=12, kernel="march_kernel<Linear2,8,64>", lines="271-278"),
+}
+
+
+def mhd_config(eq):
+    e = MHD_EQUATIONS[eq]
+    return dict(CONFIGS["c4"], bpc=e["bpc"], kernel=e["kernel"], equation=eq,
+                title=f"C4 2D MHD {eq} residual (Marginal/MHD_Residuals_CP.py:{e['lines']}), 8192/8 samples per rank")
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--equation", choices=sorted(MHD_EQUATIONS), default="induction",
+                    help="c4: which of the five MHD residuals (default: the script's own, induction)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -96,6 +124,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default c3 joint line only: do not measure the other BASELINE configs after it")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="c3: skip the post-timing oracle check of two samples of the last slab (profiling passes)")
     ap.add_argument("--no-prune", action="store_true",
                     help="joint mode: read the whole residual in the score pass instead of the branch-and-bound form")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
@@ -128,8 +158,8 @@ def launch_plan(gpus, environ, argv, script=None):
 
 def resident_bytes(B, n, slab, other):
     """HBM held by the c3 driver: three input slabs of B + n_slabs - 1 samples with their two halo planes (t-slabs) or
-    rows (x-slabs) + the residual buffer of the slab's own planes / rows.  ``n``: extent of the slab axis, ``other``:
-    cells per unit of it (X*Y for t-slabs, T*Y for x-slabs)."""
+    rows (x-slabs) + the residual buffer of the slab's own planes / rows.  ``n``: extent of the slab axis that is cut
+    (x-slabs: the interior rows, Nx - 2), ``other``: cells per unit of it (X*Y for t-slabs, T*Y for x-slabs)."""
     slabs = split_slabs(n, slab)
     S = max(slabs)
     return ((B + len(slabs) - 1) * 3 * (S + 2) + B * S) * other * 4 + B * 256      # (+ the residual rows' pad)
@@ -162,6 +192,99 @@ def synth_(field, seed, positive=False):
 SYNTH = "synthetic smooth-plus-noise fields (sin*cos*cos mode + 0.01 N(0,1); U(0.5,1.5) for rho, p), generated on device"
 
 
+class C3Stream:
+    """The C3 job as bench.py streams it - what `main()` times and what tests/test_gpu_fullsize.py::test_full_size_c3_xslab
+    checks against the oracle: the resident synthetic slab, the residual buffer in each of its layouts, one slab pass.
+
+    x-slabs (default): the reference's interior rows 1 .. X-2 (Marginal/NS_Residuals_CP.py:240 crops rows 0 and X-1) in
+    runs of `slab` rows; a run of `sl` rows reads rows [0, sl + 2) of the resident slab - its own rows 1 .. sl and the row
+    before / after them, real rows of the grid (PRE_FLAG_HALO_X) - with the T axis whole, and writes its own rows only.
+    t-slabs: `sl` planes + one halo plane per side (PRE_FLAG_OUT_INTERIOR_T).  Slab position s reads the batch window
+    [s, s + B) of the resident slab, so no two passes of a step see the same input."""
+
+    def __init__(self, B, T, X, Y, slab, slab_axis, dev, rank=0, nu=1e-3):
+        from cp_pre_amd.residuals import NavierStokes
+        self.B, self.T, self.X, self.Y, self.dev = B, T, X, Y, dev
+        self.xs = slab_axis == "x"
+        self.n_axis, self.other = ((X - 2, T * Y) if self.xs else (T, X * Y))
+        self.slabs = split_slabs(self.n_axis, slab)               # rows (x) / interior planes (t) per slab position
+        self.S = max(self.slabs)
+        self.dt, self.dx, self.dy, self.nu = 1e-2, 1.0 / X, 1.0 / Y, nu
+        self.ns = NavierStokes(self.dt, self.dx, self.dy, nu=nu)
+        n_slabs, S = len(self.slabs), self.S
+        # vars[:, i] views of one [B',3,T,S+2,Y] (x-slabs) or [B',3,S+2,X,Y] (t-slabs) tensor, like the reference's `vars`
+        self.vars_ = torch.empty((B + n_slabs - 1, 3, T, S + 2, Y) if self.xs else (B + n_slabs - 1, 3, S + 2, X, Y),
+                                 dtype=torch.float32, device=dev)
+        for i in range(3):
+            synth_(self.vars_[:, i], 100 * rank + 20 + i)
+        # residual buffer: the slab's OWN rows / planes only (room for either padded layout)
+        self.res_buf = torch.empty(B * (self.other * S + 64 * (T if self.xs else S)), dtype=torch.float32, device=dev)
+        # cells within `crop` of the slab's rim are excluded from the scores: the y rim always; x-slabs: the grid's own t
+        # rim (every plane is computed, zero padding beyond, as the reference's conv3d has it), no rows (all of a slab's
+        # rows are interior rows of the grid); t-slabs: the x rim, no planes (all interior)
+        self.crop = (1, 0, 1) if self.xs else (0, 1, 1)
+
+    def rshape(self, sl):
+        return (self.B, self.T, sl, self.Y) if self.xs else (self.B, sl, self.X, self.Y)
+
+    def plane(self, sl):
+        """Cells of one time plane of the residual."""
+        return sl * self.Y if self.xs else self.X * self.Y
+
+    def views(self, mode, sharded=False):
+        """The residual buffer as each slab thickness sees it: {sl: tensor [B, ...]}."""
+        B, Y, buf, rshape, plane = self.B, self.Y, self.res_buf, self.rshape, self.plane
+        if mode == "marginal" and sharded:
+            # time-major [planes][B][plane] seen as [B,planes,..]: plane t of all local samples is one contiguous block, the
+            # send block of the all-to-all that hands plane t to rank t % world (pipeline.marginal_qhat: no pack copy)
+            # (samples of a plane 64 floats further apart than a plane is long: profiles/r03/row_pitch.txt)
+            return {sl: buf.as_strided(rshape(sl), (plane(sl) + 64, B * (plane(sl) + 64), Y, 1)) for sl in set(self.slabs)}
+        if mode == "marginal":
+            # rows 64 floats further apart than they are long: a power-of-two distance between the rows of a cell's column
+            # (2^22 cells) costs the per-cell select ~10 % (pipeline.row_padded, profiles/r03/row_pitch.txt)
+            return {sl: buf.as_strided(rshape(sl), (rshape(sl)[1] * plane(sl) + 64, plane(sl), Y, 1)) for sl in set(self.slabs)}
+        return {sl: buf[:B * rshape(sl)[1] * plane(sl)].view(rshape(sl)) for sl in set(self.slabs)}
+
+    def inputs(self, s, sl):
+        """The view of the resident slab that slab position s (sl rows / planes) hands the kernel."""
+        if self.xs:
+            return self.vars_[s:s + self.B, :, :, 1:sl + 1]             # rows 0 and sl + 1 are read as halo rows
+        return self.vars_[s:s + self.B, :, :sl + 2]
+
+    def eval_slab(self, s, sl, res, absolute=False):
+        """ONE fused launch: the residual of slab position s into `res` (a view from `views`)."""
+        if self.xs:
+            return self.ns.residual_momentum(self.inputs(s, sl), boundary=True, absolute=absolute, out=res, halo_x=True)
+        return self.ns.residual_momentum(self.inputs(s, sl), boundary=True, absolute=absolute, out=res, skip_t_rim=True)
+
+    def oracle_inputs(self, s, sl, i):
+        """Host copy of what sample i of slab position s reads, halo rows / planes included: [1,3,T,sl+2,Y] / [1,3,sl+2,X,Y]."""
+        v = self.vars_[s + i, :, :, 0:sl + 2] if self.xs else self.vars_[s + i, :, :sl + 2]
+        return v.unsqueeze(0).cpu()
+
+    def oracle_crop(self, ref):
+        """The slab's own rows / planes of an oracle residual evaluated on `oracle_inputs` with boundary=True."""
+        return ref[:, :, 1:-1] if self.xs else ref[:, 1:-1]
+
+    def free(self):
+        self.vars_ = self.res_buf = None
+        torch.cuda.empty_cache()
+
+
+def c3_parity(stream, res, s, sl, samples):
+    """CHECKER, outside every timed region: samples `samples` of the residual slab `res` the HIP kernel wrote for slab
+    position s, against the CPU oracle (oracle/residuals.py::ns_momentum = the reference's own F.conv3d arithmetic,
+    Marginal/NS_Residuals_CP.py:231-240) evaluated on the same rows with their halo rows.  Tensor-scale relative error."""
+    from oracle import residuals as orr
+    worst = 0.0
+    for i in samples:
+        v = stream.oracle_inputs(s, sl, i)
+        ref = stream.oracle_crop(orr.ns_momentum(v, stream.dt, stream.dx, stream.dy, nu=stream.nu, boundary=True))[0]
+        got = res[i].cpu()
+        worst = max(worst, float((got - ref).abs().max() / ref.abs().max()))
+    return worst
+
+
 def run_secondary(args, cfg, dev, group, rank, world, par):
     """c1/c2/c4/c5: whole per-rank tensor resident; one step = fused residual + calibration.  Returns the JSON line
     (rank 0; None elsewhere)."""
@@ -192,7 +315,8 @@ def run_secondary(args, cfg, dev, group, rank, world, par):
         for i in range(6):
             synth_(v[:, i], 100 * rank + 10 + i, positive=i in (0, 3))
         op = R.MHD()
-        evaluate = lambda: op.residual_induction(v, boundary=True, absolute=absolute)
+        fn = getattr(op, "residual_" + cfg.get("equation", "induction"))
+        evaluate = lambda: fn(v, boundary=True, absolute=absolute)
         crop, cells = (1, 1, 1), B * T * X * Y
     ev = []
     pruned = [False]
@@ -218,7 +342,7 @@ def run_secondary(args, cfg, dev, group, rank, world, par):
     def sync():
         torch.cuda.synchronize()
         if group is not None:
-            torch.distributed.barrier()
+            torch.distributed.barrier(group=group)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -232,12 +356,12 @@ def run_secondary(args, cfg, dev, group, rank, world, par):
     elapsed = time.perf_counter() - t0
     if group is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=group)
         elapsed = float(tt.item())
     if rank == 0:
         kms = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
         cms = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev)            # calibration: everything after the residual kernel
-        pmc = pmc_traffic(args)
+        pmc = pmc_traffic(args, cfg.get("equation"))
         launch_bytes = cfg["bpc"] * cells
         achieved = launch_bytes / (kms * 1e-3) / 1e9
         shape = [B, T, X] + ([Y] if Y else [])
@@ -277,26 +401,102 @@ def secondary_entry(line):
 
 
 def measure_others(dev):
-    """C1 (the reference's own CPU-sized case: launch-bound here), C2, the C4 / C5 per-GPU shards and C5 whole, one after the
-    other (each frees its tensors on return)."""
+    """C1 (the reference's own CPU-sized case: launch-bound here), C2, the C4 shard for each of its five equations
+    (`c4_shard` = induction, the script's default), the C5 shard and C5 whole, one after the other (each frees its tensors
+    on return)."""
     found = {}
-    for key, name, batch in (("c1", "c1", None), ("c2", "c2", None), ("c4_shard", "c4", None), ("c5_shard", "c5", None),
-                             ("c5_whole", "c5", 65536)):
-        cfg = CONFIGS[name]
+    jobs = [("c1", "c1", None, None), ("c2", "c2", None, None)]
+    jobs += [("c4_shard" if eq == "induction" else "c4_" + eq, "c4", None, eq)
+             for eq in ("induction", "continuity", "momentum", "energy", "gauss")]
+    jobs += [("c5_shard", "c5", None, None), ("c5_whole", "c5", 65536, None)]
+    for key, name, batch, eq in jobs:
+        cfg = mhd_config(eq) if eq else CONFIGS[name]
         shp = cfg["shape"]
         a = argparse.Namespace(config=name, mode=cfg["mode"], batch=batch or shp[0], nt=shp[1], nx=shp[2],
                                ny=shp[3] if len(shp) == 4 else 0, steps=5, warmup=2, no_prune=False, scaling="weak", slab=0,
                                slab_axis="x")
-        title = cfg["title"] if batch is None else "C5 1D Burgers residual (Joint/Burgers_Residuals_CP.py) at its single-GPU size"
-        line = run_secondary(a, dict(cfg, title=title), dev, None, 0, 1, {})
+        if batch is not None:
+            cfg = dict(cfg, title="C5 1D Burgers residual (Joint/Burgers_Residuals_CP.py) at its single-GPU size")
+        line = run_secondary(a, cfg, dev, None, 0, 1, {})
         found[key] = secondary_entry(line)
         torch.cuda.empty_cache()
     return found
 
 
-def pmc_traffic(args):
+def one_rank_group(dev):
+    """An RCCL ("nccl" on ROCm) process group of ONE rank on this GPU: what every collective of the sharded path costs when
+    nothing has to travel.  Returns (group, note); (None, reason) when the communicator cannot be created here."""
+    import socket
+    import torch.distributed as dist
+    try:
+        if not dist.is_initialized():
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        warm = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
+        return dist.group.WORLD, "RCCL, world size 1"
+    except Exception as e:                                        # never lose the contract line to a communicator problem
+        return None, f"no RCCL group on this box: {type(e).__name__}: {e}"[:200]
+
+
+def measure_strong_rank(dev, alphas, world=8):
+    """`c3_strong_rank8`: the per-rank job of the STRONG-scaled 8-GPU curve north_star's ">= 6x" speaks of - C3's 4096
+    samples split over 8 ranks = [512,64,512,512] x3 per rank, the whole grid resident (137 GB: one slab of all 510
+    interior rows, no halo re-read), joint and marginal CP through the sharded code path with a process group of one rank
+    (every collective issued, nothing on the wire).  Numerator of the projected speed-up in DESIGN.md 5; a one-GPU
+    measurement, not a multi-GPU one."""
+    from cp_pre_amd import pipeline
+    shp = CONFIGS["c3"]["shape"]
+    B, T, X, Y = shp[0] // world, shp[1], shp[2], shp[3]
+    group, note = one_rank_group(dev)
+    st = C3Stream(B, T, X, Y, X - 2, "x", dev)
+    assert st.slabs == [X - 2]
+    out = {"workload": f"C3 strong-scaled over {world} ranks: the per-rank job [{B},{T},{X},{Y}] x3, whole grid resident (one slab of "
+                       f"{X - 2} interior rows, no halo re-read), calibration through the sharded path with {note}",
+           "group": note, "steps": 5, "warmup": 2}
+    cells = B * T * (X - 2) * Y
+    for mode in ("joint", "marginal"):
+        res = st.views(mode, sharded=(mode == "marginal" and group is not None))[X - 2]
+        ev = []
+
+        def step():
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            st.eval_slab(0, X - 2, res, absolute=(mode == "marginal"))
+            e1.record()
+            if mode == "joint":
+                jc = pipeline.JointCalibration(B, dev, group=group)
+                jc.add_slab(res, crop=st.crop)
+                q = jc.finish(alphas)
+            else:
+                q = pipeline.marginal_qhat(res, alphas, group=group)
+            e2.record()
+            ev.append((e0, e1, e2))
+            return q
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ev.clear()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / 5
+        kms = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
+        cms = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev)
+        ach = 16.0 * cells / (kms * 1e-3) / 1e9
+        out[mode] = {"ms_per_step": ms, "cells_per_s_per_rank": cells / (ms * 1e-3), "kernel_ms": kms, "calibrate_ms": cms,
+                     "achieved_gbs": ach, "frac": ach / HBM_PEAK_GBS}
+    st.free()
+    return out
+
+
+def pmc_traffic(args, equation=None):
     """HBM bytes per launch of the fused residual kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN/pmc_hbm_<config>.json, written by tools/distill_profiles.py).  Counters cannot be
+    (profiles/rNN/pmc_hbm_<config>[_<equation>].json, written by tools/distill_profiles.py).  Counters cannot be
     read from inside this process; the file is used only when it was collected on this exact
     workload (latest round wins), otherwise `traffic` stays null."""
     import glob
@@ -305,7 +505,9 @@ def pmc_traffic(args):
     if args.config == "c3":
         want["slab"] = args.slab
         want["slab_axis"] = args.slab_axis
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_hbm_{args.config}.json"))):
+        want["rows"] = "interior"
+    names = [f"pmc_hbm_{args.config}_{equation}.json"] if equation else [f"pmc_hbm_{args.config}.json"]
+    for f in sorted(sum((glob.glob(os.path.join(ROOT, "profiles", "r*", n)) for n in names), [])):
         try:
             d = json.load(open(f))
         except Exception:
@@ -437,11 +639,11 @@ def main():
     par = {"parallelism": f"batch-sharded x{world} ({args.scaling} scaling: {args.batch} samples per rank)",
            "rccl_ranks": rccl_ranks}
 
-    def done():
-        if group is not None:
+    def done(code=0):
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
-        return 0
+        return code
 
     if args.plumbing_check:
         if rank == 0:
@@ -451,23 +653,20 @@ def main():
         return done()
 
     if args.config != "c3":
-        line = run_secondary(args, CONFIGS[args.config], dev, group, rank, world, par)
+        cfg = mhd_config(args.equation) if args.config == "c4" else CONFIGS[args.config]
+        line = run_secondary(args, cfg, dev, group, rank, world, par)
         if line is not None:
             print(json.dumps(line), flush=True)
         return done()
 
     from cp_pre_amd import inductive_cp as icp
     from cp_pre_amd import pipeline
-    from cp_pre_amd.residuals import NavierStokes
 
     B, T, X, Y = args.batch, args.nt, args.nx, args.ny
     xs = args.slab_axis == "x"
     # The grid does not fit the HBM next to its residual (C3: 3 x 275 GB of fields), so the job streams SLABS of it, all
-    # samples of a slab at a time (a per-cell std / quantile needs every sample of its cell).  x-slabs (default): the T
-    # axis whole - the kernel marches along it with the planes in registers - and rows [x0, x1) of the grid with one halo
-    # ROW per side (PRE_FLAG_HALO_X): 2 rows re-read per 128.  t-slabs (rounds 1-3): planes [t0, t1) with one halo
-    # PLANE per side: 2 planes re-read per 16, 12 % more input traffic.
-    n_axis, other = (X, T * Y) if xs else (T, X * Y)
+    # samples of a slab at a time (a per-cell std / quantile needs every sample of its cell): see C3Stream.
+    n_axis, other = (X - 2, T * Y) if xs else (T, X * Y)
     free = torch.cuda.mem_get_info(dev)[0]
     if not args.slab:
         # fewer, thicker slabs re-read fewer halo rows / planes; the resident set must fit the free HBM (t-slabs of 16
@@ -478,7 +677,7 @@ def main():
         per_plane = (X * Y if not xs else (n_axis // 4 + 2) * Y)
         extra = 4 * world * B * per_plane if (args.mode == "marginal" and world > 1) else 0
         extra += (1 << 30) if group is not None else 0                 # headroom for RCCL's own scratch beyond the warm-up collective
-        if xs:      # halves of the axis (whole 8-row tiles for a power-of-two grid), down to 16 rows
+        if xs:      # the interior rows in 1, 2, 4, ... runs (510 rows: 510, 255, 128, 64, ...), down to 16 rows
             div = [-(-n_axis // d) for d in (1, 2, 4, 8, 16, 32, 64) if -(-n_axis // d) >= 16] or [n_axis]
         else:
             div = [n_axis, (n_axis + 1) // 2, (n_axis + 2) // 3, (n_axis + 3) // 4, 16, 13, 8]
@@ -492,17 +691,9 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
             idx = int(t.item())
         args.slab = cands[idx]
-    slabs = split_slabs(n_axis, args.slab)                    # rows (x) / interior planes (t) per slab position
-    n_slabs, S = len(slabs), max(slabs)
     alphas = [float(a) for a in icp.ALPHA_LEVELS]
-    dt, dx, dy = 1e-2, 1.0 / X, 1.0 / Y
-    ns = NavierStokes(dt, dx, dy, nu=1e-3)
 
-    # resident synthetic slab: vars[:, i] views of one [B,3,S+2,X,Y] (t-slabs) or [B,3,T,S+2,Y] (x-slabs) tensor, like
-    # the reference's `vars`
     torch.manual_seed(1234 + rank)
-    # n_slabs - 1 extra samples: slab position s reads the batch window [s, s + B), so no two slab passes of a
-    # step see the same input (and no layer of the memory system could serve one from another)
     need = resident_bytes(B, n_axis, args.slab, other)
     short = need > free - (2 << 30)
     if short:
@@ -513,42 +704,15 @@ def main():
         short = bool(t.item())
     if short:
         return 2
-    vars_ = torch.empty((B + n_slabs - 1, 3, T, S + 2, Y) if xs else (B + n_slabs - 1, 3, S + 2, X, Y),
-                        dtype=torch.float32, device=dev)
-    for i in range(3):
-        synth_(vars_[:, i], 100 * rank + 20 + i)
-    # residual buffer: the slab's OWN rows / planes only (its first and last row / plane are halo: read by the kernel,
-    # neither computed nor stored - PRE_FLAG_HALO_X / PRE_FLAG_OUT_INTERIOR_T)
-    def rshape(sl):
-        return (B, T, sl, Y) if xs else (B, sl, X, Y)
-    plane = lambda sl: (sl * Y) if xs else (X * Y)           # cells of one time plane of the residual
-    res_buf = torch.empty(B * (other * S + 64 * (T if xs else S)), dtype=torch.float32, device=dev)      # (room for either padded layout)
-
-    def views(mode):
-        """The residual buffer as each slab thickness sees it."""
-        if mode == "marginal" and group is not None:
-            # time-major [planes][B][plane] seen as [B,planes,..]: plane t of all local samples is one contiguous block, the
-            # send block of the all-to-all that hands plane t to rank t % world (pipeline.marginal_qhat: no pack copy)
-            # (samples of a plane 64 floats further apart than a plane is long: profiles/r03/row_pitch.txt)
-            return {sl: res_buf.as_strided(rshape(sl), (plane(sl) + 64, B * (plane(sl) + 64), Y, 1)) for sl in set(slabs)}
-        if mode == "marginal":
-            # rows 64 floats further apart than they are long: a power-of-two distance between the rows of a cell's column
-            # (2^22 cells) costs the per-cell select ~10 % (pipeline.row_padded, profiles/r03/row_pitch.txt)
-            return {sl: res_buf.as_strided(rshape(sl), (rshape(sl)[1] * plane(sl) + 64, plane(sl), Y, 1)) for sl in set(slabs)}
-        return {sl: res_buf[:B * rshape(sl)[1] * plane(sl)].view(rshape(sl)) for sl in set(slabs)}
-    res_of = views(args.mode)
-    # cells within `crop` of the slab's rim are excluded from the scores: the y rim always; x-slabs: the t rim (the
-    # grid's own: every plane is computed, zero padding beyond, as the reference's conv3d has it), no rows (all own);
-    # t-slabs: the x rim, no planes (all interior)
-    # (x-slabs score all their rows: the grid's rows 0 and X-1, which the reference's [...,1:-1,...] drops, stay in - a
-    # 2/X superset that costs the same; tests/test_gpu_parity.py::test_x_slab_stream_equals_whole_grid_calibration
-    # streams the cropped form)
-    crop = (1, 0, 1) if xs else (0, 1, 1)
+    st = C3Stream(B, T, X, Y, args.slab, args.slab_axis, dev, rank=rank)
+    slabs, n_slabs, S, crop = st.slabs, len(st.slabs), st.S, st.crop
 
     ev_used = []
     last_jc = [None]
 
-    def step(k, prune=not args.no_prune, mode=args.mode, res_of=res_of):
+    def step(k, res_of, prune=not args.no_prune, mode=args.mode):
+        """One whole job: every slab position evaluated into its view of the residual buffer (`res_of`: passed by every
+        caller, never captured - the buffer must be freeable) and calibrated."""
         jc = pipeline.JointCalibration(B, dev, group=group, prune=prune) if mode == "joint" else None
         last_jc[0] = jc
         q = None
@@ -556,12 +720,7 @@ def main():
             res = res_of[sl]
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record()
-            if xs:
-                ns.residual_momentum(vars_[s:s + B, :, :, 1:sl + 1], boundary=True, absolute=(mode == "marginal"), out=res,
-                                     halo_x=True)
-            else:
-                ns.residual_momentum(vars_[s:s + B, :, :sl + 2], boundary=True, absolute=(mode == "marginal"), out=res,
-                                     skip_t_rim=True)
+            st.eval_slab(s, sl, res, absolute=(mode == "marginal"))
             e1.record()
             if jc is not None:
                 jc.add_slab(res, crop=crop)
@@ -577,12 +736,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    res_main = st.views(args.mode, sharded=group is not None)
     for k in range(args.warmup):
-        step(k)
+        step(k, res_main)
     sync()
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
-        qhat = step(k)
+        qhat = step(k, res_main)
     sync()
     elapsed = time.perf_counter() - t0
     if group is not None:
@@ -590,19 +750,19 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    cells_per_step = B * sum(slabs) * other * world                   # whole job, all ranks
+    cells_per_step = B * sum(slabs) * other * world                   # the cells the launches compute, all ranks
     value = cells_per_step * args.steps / elapsed
 
     # The branch-and-bound score pass makes `value` depend on the data (how much of the residual the bounds let it
     # skip).  Say by how much: the share of the pass that was read, and the same step with the full pass - one more
     # step, timed apart, not part of `value`.
-    read_frac = ms_full = None
+    read_frac = ms_full = qhat_full = None
     if args.mode == "joint" and not args.no_prune:
         read_frac = last_jc[0].score_pass_read_frac()
-        step(args.warmup + args.steps, prune=False)                   # (untimed: first use of the full-pass kernels)
+        step(args.warmup + args.steps, res_main, prune=False)         # (untimed: first use of the full-pass kernels)
         sync()
         t1 = time.perf_counter()
-        step(args.warmup + args.steps + 1, prune=False)
+        qhat_full = step(args.warmup + args.steps + 1, res_main, prune=False)
         sync()
         ms_full = 1e3 * (time.perf_counter() - t1)
         if group is not None:
@@ -610,11 +770,12 @@ def main():
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             ms_full = float(tt.item())
 
+    code = 0
     if rank == 0:
         timed = [(sl, e0.elapsed_time(e1)) for (k, sl, e0, e1, _) in ev_used if args.warmup <= k < args.warmup + args.steps]     # ms, this rank
         kms = sum(d for _, d in timed) / len(timed)
-        # 3 fields read + 1 residual written = 16 B per cell the launch COMPUTES (its interior
-        # planes); the two halo planes each slab re-reads are overhead, reported apart
+        # 3 fields read + 1 residual written = 16 B per cell the launch COMPUTES (its own rows / interior
+        # planes); the two halo rows / planes each slab re-reads are overhead, reported apart
         launch_bytes = sum(16 * B * sl * other for sl, _ in timed) / len(timed)
         halo_bytes = sum((12 * (sl + 2) + 4 * sl) * B * other for sl, _ in timed) / len(timed)
         achieved = launch_bytes / (kms * 1e-3) / 1e9
@@ -627,11 +788,13 @@ def main():
             "data": SYNTH + f"; one resident {'x' if xs else 't'}-slab, slab position s reads the batch window [s, s+B) of it",
             "config": {"workload": f"C3 2D Navier-Stokes momentum residual [{B},{args.nt},{X},{Y}] x3 fields per rank, "
                                    f"{args.mode} CP, 10 alpha levels; streamed as " +
-                                   (f"{n_slabs} x-slabs of {slabs} rows (+2 halo rows each; all {X} rows scored), T whole" if xs else
-                                    f"{n_slabs} t-slabs of {slabs} interior planes (+2 halo planes each)"),
+                                   (f"{n_slabs} x-slabs of {slabs} rows = the reference's interior rows 1..{X - 2} "
+                                    f"(Marginal/NS_Residuals_CP.py:240 crops rows 0 and {X - 1}: not computed), +2 halo rows each, T whole"
+                                    if xs else f"{n_slabs} t-slabs of {slabs} interior planes (+2 halo planes each)"),
                        "mode": args.mode, "batch_per_rank": B, "slab_axis": args.slab_axis, "slab": args.slab, **par,
-                       # the per-rank slab plan: resident bytes, and what the t-slab halo re-reads cost (strong scaling
-                       # shrinks the per-rank batch, which affords thicker slabs - up to the whole T axis, no halo)
+                       "cells_per_step": cells_per_step, "uncropped_grid_cells": B * T * X * Y * world,
+                       # the per-rank slab plan: resident bytes, and what the slab halo re-reads cost (strong scaling
+                       # shrinks the per-rank batch, which affords thicker slabs - up to the whole axis, no halo)
                        "slab_plan": {"axis": args.slab_axis, "slabs": slabs,
                                      "resident_gb": round(resident_bytes(B, n_axis, args.slab, other) / 1e9, 1),
                                      "input_read_per_cell_computed": round(sum(sl + 2 for sl in slabs) / sum(slabs), 4)},
@@ -643,7 +806,7 @@ def main():
                        "inputs": "resident in HBM", "host_fed_bound_cells_per_s": 63e9 / 12.0,
                        **({"score_pass": "branch-and-bound (same scores as the full pass for the same modulation; adaptive: "
                                          "flagged samples and wasteful streams take the full pass)"
-                           if not args.no_prune and pipeline.HipOps.can_prune(res_of[slabs[0]], crop) else "full"}
+                           if not args.no_prune and pipeline.HipOps.can_prune(res_main[slabs[0]], crop) else "full"}
                           if args.mode == "joint" else {})},
             # data dependence of `value`: share of the score pass's segments that were read (the synthetic residuals are
             # noise-like: tight bounds), and the same step with the full score pass (--no-prune)
@@ -660,18 +823,40 @@ def main():
         if args.mode == "marginal":
             sel = [e1.elapsed_time(e2) for (k, sl, _, e1, e2) in ev_used if args.warmup <= k < args.warmup + args.steps]
             out["select_ms_per_slab"] = sum(sel) / len(sel)
-            out["select_one_read_gbs"] = 4.0 * B * S * other / (out["select_ms_per_slab"] * 1e-3) / 1e9
+            out["select_one_read_gbs"] = 4.0 * B * sum(slabs) / n_slabs * other / (out["select_ms_per_slab"] * 1e-3) / 1e9
+        if not args.no_parity:
+            # CHECKER (outside every timed region): what the last slab pass left in the residual buffer against the CPU
+            # oracle on two samples (first and last of the batch window), and the pruned q-hats against the full pass's
+            s_last, sl_last = n_slabs - 1, slabs[-1]
+            res_last = res_main[sl_last]
+            if args.mode == "marginal":                                  # |res| is in the buffer: re-evaluate signed
+                st.eval_slab(s_last, sl_last, res_last, absolute=False)
+                torch.cuda.synchronize()
+            err = c3_parity(st, res_last, s_last, sl_last, (0, B - 1))
+            out["parity"] = {"residual_rel_err": err, "tol": RES_TOL, "samples": 2, "slab": [s_last, sl_last],
+                             "oracle": "oracle/residuals.py::ns_momentum (F.conv3d per operator, Marginal/NS_Residuals_CP.py:231-240) "
+                                       "on the same rows with their halo rows, host"}
+            if qhat_full is not None:
+                rel = float(((qhat - qhat_full).abs() / qhat_full.abs()).max())
+                out["parity"]["qhat_pruned_vs_full_pass_rel"] = rel
+                out["parity"]["qhat_tol"] = 1e-6
+                if not rel <= 1e-6:
+                    code = 3
+            if not err <= RES_TOL:
+                code = 3
+            del res_last                                                 # (a view: it would keep the 69 GB buffer alive)
         if world == 1 and args.mode == "joint" and group is None and not args.no_secondary and not args.no_prune:
             # every other BASELINE config under the same clock: C3 marginal on the slab that is already resident, then
-            # (C3's buffers freed) C2, the C4 / C5 shards and C5 whole.  Not part of `value`.
+            # (C3's buffers freed) the strong-scaled per-rank job, C1, C2, C4 x5, the C5 shard and C5 whole.  Not part
+            # of `value`.
             sec = {}
-            mres, k0, n2 = views("marginal"), args.warmup + args.steps + 2, 2 + 5
+            mres, k0, n2 = st.views("marginal"), args.warmup + args.steps + 2, 2 + 5
             for k in range(k0, k0 + 2):
-                step(k, mode="marginal", res_of=mres)
+                step(k, mres, mode="marginal")
             sync()
             t2 = time.perf_counter()
             for k in range(k0 + 2, k0 + n2):
-                step(k, mode="marginal", res_of=mres)
+                step(k, mres, mode="marginal")
             sync()
             ms = 1e3 * (time.perf_counter() - t2) / 5
             mt = [(sl, e0.elapsed_time(e1), e1.elapsed_time(e2)) for (k, sl, e0, e1, e2) in ev_used if k >= k0 + 2]
@@ -683,18 +868,29 @@ def main():
                 "ms_per_step": ms, "cells_per_s": cells_per_step / (ms * 1e-3), "steps": 5, "warmup": 2,
                 "kernel": "march_kernel<NSMomentum<0>,8,64>", "kernel_ms": kms_m, "achieved_gbs": ach, "frac": ach / HBM_PEAK_GBS,
                 "traffic": None, "select_ms_per_slab": sel_m,
-                "select_one_read_gbs": 4.0 * B * S * other / (sel_m * 1e-3) / 1e9}
-            del vars_, res_buf, res_of, mres
-            torch.cuda.empty_cache()
+                "select_one_read_gbs": 4.0 * B * sum(slabs) / n_slabs * other / (sel_m * 1e-3) / 1e9}
+            del mres
+        del res_main
+        ev_used.clear()
+        last_jc[0] = None
+        st.free()
+        held = torch.cuda.memory_allocated(dev)                   # C3's 278 GB must be gone before anything else is allocated
+        if world == 1 and args.mode == "joint" and group is None and not args.no_secondary and not args.no_prune:
+            if held >= (8 << 30):
+                sec["error"] = f"C3's buffers were not released ({held / 1e9:.1f} GB still allocated): the other configs were not measured"
+                out["secondary"] = sec
+        if world == 1 and args.mode == "joint" and group is None and not args.no_secondary and not args.no_prune and held < (8 << 30):
+            try:
+                sec["c3_strong_rank8"] = measure_strong_rank(dev, alphas)
+            except Exception as e:                                # (a secondary must never cost the contract line)
+                sec["c3_strong_rank8"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                torch.cuda.empty_cache()
             sec.update(measure_others(dev))
             out["secondary"] = sec
-            vars_ = res_buf = res_of = None
         if world == 1 and not args.no_cpu_baseline:
-            del vars_, res_buf, res_of
-            torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args, alphas, S, xs)
         print(json.dumps(out), flush=True)
-    return done()
+    return done(code)
 
 
 if __name__ == "__main__":

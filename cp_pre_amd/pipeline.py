@@ -30,8 +30,6 @@ from . import inductive_cp as icp
 class HipOps:
     """Device back end: every method is one or two ``libcp_pre_hip.so`` launches."""
 
-    interior_t = True      # can reduce only the interior t planes of an uncropped [n,T,X,Y] slab in place
-
     @staticmethod
     def zeros_moments(M, device):
         return torch.zeros(2, M, dtype=torch.float64, device=device)

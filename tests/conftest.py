@@ -19,13 +19,18 @@ def pytest_configure(config):
     stale = not all(os.path.exists(f) for f in libs + [os.path.join(ROOT, "oracle", "liboracle.so")])
     if not stale:
         # ... or holds a library of another ABI version (a tree that was built before the header changed): rebuild rather than
-        # fail every test on the binding's load-time check
-        import ctypes
+        # fail every test on the binding's load-time check.  The candidate is probed in a CHILD process: a library this
+        # process had dlopen'ed stays mapped (ctypes never dlcloses; glibc hands the stale mapping back for the same path),
+        # so a rebuild could not be seen here afterwards - and a linker rewriting a mapped file can SIGBUS the process.
         import re
+        import subprocess
         want = int(re.search(r"#define\s+PRE_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "cp_pre_hip.h")).read()).group(1))
+        probe = ("import sys, ctypes\n"
+                 "import torch  # the library binds to the HIP runtime torch loads\n"
+                 "print(ctypes.CDLL(sys.argv[1]).pre_abi_version())")
         try:
-            import torch  # noqa: F401  (the library binds to the HIP runtime torch loads)
-            have = ctypes.CDLL(libs[0]).pre_abi_version()
+            r = subprocess.run([sys.executable, "-c", probe, libs[0]], capture_output=True, text=True, timeout=300)
+            have = int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else -1
         except Exception:
             have = -1
         stale = have != want

@@ -71,7 +71,6 @@ class PruneOps(CpuOps):
     ``max_scores_pruned`` / ``interior_planes``): the same layout rules (taken from ``HipOps`` itself - they are pure
     functions of shape, strides and crop) and the same interior-plane moments, with torch-CPU arithmetic.  "How much the
     bounds saved" is scripted: a sample with an entry above 1e3 counts as read whole, the others as 1 % read."""
-    interior_t = True
     dense_order = staticmethod(pipeline.HipOps.dense_order)
     interior_planes = staticmethod(pipeline.HipOps.interior_planes)
     routes = []

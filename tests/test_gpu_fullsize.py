@@ -1,6 +1,9 @@
-"""BASELINE.json configurations at their FULL per-GPU sizes (far beyond what the CPU oracle can check in a test):
-size-independent properties of the hot path, through the same classes bench.py drives.
+"""BASELINE.json configurations at their FULL per-GPU sizes, through the same classes bench.py drives: a few samples of
+every residual against the CPU oracle (oracle/residuals.py = the reference's F.conv3d / F.conv2d arithmetic; whole tensors
+are beyond what it can check in a test, two or three samples take seconds) + size-independent properties of the rest.
 
+  C1 whole [256,100,200]                 advection additive kernel (Marginal/Advection_Residuals_CP.py:156-164,234-237): ALL of it vs the oracle
+  C3 x-slab [4096,64,128+2,512] x3       THE BENCHMARKED JOB, call for call (bench.C3Stream): NS momentum, joint + marginal CP
   C3 slab  [4096,10,512,512] x3 fields   NS momentum residual (Marginal/NS_Residuals_CP.py:231-240), joint + marginal CP
   C4 shard [1024,64,256,256] x6 fields   MHD induction residual (Marginal/MHD_Residuals_CP.py:259-268), joint CP
   C5 shard [8192,200,512]                Burgers residual (Joint/Burgers_Residuals_CP.py:182-187), joint + marginal CP
@@ -14,7 +17,11 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import rel_err
+
 pytestmark = pytest.mark.gpu
+
+RES_TOL = 1e-5          # north_star: residuals within 1e-5 rel fp32 (tensor-scale) of the reference arithmetic
 
 
 @pytest.fixture(scope="module")
@@ -55,6 +62,98 @@ def _check_joint(icp, pipeline, res, crop, n, gpu):
     return q, mod, sc
 
 
+
+def _oracle_err(got, ref):
+    return rel_err(got.detach().cpu().numpy(), ref.detach().cpu().numpy())
+
+
+def test_full_size_c1_vs_oracle(gpu):
+    """BASELINE config 1 WHOLE ([256,100,200], the reference's own CPU-sized case) against the oracle end to end:
+    Marginal/Advection_Residuals_CP.py:156-164 (additive kernel D_t + (v disc dt/dx) D_x), :234-235 (residual, cropped),
+    :237 ff. (|res| -> per-cell q-hat at the 10 alpha levels over the 256 samples)."""
+    import bench
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd.residuals import Advection
+    from oracle import conformal as oc
+    from oracle import residuals as orr
+    B, T, X = 256, 100, 200
+    u = bench.synth_(torch.empty(B, T, X, device=gpu), 1) + 1.0                 # bench.py's C1 input
+    adv = Advection(1.0, 0.005, 0.01, disc=2)
+    res = adv.residual(u)                                                       # the reference's crop: [256,98,198]
+    ref = orr.advection_residual(u.cpu(), 1.0, 2, 0.005, 0.01)
+    assert res.shape == ref.shape == (B, T - 2, X - 2)
+    assert _oracle_err(res, ref) <= RES_TOL
+    full = adv.residual(u, boundary=True, absolute=True)
+    assert _oracle_err(full, orr.advection_residual(u.cpu(), 1.0, 2, 0.005, 0.01, boundary=True).abs()) <= RES_TOL
+    scores = res.abs().contiguous()
+    sc_host = scores.cpu().numpy()
+    alphas = _alphas()
+    q = icp.calibrate_multi(scores, B, alphas).cpu().numpy()                    # ONE select for the ten levels
+    for j, a in enumerate(alphas):
+        # the device select against the oracle's calibrate on the SAME scores: bit for bit
+        assert np.array_equal(q[j], oc.calibrate(sc_host, B, a)), a
+        assert np.array_equal(icp.calibrate(scores, B, a).cpu().numpy(), q[j])  # the reference's one-level call
+    # and end to end (oracle residual -> oracle scores -> oracle q-hat): the residuals differ in their last bits, so do
+    # the order statistics picked from them
+    q_ref = np.stack([oc.calibrate(np.abs(ref.numpy()), B, a) for a in alphas])
+    assert rel_err(q, q_ref) <= RES_TOL
+
+
+@pytest.mark.timeout(900)
+def test_full_size_c3_xslab(gpu):
+    """THE JOB THE HEADLINE IS MEASURED ON, call for call: bench.C3Stream builds what `python bench.py` times - the
+    resident synthetic x-slab [4096+3,3,64,128+2,512], the residual buffer in its joint and its row-padded marginal
+    layout - and `eval_slab` is the timed launch: `residual_momentum(vars_[s:s+4096,:,:,1:sl+1], boundary=True, out=res,
+    halo_x=True)`.  Reference job: Marginal/NS_Residuals_CP.py:231-240 (residual), :282-289 (|res| -> calibrate).
+      (i)   samples {0, 2047, 4095} of the first and of the last slab position against the CPU oracle on the same rows
+            with their halo rows (<= 1e-5);
+      (ii)  the streaming joint calibration of the slab, branch-and-bound == full pass, and the whole four-slab stream;
+      (iii) the marginal q-hat through the row-padded view on three cells against torch.sort, bit for bit, and the
+            |.| epilogue against the oracle."""
+    import bench
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    from oracle import residuals as orr
+    torch.cuda.empty_cache()
+    B, T, X, Y = bench.CONFIGS["c3"]["shape"]
+    alphas = _alphas()
+    st = bench.C3Stream(B, T, X, Y, 128, "x", gpu)
+    assert st.slabs == [128, 128, 127, 127] and sum(st.slabs) == X - 2 and st.crop == (1, 0, 1)
+    assert tuple(st.vars_.shape) == (B + 3, 3, T, 130, Y)
+    res_of = st.views("joint")
+    for s in (0, 3):
+        sl = st.slabs[s]
+        res = st.eval_slab(s, sl, res_of[sl])
+        assert res.data_ptr() == st.res_buf.data_ptr() and tuple(res.shape) == (B, T, sl, Y) and res.is_contiguous()
+        assert bench.c3_parity(st, res, s, sl, (0, 2047, B - 1)) <= RES_TOL                     # (i)
+    # (ii) the last slab's calibration: pruned == full pass, q-hat an input value, the conformal guarantee
+    _check_joint(icp, pipeline, res, st.crop, B, gpu)
+    # ... and the stream as bench.py's step runs it (adaptive route over the four slab positions) against the full passes
+    qs = []
+    for prune in (True, False):
+        jc = pipeline.JointCalibration(B, gpu, prune=prune)
+        for s, sl in enumerate(st.slabs):
+            jc.add_slab(st.eval_slab(s, sl, res_of[sl]), crop=st.crop)
+        qs.append((jc.finish(alphas), jc.all_scores))
+    assert torch.allclose(qs[0][0], qs[1][0], rtol=1e-6, atol=0.0) and torch.allclose(qs[0][1], qs[1][1], rtol=1e-6, atol=0.0)
+    assert torch.isfinite(qs[0][0]).all() and (qs[0][0][:-1] >= qs[0][0][1:]).all()
+    # (iii) marginal CP on the last slab position: |.| epilogue into the row-padded view, per-cell q-hat
+    del res, res_of
+    s, sl = 3, st.slabs[3]
+    a = st.eval_slab(s, sl, st.views("marginal")[sl], absolute=True)
+    assert a.stride(0) == T * sl * Y + 64 and not a.is_contiguous()
+    v = st.oracle_inputs(s, sl, B - 1)
+    ref = st.oracle_crop(orr.ns_momentum(v, st.dt, st.dx, st.dy, nu=st.nu, boundary=True))[0].abs()
+    assert _oracle_err(a[B - 1], ref) <= RES_TOL
+    q = pipeline.marginal_qhat(a, alphas)
+    assert q.shape == (len(alphas), T, sl, Y) and (q[:-1] >= q[1:]).all()
+    ks = [icp.kth_index(B, B, al) for al in alphas]
+    for (t, x, y) in ((0, 0, 0), (31, 64, 257), (T - 1, sl - 1, Y - 1)):
+        col = torch.sort(a[:, t, x, y].contiguous()).values
+        assert torch.equal(q[:, t, x, y], col[ks])
+    st.free()
+
+
 @pytest.mark.timeout(300)
 def test_full_size_c3_slab(gpu):
     from cp_pre_amd import inductive_cp as icp
@@ -68,11 +167,12 @@ def test_full_size_c3_slab(gpu):
     ns = NavierStokes(1e-2, 1.0 / X, 1.0 / Y, nu=1e-3)
     full = ns.residual_momentum(v, boundary=True)
     assert full.shape == (B, T, X, Y) and torch.isfinite(full[::512]).all()
-    # the tail of the batch alone (offsets beyond 2^31 elements: B*3*T*X*Y = 3.2e10)
-    tail = ns.residual_momentum(v[-3:].clone(), boundary=True)
+    # the middle and the tail of the batch (offsets beyond 2^31 elements: B*3*T*X*Y = 3.2e10) against the CPU oracle
+    from oracle import residuals as orr
+    for b0 in (2047, B - 1):
+        assert _oracle_err(full[b0], orr.ns_momentum(v[b0:b0 + 1].cpu(), 1e-2, 1.0 / X, 1.0 / Y, nu=1e-3, boundary=True)[0]) <= RES_TOL
+    tail = ns.residual_momentum(v[-3:].clone(), boundary=True)          # (and alone: grid decomposition, 64-bit indexing)
     assert torch.equal(full[-3:], tail)
-    mid = ns.residual_momentum(v[2047:2049].clone(), boundary=True)
-    assert torch.equal(full[2047:2049], mid)
     # interior-plane fast paths == full path
     inner = torch.empty(B, T - 2, X, Y, device=gpu)
     got = ns.residual_momentum(v, boundary=True, out=inner, skip_t_rim=True)
@@ -117,8 +217,10 @@ def test_full_size_c4_shard(gpu):
     mhd = MHD()
     res = mhd.residual_induction(v, boundary=True)
     assert res.shape == (B, T, X, Y) and torch.isfinite(res[::128]).all()
+    from oracle import residuals as orr
+    for b0 in (511, B - 1):                                                 # two samples against the CPU oracle
+        assert _oracle_err(res[b0], orr.mhd_induction(v[b0:b0 + 1].cpu(), boundary=True)[0]) <= RES_TOL
     assert torch.equal(res[-2:], mhd.residual_induction(v[-2:].clone(), boundary=True))
-    assert torch.equal(res[511:513], mhd.residual_induction(v[511:513].clone(), boundary=True))
     a = mhd.residual_induction(v, boundary=True, absolute=True)
     assert torch.equal(a, res.abs())
     crop_view = mhd.residual_induction(v[:4])                               # boundary=False: the reference's crop
@@ -146,6 +248,9 @@ def test_full_size_c5_shard(gpu):
     bur = Burgers(2.0 / X, 1.25 / T, 0.002)
     res = bur.residual(u, boundary=True)
     assert res.shape == (B, T, X) and torch.isfinite(res).all()
+    from oracle import residuals as orr
+    for b0 in (0, B - 1):                                                   # two samples against the CPU oracle
+        assert _oracle_err(res[b0], orr.burgers_residual(u[b0:b0 + 1].cpu(), 2.0 / X, 1.25 / T, 0.002, boundary=True)[0]) <= RES_TOL
     assert torch.equal(res[-3:], bur.residual(u[-3:].clone(), boundary=True))
     assert torch.equal(bur.residual(u[:5]), res[:5, 1:-1, 1:-1])
     a = bur.residual(u, boundary=True, absolute=True)
@@ -179,7 +284,10 @@ def test_full_size_c5_whole(gpu):
     bur = Burgers(2.0 / X, 1.25 / T, 0.002)
     res = bur.residual(u, boundary=True)
     assert res.shape == (B, T, X) and torch.isfinite(res[::4096]).all()
-    for b0 in (0, 32767, B - 3):                                            # (byte offsets 0, 13.4e9, 26.8e9)
+    from oracle import residuals as orr
+    for b0 in (32767, B - 1):                                               # (byte offsets 13.4e9, 26.8e9) vs the CPU oracle
+        assert _oracle_err(res[b0], orr.burgers_residual(u[b0:b0 + 1].cpu(), 2.0 / X, 1.25 / T, 0.002, boundary=True)[0]) <= RES_TOL
+    for b0 in (0, B - 3):
         assert torch.equal(res[b0:b0 + 3], bur.residual(u[b0:b0 + 3].clone(), boundary=True))
     assert torch.equal(bur.residual(u[-5:]), res[-5:, 1:-1, 1:-1])
     a = bur.residual(u, boundary=True, absolute=True)

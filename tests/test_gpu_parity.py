@@ -1610,11 +1610,12 @@ def test_interior_t_fast_path_equals_full_path(gpu):
     a.add_slab(fast, crop=(1, 1, 1))                                                # interior-only moments
     qa = a.finish(alphas)
 
-    class FullOps(pipeline.HipOps):
-        interior_t = False
+    class FullOps(pipeline.HipOps):        # the full-slab route: every plane reduced (all 10 are valid in `full`), crop in the score
+        interior_planes = staticmethod(lambda res, crop: 0)
     b = pipeline.JointCalibration(30, gpu, ops=FullOps)
     b.add_slab(full, crop=(1, 1, 1))
     qb = b.finish(alphas)
+    assert not torch.isnan(b.modulation[0][0]).any()                                # (the rim planes WERE reduced here)
     assert torch.equal(qa, qb)
     assert torch.equal(a.modulation[0][1:-1], b.modulation[0][1:-1]) and torch.isnan(a.modulation[0][0]).all()
 
@@ -1851,12 +1852,14 @@ def test_spectral_native_route_equals_torch_fft_composition(gpu):
 
 
 def test_full_size_properties_c2(gpu):
-    """BASELINE config 2 at its full size [512,32,256,256] (too big for the CPU oracle in a test):
+    """BASELINE config 2 at its full size [512,32,256,256]: two samples against the CPU oracle
+    (Marginal/Wave_Residuals_CP.py:170-184; the whole tensor is beyond it in a test) and
     size-independent properties - linearity of the additive wave kernel, |.| idempotence, per-cell
     q-hat non-increasing in alpha and an input value, conformal guarantee on the calibration set
     (at least ceil((n+1)(1-alpha)) of n calibration scores lie within q-hat) for marginal and joint CP."""
     from cp_pre_amd import inductive_cp as icp
     from cp_pre_amd.residuals import PRE_Wave
+    from oracle import residuals as orr
     B, T, X, Y = 512, 32, 256, 256
     g = torch.Generator(device=gpu).manual_seed(3)
     u1 = torch.randn(B, T, X, Y, device=gpu, generator=g)
@@ -1867,6 +1870,9 @@ def test_full_size_properties_c2(gpu):
     assert (lin - (0.75 * r1 - 1.25 * r2)).abs().max().item() <= 1e-5 * lin.abs().max().item()
     a1 = w.residual(u1, boundary=True, absolute=True)
     assert torch.equal(a1, r1.abs()) and torch.equal(a1.abs(), a1)
+    for b0 in (0, B - 1):                                                   # two samples against the CPU oracle
+        ref = orr.wave_residual(u1[b0:b0 + 1].cpu(), 1.0, 0.005, 0.01, boundary=True)[0]
+        assert rel_err(r1[b0].cpu().numpy(), ref.numpy()) <= RES_TOL
     del u2, r2, lin
     n = B
     alphas = [float(a) for a in icp.ALPHA_LEVELS]
