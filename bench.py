@@ -60,6 +60,31 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The driver reads ONE JSON line from stdout.  RCCL prints a five-line version banner to stdout when its communicator is
+# created (a run of round 5 came back with the banner in front of the line, and one - without `python -u` - with an empty
+# stdout and rc 0), so a process that computes keeps a private duplicate of stdout for the line and points fd 1 at stderr
+# for everything else, libraries included (`claim_stdout`, called once the launcher logic has decided that this process
+# is a rank and not the spawner of the ranks, whose children must inherit the real stdout).
+_LINE_FD = None
+
+
+def claim_stdout():
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    fd = _LINE_FD if _LINE_FD is not None else 1
+    try:
+        sys.stdout.flush()
+    except Exception:
+        pass
+    while line:
+        line = line[os.write(fd, line):]
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 RES_TOL = 1e-5                 # north_star: residuals within 1e-5 rel fp32 of the reference ConvOperator arithmetic
@@ -154,6 +179,12 @@ def launch_plan(gpus, environ, argv, script=None):
     if int(ws) != gpus:
         return "error", f"bench.py: WORLD_SIZE={ws} but --gpus {gpus}: launch with --nproc-per-node {gpus} (or pass --gpus {ws})"
     return "run", int(ws)
+
+
+def note(msg):
+    """Progress on stderr (rank 0's stdout carries the ONE JSON line and nothing else)."""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def resident_bytes(B, n, slab, other):
@@ -410,6 +441,7 @@ def measure_others(dev):
              for eq in ("induction", "continuity", "momentum", "energy", "gauss")]
     jobs += [("c5_shard", "c5", None, None), ("c5_whole", "c5", 65536, None)]
     for key, name, batch, eq in jobs:
+        note(f"secondary {key}")
         cfg = mhd_config(eq) if eq else CONFIGS[name]
         shp = cfg["shape"]
         a = argparse.Namespace(config=name, mode=cfg["mode"], batch=batch or shp[0], nt=shp[1], nx=shp[2],
@@ -451,12 +483,13 @@ def measure_strong_rank(dev, alphas, world=8):
     from cp_pre_amd import pipeline
     shp = CONFIGS["c3"]["shape"]
     B, T, X, Y = shp[0] // world, shp[1], shp[2], shp[3]
-    group, note = one_rank_group(dev)
+    group, how = one_rank_group(dev)
+    note(f"secondary c3_strong_rank8 ({how})")
     st = C3Stream(B, T, X, Y, X - 2, "x", dev)
     assert st.slabs == [X - 2]
     out = {"workload": f"C3 strong-scaled over {world} ranks: the per-rank job [{B},{T},{X},{Y}] x3, whole grid resident (one slab of "
-                       f"{X - 2} interior rows, no halo re-read), calibration through the sharded path with {note}",
-           "group": note, "steps": 5, "warmup": 2}
+                       f"{X - 2} interior rows, no halo re-read), calibration through the sharded path with {how}",
+           "group": how, "steps": 5, "warmup": 2}
     cells = B * T * (X - 2) * Y
     for mode in ("joint", "marginal"):
         res = st.views(mode, sharded=(mode == "marginal" and group is not None))[X - 2]
@@ -629,6 +662,7 @@ def main():
         env.setdefault("OMP_NUM_THREADS", "4")
         return subprocess.run(what, env=env).returncode
     world = what
+    claim_stdout()
     if args.scaling == "strong":
         if args.batch % world:
             print(f"bench.py: --scaling strong needs --batch ({args.batch}) divisible by the rank count ({world})",
@@ -647,16 +681,15 @@ def main():
 
     if args.plumbing_check:
         if rank == 0:
-            print(json.dumps({"plumbing_check": True, "n_gpus": world, "rccl_ranks": rccl_ranks, "scaling": args.scaling,
-                              "batch_per_rank": args.batch, "backend": torch.distributed.get_backend() if group else None}),
-                  flush=True)
+            emit({"plumbing_check": True, "n_gpus": world, "rccl_ranks": rccl_ranks, "scaling": args.scaling,
+                  "batch_per_rank": args.batch, "backend": torch.distributed.get_backend() if group else None})
         return done()
 
     if args.config != "c3":
         cfg = mhd_config(args.equation) if args.config == "c4" else CONFIGS[args.config]
         line = run_secondary(args, cfg, dev, group, rank, world, par)
         if line is not None:
-            print(json.dumps(line), flush=True)
+            emit(line)
         return done()
 
     from cp_pre_amd import inductive_cp as icp
@@ -737,6 +770,7 @@ def main():
         torch.cuda.synchronize()
 
     res_main = st.views(args.mode, sharded=group is not None)
+    note(f"c3 {args.mode}: {len(slabs)} slabs of {slabs}, {args.warmup} + {args.steps} steps")
     for k in range(args.warmup):
         step(k, res_main)
     sync()
@@ -827,6 +861,7 @@ def main():
         if not args.no_parity:
             # CHECKER (outside every timed region): what the last slab pass left in the residual buffer against the CPU
             # oracle on two samples (first and last of the batch window), and the pruned q-hats against the full pass's
+            note("parity check against the CPU oracle (2 samples of the last slab)")
             s_last, sl_last = n_slabs - 1, slabs[-1]
             res_last = res_main[sl_last]
             if args.mode == "marginal":                                  # |res| is in the buffer: re-evaluate signed
@@ -850,6 +885,7 @@ def main():
             # (C3's buffers freed) the strong-scaled per-rank job, C1, C2, C4 x5, the C5 shard and C5 whole.  Not part
             # of `value`.
             sec = {}
+            note("secondary c3_marginal")
             mres, k0, n2 = st.views("marginal"), args.warmup + args.steps + 2, 2 + 5
             for k in range(k0, k0 + 2):
                 step(k, mres, mode="marginal")
@@ -888,8 +924,10 @@ def main():
             sec.update(measure_others(dev))
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
+            note("cpu baseline (the oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline(args, alphas, S, xs)
-        print(json.dumps(out), flush=True)
+        note("done")
+        emit(out)
     return done(code)
 
 

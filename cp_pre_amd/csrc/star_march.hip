@@ -71,6 +71,27 @@ template <int MODE> struct OpKinds {
     static constexpr int LAP = MODE == 2 ? K_STAR7 : (MODE >= 3 ? K_TX5 : K_XY5);
 };
 
+// Which fields does a functor need x-NEIGHBOURS of?  Only those are staged through LDS (and only their halo rows are
+// fetched): a field that a functor reads at the centre alone, or only along t / y in the tap structure of its MODE, skips
+// the LDS store, the two LDS reads, the halo-row loads and its share of the tile (MHD momentum never differentiates rho;
+// in the reference's construction D_y has its taps on Nt, so what is only ever under D_y / D_t needs no x-neighbour:
+// MHD energy stages 4 of its 6 fields, continuity 2 of 3).  O_*: the operators applied to a field; XMASK bit i = field i is
+// staged.  A functor without XMASK stages everything.  (A wrong mask cannot pass silently: the x-neighbours of an unstaged
+// field are NaN.)
+enum { O_DT = 1, O_DX = 2, O_DY = 4, O_LAP = 8 };
+constexpr bool kind_has_x(int k) { return k == K_X3 || k == K_XY5 || k == K_TX5 || k == K_STAR7; }
+template <int MODE> constexpr bool ops_have_x(int ops)
+{
+    using K = OpKinds<MODE>;
+    return ((ops & O_DT) && kind_has_x(K::DT)) || ((ops & O_DX) && kind_has_x(K::DX)) || ((ops & O_DY) && kind_has_x(K::DY)) ||
+           ((ops & O_LAP) && kind_has_x(K::LAP));
+}
+template <int MODE> constexpr unsigned xmask_of(int o0, int o1 = 0, int o2 = 0, int o3 = 0, int o4 = 0, int o5 = 0)
+{
+    return (ops_have_x<MODE>(o0) ? 1u : 0u) | (ops_have_x<MODE>(o1) ? 2u : 0u) | (ops_have_x<MODE>(o2) ? 4u : 0u) |
+           (ops_have_x<MODE>(o3) ? 8u : 0u) | (ops_have_x<MODE>(o4) ? 16u : 0u) | (ops_have_x<MODE>(o5) ? 32u : 0u);
+}
+
 struct Linear1 {       // out = S(f0): any single ConvOperator / additive kernel (README.md:47-54)
     static constexpr int F = 1;
     struct Params { Star s; };
@@ -101,6 +122,7 @@ struct NSMomentum {    // Marginal/NS_Residuals_CP.py:231-240
     // spills 0-6 dwords and runs 4 waves/SIMD: +11 % (4.7-5.0 TB/s).  The same cap on the MHD induction kernel
     // (146 VGPRs, 17 dwords spilled) was -30 %: scratch traffic inside the plane loop.
     static constexpr int MIN_WAVES = MODE >= 3 ? 4 : 1;
+    static constexpr unsigned XMASK = xmask_of<MODE>(O_DT | O_DX | O_DY | O_LAP, O_DT | O_DX | O_DY | O_LAP, O_DX | O_DY);
     using Params = NSParams;
     static __device__ __forceinline__ float4 eval(const Nbr (&n)[3], const Params &p)
     {
@@ -140,6 +162,7 @@ struct Burgers {       // Joint/Burgers_Residuals_CP.py:182-187
 template <int MODE>
 struct MHDContinuity { // Marginal/MHD_Residuals_CP.py:225-231   fields rho,u,v
     static constexpr int F = 3;
+    static constexpr unsigned XMASK = xmask_of<MODE>(O_DT | O_DX | O_DY, O_DX, O_DY);
     using Params = MHDParams;
     static __device__ __forceinline__ float4 eval(const Nbr (&n)[3], const Params &p)
     {
@@ -156,6 +179,7 @@ struct MHDContinuity { // Marginal/MHD_Residuals_CP.py:225-231   fields rho,u,v
 template <int MODE>
 struct MHDMomentum {   // Marginal/MHD_Residuals_CP.py:234-243   fields rho,u,v,p,Bx,By
     static constexpr int F = 6;
+    static constexpr unsigned XMASK = xmask_of<MODE>(0, O_DT | O_DX | O_DY, O_DT | O_DX | O_DY, O_DX | O_DY, O_DX | O_DY, O_DX | O_DY);
     using Params = MHDParams;
     static __device__ __forceinline__ float4 eval(const Nbr (&n)[6], const Params &p)
     {
@@ -181,6 +205,7 @@ struct MHDMomentum {   // Marginal/MHD_Residuals_CP.py:234-243   fields rho,u,v,
 template <int MODE>
 struct MHDEnergy {     // Marginal/MHD_Residuals_CP.py:247-256; PRE_estimations.py:70-80
     static constexpr int F = 6;
+    static constexpr unsigned XMASK = xmask_of<MODE>(O_DT, O_DX | O_DY, O_DX | O_DY, O_DX | O_DY, O_DX, O_DY);
     using Params = MHDParams;
     static __device__ __forceinline__ float4 eval(const Nbr (&n)[6], const Params &p)
     {
@@ -201,7 +226,7 @@ struct MHDEnergy {     // Marginal/MHD_Residuals_CP.py:247-256; PRE_estimations.
 template <int MODE>
 struct MHDInduction {  // Marginal/MHD_Residuals_CP.py:259-268   fields u,v,Bx,By
     static constexpr int F = 4;
-
+    static constexpr unsigned XMASK = xmask_of<MODE>(O_DX | O_DY, O_DX | O_DY, O_DT | O_DX | O_DY, O_DT | O_DX | O_DY);
     using Params = MHDParams;
     static __device__ __forceinline__ float4 eval(const Nbr (&n)[4], const Params &p)
     {
@@ -319,17 +344,43 @@ template <int F, bool BC, bool COOP> struct Halo {
 struct BCInfo { int xlo, xhi, ylo, yhi; float vxlo, vxhi, vylo, vyhi; };
 struct NoBC {};
 
+// experiment knobs for the functors of five or more fields (tools/exp/build_variants.sh; the defaults are the product)
+#ifndef MARCH6_NR
+#define MARCH6_NR 8
+#endif
+#ifndef MARCH6_TYQ
+#define MARCH6_TYQ 64
+#endif
+#ifndef MARCH6_MINW
+#define MARCH6_MINW 1
+#endif
+#ifndef MARCH_COOP_MAXF
+#define MARCH_COOP_MAXF 4
+#endif
+
 // Fn::MIN_WAVES (optional): waves per SIMD the register allocator must leave room for
-template <class Fn, class = void> struct MinWaves { static constexpr int value = 1; };
+template <class Fn, class = void> struct MinWaves { static constexpr int value = Fn::F >= 5 ? MARCH6_MINW : 1; };
 template <class Fn> struct MinWaves<Fn, std::void_t<decltype(Fn::MIN_WAVES)>> { static constexpr int value = Fn::MIN_WAVES; };
+
+// Fn::XMASK (optional): the fields staged through LDS for their x-neighbours (default: all)
+template <class Fn, class = void> struct XMask { static constexpr unsigned value = (1u << Fn::F) - 1u; };
+template <class Fn> struct XMask<Fn, std::void_t<decltype(Fn::XMASK)>> { static constexpr unsigned value = Fn::XMASK & ((1u << Fn::F) - 1u); };
+template <class Fn> struct Staged {
+    static constexpr unsigned M = XMask<Fn>::value;
+    static constexpr int count = __builtin_popcount(M);
+    static constexpr int FX = count > 0 ? count : 1;                      // (array extent; nothing is stored when count == 0)
+    static __device__ __forceinline__ constexpr bool has(int i) { return (M >> i) & 1u; }
+    static __device__ __forceinline__ constexpr int slot(int i) { return __builtin_popcount(M & ((1u << i) - 1u)); }
+};
 
 template <class Fn, int NR, int TYQ, bool BC = false>
 __global__ void __launch_bounds__(NR *TYQ, MinWaves<Fn>::value)
 march_kernel(const Geom g, const typename Fn::Params prm, const typename std::conditional<BC, BCInfo, NoBC>::type bc)
 {
     constexpr int F = Fn::F;
+    using SX = Staged<Fn>;
     static_assert(NR >= 2, "tile needs at least two rows (top and bottom halo owners differ)");
-    __shared__ float4 lds[2][F][NR + 2][TYQ];
+    __shared__ float4 lds[2][SX::FX][NR + 2][TYQ];
 
     const int q = threadIdx.x, ty = threadIdx.y;
     unsigned L = xcd_remap(blockIdx.x, gridDim.x);
@@ -361,7 +412,7 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
     // halo-row duty: the workgroup's first 4*TYQ threads fetch the row above the tile, the next 4*TYQ the row below, one
     // float each (a wave = 64 consecutive floats of one row)
     static_assert(NR >= 8 && (4 * TYQ) % 64 == 0, "the two halo rows are fetched by the first 8*TYQ threads, a wave per 64 floats");
-    constexpr bool COOP = F <= 4;
+    constexpr bool COOP = F <= MARCH_COOP_MAXF;
     const int hl = ty * TYQ + q;                     // linear thread index
     const bool hduty = COOP ? hl < 8 * TYQ : (ty == 0 || ty == NR - 1), hbot = COOP ? hl >= 4 * TYQ : ty == NR - 1;
     const int hcol = COOP ? hl & (4 * TYQ - 1) : 4 * q;          // column within the tile (!COOP: of the quad's first cell)
@@ -435,7 +486,9 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
         const bool okt = (t >= 0) && (t < g.T);
 #pragma unroll
         for (int i = 0; i < F; ++i) {
-            if constexpr (COOP) {
+            if (!SX::has(i)) {                                   // no x-neighbours of this field are read: no halo row
+                if constexpr (COOP) h.row[i] = 0.f; else h.row[i] = f4(0.f);
+            } else if constexpr (COOP) {
                 h.row[i] = (hrow && okt) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(plane(i, t), (int)hoff[i], 0, 0))
                                          : (BC ? hfill : 0.f);
             } else if (hrow && okt) {
@@ -460,11 +513,13 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
         const int bi = (t - t0) & 1;
 #pragma unroll
         for (int i = 0; i < F; ++i) {
-            lds[bi][i][ty + 1][q] = C[i];
+            if (!SX::has(i)) continue;
+            const int k = SX::slot(i);
+            lds[bi][k][ty + 1][q] = C[i];
             if constexpr (COOP) {
-                if (hduty) reinterpret_cast<float *>(&lds[bi][i][hslot][0])[hcol] = hc.row[i];
+                if (hduty) reinterpret_cast<float *>(&lds[bi][k][hslot][0])[hcol] = hc.row[i];
             } else {
-                if (hduty) lds[bi][i][hslot][q] = hc.row[i];
+                if (hduty) lds[bi][k][hslot][q] = hc.row[i];
             }
         }
         // halo first: it is consumed first (next plane's LDS staging), and vmcnt retires in
@@ -473,7 +528,7 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
         // the slc / nt bit -5 ... -12 % on every functor, with glc +-0)
         load_halo(t + 1, hn);
         load_own(t + 2, D);
-        lds_barrier();
+        if constexpr (SX::count > 0) lds_barrier();
 
         Nbr n[F];
 #pragma unroll
@@ -481,8 +536,12 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
             n[i].c = C[i];
             n[i].tm = P[i];
             n[i].tp = N[i];
-            n[i].xm = lds[bi][i][ty][q];
-            n[i].xp = lds[bi][i][ty + 2][q];
+            if (SX::has(i)) {
+                n[i].xm = lds[bi][SX::slot(i)][ty][q];
+                n[i].xp = lds[bi][SX::slot(i)][ty + 2][q];
+            } else {
+                n[i].xm = n[i].xp = f4(__builtin_nanf(""));      // never read by the functor (or the result says so)
+            }
             float lft = __shfl_up(C[i].w, 1);
             float rgt = __shfl_down(C[i].x, 1);
             lft = ledge ? hc.ye[i] : lft;
@@ -550,7 +609,7 @@ int pick_mode(const Star &Dt, const Star &Dx, const Star &Dy, const Star *L)
 template <class Fn, int NR, int TYQ, bool BC = false>
 int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const BCInfo *bc = nullptr)
 {
-    static_assert(2 * Fn::F * (NR + 2) * TYQ * 16 <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    static_assert(2 * Staged<Fn>::FX * (NR + 2) * TYQ * 16 <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     {
     g.nXT = (g.X + NR - 1) / NR;
     g.nYT = (g.Yc + 4 * TYQ - 1) / (4 * TYQ);
@@ -759,6 +818,8 @@ int launch(Geom &g, const typename Fn::Params &prm, hipStream_t st, const BCInfo
     // induction capped at 128 VGPRs (17 dwords spilled) so that two of its 80 KB workgroups share a CU: -30 %
     // round 3, x-slabs (64-plane marches: x-neighbour tiles drift apart, 8 % of the input is fetched twice): NS momentum
     // 16x64 (1024 threads) 50.5 ms, 16x32 48.5, 32x16 50.7 against 47.4 for 8x64 (gpurun_out/r3b/nr_*.log)
+    if constexpr (Fn::F >= 5)
+        if (g.Y >= 192) return launch_tiled<Fn, MARCH6_NR, MARCH6_TYQ, BC>(g, prm, st, bc);
     if (g.Y >= 192) return launch_tiled<Fn, 8, 64, BC>(g, prm, st, bc);
     if (g.Y >= 96) return launch_tiled<Fn, 16, 32, BC>(g, prm, st, bc);
     return launch_tiled<Fn, 32, 16, BC>(g, prm, st, bc);
