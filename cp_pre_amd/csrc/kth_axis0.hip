@@ -758,21 +758,53 @@ __device__ __forceinline__ void lds_barrier()
 
 constexpr unsigned int KT_MARK = 0xffc0dead;      // "left to the streaming kernel" (results are input values or 0x7fc00000)
 
+// experiment build only (tools/exp/build_variants.sh ... -DKT_CLOCK): thread 0 of every workgroup stamps the shader clock at
+// the phase boundaries of its first 64 tiles (tools/exp/tile_phases.py reads them back)
+#ifdef KT_CLOCK
+__device__ unsigned long long kt_clock_buf[1024 * 64 * 8];
+#define KT_STAMP(i)                                                                                                         \
+    do {                                                                                                                    \
+        if (threadIdx.x == 0 && kt_it < 64 && blockIdx.x < 1024)                                                            \
+            kt_clock_buf[((size_t)blockIdx.x * 64 + kt_it) * 8 + (i)] = __builtin_readcyclecounter();                       \
+    } while (0)
+#else
+#define KT_STAMP(i)
+#endif
+
 // WGS = workgroups per CU.  Two (R = 32: 64 registers per thread, 80 KiB each) hide each other's barriers and LDS round
-// trips - at these tile sizes the phases are latency chains, not throughput; that takes 256 first-digit buckets and
-// 21-entry lists.  One (R = 64: the data alone are half the register file) has 512 buckets and 31-entry lists.
+// trips - at these tile sizes the phases are latency chains, not throughput; that takes 256 first-digit buckets.
+// One (R = 64: the data alone are half the register file) has 512 buckets.
+//
+// LDS (round 5): [histogram + group sums | lists | side].  "Which list, if any, wants this row of this cell" used to be a
+// byte map (a byte per (row, cell), rows 68 bytes apart): the 64 byte reads of a wave-instruction of the collect sweep
+// fell on ~random banks, 3.5 lanes deep on the fullest one - the sweep cost 300 clocks per element and wave, four times the
+// histogram sweep next to it, whose word (row, lane & 31) is conflict-free by construction (tools/exp/tile_phases.py,
+// profiles/r05/tile_phases_*.txt: the same sweep without any memory load still took 85 % of its time - it was never
+// waiting for HBM).  Now the answer lives IN the histogram word the element's row was counted in: a count is at most
+// n <= 2048, 12 bits, so bits 12-15 of each 16-bit half (bits 16-19 of a 32-cell tile's full-word counters) are free for
+// "list + 1" - written by the rank's owner with a compare-and-swap once the narrowing has found its row, read back by the
+// collect sweep from the very address the histogram sweep incremented: conflict-free, no map memory, nothing to clean up
+// (the next tile's histogram clear wipes the tags).  The lists therefore no longer alias the histogram - which also
+// lets the owners pick their ranks while the other waves are already taking the next tile's window and clearing its
+// histogram: no barrier at the end of a tile.  Five barriers per tile instead of seven.
 template <int LOG_NB1, int WGS>
 struct KTCfg {
-    static constexpr int NB1 = 1 << LOG_NB1, LS = WGS == 2 ? 22 : 32, CAP = LS - 1;
-    static constexpr int FIRST_WORDS = (NB1 + 1) * 32 + KA_WAVES * 64;       // first-digit histogram + group sums
-    static constexpr int LIST_WORDS = KA_MAXK * LS * 64;                     // (aliases the histogram: filled after the narrowing)
-    static constexpr int WORDS = FIRST_WORDS > LIST_WORDS ? FIRST_WORDS : LIST_WORDS;
-    static constexpr int MAP_WORDS = (NB1 + 1) * (KA_MAPROW / 4);            // a byte per (row, cell): list + 1, 0 = not wanted
-    // side arrays that are NOT aliased: window (min key, max key, NaN flag per cell), published rows, list fill
-    // counters, per-wave flags
-    static constexpr int WIN_AT = 0, PUB_AT = 192, CNT_AT = PUB_AT + KA_MAXK * 64, FLG_AT = CNT_AT + KA_MAXK * 64,
-                         SIDE_WORDS = FLG_AT + KA_WAVES;
-    static constexpr int HOT_WORDS = WORDS + MAP_WORDS + SIDE_WORDS;
+    static constexpr int NB1 = 1 << LOG_NB1;
+    static constexpr int HIST_WORDS = (NB1 + 1) * 32 + KA_WAVES * 64;        // first-digit histogram (+ tags) + group sums
+    // The candidate lists of a cell share ONE pool of POOL entries (entry i of cell c: word i * 64 + c): a list is a
+    // segment of exactly `count` entries - the histogram knows the size - that its owner allocates with one atomic add
+    // on the cell's pool pointer.  Ten fixed lists of 15 (what the same memory holds with two workgroups per CU) sent
+    // 2 % of the tiles of n = 512 |N(0,1)| scores to the streaming form - a bucket at the mode holds 5 on average - and
+    // their late, lonely repeats cost 19 %; from the pool a list can have all 31 entries the pick can sort while the ~40
+    // a cell's ten ranks need in total always fit.
+    // (the pick reads a fixed 8 / 16 / 32 entries from a list's start whatever its length: SLACK entries behind the last
+    // allocatable one keep those reads inside the pool)
+    static constexpr int SLACK = WGS == 2 ? 16 : 32, POOL = (WGS == 2 ? 160 : 320) - SLACK, CAP = 31;
+    static constexpr int LIST_AT = HIST_WORDS, LIST_WORDS = (POOL + SLACK) * 64;
+    // side arrays: window (min key, max key per cell), list fill pointers, pool pointers, per-wave flags
+    static constexpr int SIDE_AT = LIST_AT + LIST_WORDS;
+    static constexpr int WIN_AT = 0, CNT_AT = 128, PTR_AT = CNT_AT + KA_MAXK * 64, FLG_AT = PTR_AT + 64, SIDE_WORDS = FLG_AT + KA_WAVES;
+    static constexpr int HOT_WORDS = SIDE_AT + SIDE_WORDS;
     // (the marked tiles are redone by the streaming form with 512 buckets: 80 KiB from the start of the same block)
     static constexpr int TOTAL = HOT_WORDS > KACfg<9, false>::WORDS ? HOT_WORDS : KACfg<9, false>::WORDS;
     static_assert(TOTAL * 4 * WGS <= 160 * 1024, "does not fit the 160 KiB LDS");
@@ -836,7 +868,8 @@ __device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsign
                                           unsigned int &row0, int lane, int wave)
 {
     constexpr int NB1 = 1 << LOG_NB1, GB = NB1 / KA_WAVES, GROUPS_AT = (NB1 + 1) * 32;
-    constexpr unsigned int MSK = C32 ? 0xffffffffu : 0xffffu;
+    // (a count is at most n <= 2048; the bits above it may carry the list tag of an owner that is already done: masked off)
+    constexpr unsigned int MSK = C32 ? 0xffffu : 0xfffu;
     const int l31 = lane & 31, sh = C32 ? 0 : 16 * (lane >> 5);
     // 16 groups of GB bins (rows 1 + d) are summed by all 1024 threads first; the two cells of a word are added
     // together (no carry: a sum is at most n < 65536) and taken apart at the end
@@ -884,14 +917,17 @@ __device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsign
 // lists hold the scores' raw bit patterns (the sweeping threads - all of them - do not pay for the key transform; the
 // owners - ten waves, a dozen entries - do); the sort is ks_sort's in-register network, declared below
 template <int N, int P, int NW> __device__ __forceinline__ void ks_sort(unsigned int (&v)[NW]);
-template <int N, int LS>
-__device__ __forceinline__ unsigned int kt_pick(const unsigned int *hist, int slot, unsigned int count, unsigned int myr,
-                                                unsigned int keep, int cell)
+template <int N>
+__device__ __forceinline__ unsigned int kt_pick(const unsigned int *pool, unsigned int base, unsigned int count, unsigned int myr,
+                                                unsigned int keep)
 {
     unsigned int c[N];
+    const char *p = reinterpret_cast<const char *>(pool) + base;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const unsigned int x = i < LS - 1 ? f2key(__uint_as_float(hist[ka_list<LS>(slot, i, cell)])) : 0xffffffffu;
+        // (entries beyond my own count may lie in another list's segment, or - harmlessly - just beyond the pool: inside the
+        // workgroup's LDS block either way; they are replaced by the padding)
+        const unsigned int x = f2key(__uint_as_float(*reinterpret_cast<const unsigned int *>(p + i * 256)));
         c[i] = (unsigned)i < count ? x : 0xffffffffu;
     }
     ks_sort<N, 1, N>(c);
@@ -923,7 +959,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
                 float *__restrict__ out, const KAPlanes pl)
 {
     using Cfg = KTCfg<LOG_NB1, WGS>;
-    constexpr int NB1 = Cfg::NB1, LS = Cfg::LS, CAP = Cfg::CAP;
+    constexpr int NB1 = Cfg::NB1, CAP = Cfg::CAP, POOL = Cfg::POOL;
     constexpr int W = C32 ? 32 : 64;                  // cells per tile
     constexpr int RPT = C32 ? 32 : KA_WAVES;          // rows between a thread's registers u and u + 1
     constexpr int Q = R / 4, RLO = R / 2 + Q;         // registers [RLO, R): skipped when n <= RLO * RPT
@@ -931,9 +967,8 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     constexpr int GRP = BATCH == 6 ? 3 : 4;           // rows that share a descriptor base (host: (GRP - 1) rows' stride < 2^32 bytes)
     static_assert(Q % 2 == 0 && RLO % BATCH == 0 && Q % BATCH == 0 && BATCH % GRP == 0, "register blocks");
     __shared__ unsigned int lds[Cfg::TOTAL];
-    unsigned int *hist = lds, *mapw = lds + Cfg::WORDS, *side = mapw + Cfg::MAP_WORDS;
-    unsigned char *map = reinterpret_cast<unsigned char *>(mapw);
-    unsigned int *win = side + Cfg::WIN_AT, *pub = side + Cfg::PUB_AT, *cnt = side + Cfg::CNT_AT, *flg = side + Cfg::FLG_AT;
+    unsigned int *hist = lds, *lists = lds + Cfg::LIST_AT, *side = lds + Cfg::SIDE_AT;
+    unsigned int *win = side + Cfg::WIN_AT, *cnt = side + Cfg::CNT_AT, *ptr = side + Cfg::PTR_AT, *flg = side + Cfg::FLG_AT;
     const int tid0 = threadIdx.x, wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int nk = kl.nk;
     const int S4 = (int)(S * 4);                       // (C32: the second row of a load, in bytes; host: S < 2^29)
@@ -941,13 +976,8 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     const bool hiq = (n + RPT - 1) / RPT > RLO;        // some thread has a row in the last quarter (block-uniform)
     const unsigned int pads = (unsigned)((hiq ? R : RLO) * RPT - n);       // padding rows per cell
 
-    // one-time LDS state: empty byte map, empty window, list fill "counters" = the byte offset (from `hist`) of the next
-    // free entry of list j of cell c, entry i of which lies at ((j * LS + i) * 64 + c) * 4
-    for (int i = tid0; i < Cfg::MAP_WORDS; i += 1024) mapw[i] = 0u;
-    for (int i = tid0; i < Cfg::SIDE_WORDS; i += 1024) {
-        const int k = i - Cfg::CNT_AT;
-        side[i] = i < 64 ? 0xffffffffu : (k >= 0 && k < KA_MAXK * 64) ? (unsigned)(((k >> 6) * LS * 64 + (k & 63)) * 4) : 0u;
-    }
+    // one-time LDS state: empty window (the list fill pointers and the pool pointers are set tile by tile)
+    for (int i = tid0; i < Cfg::SIDE_WORDS; i += 1024) side[i] = i < 64 ? 0xffffffffu : 0u;
 
     // records of the descriptor of register u (bytes readable from its base): `vb` of a row inside n, both rows of a C32 pair
     // (a thread's first R/2 registers are always rows of the tile: the host sends only R/2 < rows per thread <= R here)
@@ -987,8 +1017,15 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     }
     __syncthreads();
 
+#ifdef KT_CLOCK
+    int kt_it = -1;
+#endif
 #pragma unroll 1
     for (; tile < ntiles; tile += gridDim.x) {
+#ifdef KT_CLOCK
+        ++kt_it;
+#endif
+        KT_STAMP(0);
         const int wave = kt_opq_s(wave0);
         const bool state = wave < nk;
         const unsigned int k0 = state ? (unsigned)kl.k[wave] : 0u;
@@ -1032,6 +1069,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             for (int i = wave * 64 + lane; i < ((NB1 + 1) * 32) / 4; i += 1024) h4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();
+        KT_STAMP(1);
         unsigned int kmin, kmax;
         float vlo, sf;
         bool flat, badwin;
@@ -1071,14 +1109,16 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             }
         }
         __syncthreads();
+        KT_STAMP(2);
         unsigned int myr = k0, count, fl;
-        int digit;
+        int digit, myslot = wave, cmax = 0;
         bool open, nancell;
         {
             const int lane = kt_lane(), cell = C32 ? (lane & 31) : lane;
             if (wave == KA_WAVES - 1) {                              // (everyone has read the window)
                 win[cell] = 0xffffffffu;
                 win[64 + cell] = 0u;
+                ptr[cell] = 0u;                                      // this tile's pool is empty (allocations follow the next barrier)
             }
             unsigned int row0;
             kt_narrow<LOG_NB1, C32>(hist, state, myr, digit, count, row0, lane, wave);
@@ -1086,16 +1126,47 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             // finite: then every number maps to a row >= 1; a tile with a cell whose window is not is redone anyway.)
             nancell = state && row0 != pads;
             open = state && !flat && !nancell;
-            const bool bad = state && badwin, many = open && count > (unsigned)CAP;
-            if (state) pub[wave * 64 + lane] = open ? (unsigned)(digit + 1) : 0u;
+            bool many = open && count > (unsigned)CAP;
+            const bool bad = state && badwin;
+            // The list of a rank = the list of the FIRST owner to tag the rank's row in its cell.  An owner whose row carries
+            // no tag yet takes `count` entries of the cell's pool (the histogram knows the size: nothing can overflow a
+            // list, whatever the other cells of the tile decide), points the list's fill pointer at them and writes
+            // "list + 1" above the row's count with a compare-and-swap (bits 12-15 of my cell's half of the word, bits 16-19
+            // of a 32-cell tile's) - unless another rank of the cell got there first: then that rank's list is mine too (and
+            // my entries stay unused).  (C32: the two half-waves hold the same cells; the lower one acts.)
+            const int tsh = C32 ? 16 : 12 + 16 * (lane >> 5);
+            unsigned int *a = hist + (digit + 1) * 32 + (lane & 31);
+            if (open && !many && (!C32 || lane < 32)) {
+                unsigned int old = *a;
+                if (((old >> tsh) & 15u) == 0u) {
+                    const unsigned int start = atomicAdd(&ptr[cell], count);
+                    if (start + count > (unsigned)POOL) {
+                        many = true;                                 // (the pool is exhausted: ties - left to the streaming form)
+                    } else {
+                        cnt[wave * 64 + cell] = (start * 64u + (unsigned)cell) * 4u;
+                        for (;;) {
+                            const unsigned int prev = atomicCAS(a, old, old | ((unsigned)(wave + 1) << tsh));
+                            if (prev == old || ((prev >> tsh) & 15u) != 0u) break;      // mine / another rank's of my cell
+                            old = prev;                              // (the other cell of the word was tagged meanwhile)
+                        }
+                    }
+                }
+            }
             const unsigned int w = (__ballot(many) != 0 ? 1u : 0u) | (__ballot(bad) != 0 ? 2u : 0u);
             if (lane == 0) flg[wave] = w;
-            __syncthreads();                                        // the histograms are read, rows and flags published
+            cmax = open ? (int)count : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+            cmax = __builtin_amdgcn_readfirstlane(cmax);
+            __syncthreads();                                        // the histograms are read, rows tagged, flags published
             fl = flg[lane & (KA_WAVES - 1)];
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) fl |= __shfl_xor(fl, o);
             fl = __builtin_amdgcn_readfirstlane(fl);
+            // whose list holds my rank's candidates (0 when the tile is not being finished and my row went untagged)
+            myslot = open ? (int)((*a >> tsh) & 15u) - 1 : wave;
         }
+        KT_STAMP(3);
 
         const bool more = tile + gridDim.x < ntiles;               // (block-uniform)
         long long nplane = plane, nc0 = c0;
@@ -1104,49 +1175,31 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
         const float *nbase = s + nplane * pl.PS + nc0 + (long long)(C32 ? 2 * wave : wave) * S;   // my first row of the next tile
         float *outp = out + plane * pl.OPS;
 
-        // ---- collect + pick (when every pair has its <= CAP candidates: ok, block-uniform).  The list of a rank = the
-        // list of the FIRST rank of its cell with the same row.
+        // ---- collect + pick (when every pair has its <= CAP candidates: ok, block-uniform)
         const bool ok = fl == 0u;
-        const int myrow = digit + 1;
-        int myslot = wave, cmax = 0;
-        bool first = false;
-        if (ok) {
-            const int lane = kt_lane();
-            if (open) {
-#pragma unroll
-                for (int j = KA_MAXK - 1; j >= 0; --j)
-                    if (j < wave && pub[j * 64 + lane] == (unsigned)myrow) myslot = j;
-            }
-            first = open && myslot == wave;
-            cmax = open ? (int)count : 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
-            cmax = __builtin_amdgcn_readfirstlane(cmax);
-            if (first) map[myrow * KA_MAPROW + lane] = (unsigned char)(wave + 1);
-        }
-        __syncthreads();
+        KT_STAMP(4);
         {
-            // (the map is opaque to the optimiser: left alone it keeps the 64 row numbers of the first sweep for this
+            // (the sweep is opaque to the optimiser: left alone it keeps the 64 row numbers of the first sweep for this
             // one - in scratch memory, whose loads then queue behind the prefetch below and make every element wait)
             float sf2 = sf, vlo2 = vlo;
             asm volatile("" : "+v"(sf2), "+v"(vlo2));
             const int lane = kt_lane(), cell = C32 ? (lane & 31) : lane;
             const int nloff = lane_off(lane, nvb);
             const float *np = nbase;
-            const unsigned char *mapl = map + lane;
+            const char *hb = reinterpret_cast<const char *>(hist + (lane & 31));     // the word of (row, my cell): hb + row * 128
+            const unsigned int tsh = C32 ? 16u : 12u + 16u * (unsigned)(lane >> 5);
             char *cb = reinterpret_cast<char *>(cnt + cell) - 256;             // fill pointer of list m - 1 of my cell: cb + m * 256
-            char *lb = reinterpret_cast<char *>(hist);
-            // BATCH rows at a time: their map bytes are read together (one LDS latency per batch, not per element); an
-            // element that is wanted joins its list - a position below CAP always: the histogram counted the list's elements.
-            // No row is tested: padding and NaNs look up row 0 of the map, which - like the whole map of a tile that is not
-            // being finished - is zero.  (The product fits 24 bits: v_mad_u32_u24, not the quarter-rate 64-bit multiply-add
-            // that pointer arithmetic on a 32-bit row number compiles to.)
+            char *lb = reinterpret_cast<char *>(lists);
+            // BATCH rows at a time: their histogram words are read together (one LDS latency per batch, not per element); an
+            // element whose row is tagged joins the list - a position below CAP always: the histogram counted the list's
+            // elements.  No row is tested: padding and NaNs look up row 0, which is never tagged, and a tile that is not
+            // being finished has its tagged lists filled for nothing.
             auto batch = [&](const int u0) __attribute__((always_inline)) {
                 unsigned int m[BATCH];
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) {
                     const unsigned int row = kt_frow(v[u0 + i], sf2, vlo2);
-                    m[i] = mapl[__umul24(row, (unsigned)KA_MAPROW)];
+                    m[i] = *reinterpret_cast<const unsigned int *>(hb + (row << 7));
                 }
                 // (full registers from here on: no 16-bit re-masking at the tests.  AFTER the batch's loads are issued - the
                 // same barrier inside the loop above made every map read wait for the one before it)
@@ -1161,6 +1214,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) {
                     const int u = u0 + i;
+                    m[i] = __builtin_amdgcn_ubfe(m[i], tsh, 4u);
                     if (m[i]) {
                         // (the list's fill pointer IS the byte offset of its next free entry, 256 bytes = one entry across
                         // the cells further each time: nothing to multiply; raw bits: the owners transform the few they
@@ -1183,21 +1237,27 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             }
         }
         lds_barrier();
+        KT_STAMP(5);
         if (ok) {
             const int lane = kt_lane(), cell = C32 ? (lane & 31) : lane;
             unsigned int ans = kmin;                                // flat: the column's one value
             if (wave < nk) {                                        // (whole waves: cmax is theirs)
                 // my rank among the <= CAP candidates of my list: all of them into registers at once (entries beyond my
-                // own count read as all ones), a sorting network, element myr
-                if (cmax <= 8) ans = kt_pick<8, LS>(hist, myslot, open ? count : 0u, myr, ans, cell);
-                else if (cmax <= 16) ans = kt_pick<16, LS>(hist, myslot, open ? count : 0u, myr, ans, cell);
-                else if constexpr (WGS == 1) ans = kt_pick<32, LS>(hist, myslot, open ? count : 0u, myr, ans, cell);
+                // own count are replaced by all ones), a sorting network, element myr.  The list's fill pointer has reached
+                // its end: the first entry lies `count` entries before it.
+                const unsigned int cn = open ? count : 0u;
+                const unsigned int base = open ? cnt[myslot * 64 + cell] - cn * 256u : 0u;
+                if (cmax <= 8) ans = kt_pick<8>(lists, base, cn, myr, ans);
+                else if (cmax <= 16) ans = kt_pick<16>(lists, base, cn, myr, ans);
+                else if constexpr (WGS == 1) ans = kt_pick<32>(lists, base, cn, myr, ans);
                 else if (open) {                                    // (no 32 registers to spare: count in place)
+                    const char *lp = reinterpret_cast<const char *>(lists) + base;
                     ans = 0xffffffffu;
                     for (int i = 0; i < (int)count; ++i) {
-                        const unsigned int ki = f2key(__uint_as_float(hist[ka_list<LS>(myslot, i, cell)]));
+                        const unsigned int ki = f2key(__uint_as_float(*reinterpret_cast<const unsigned int *>(lp + i * 256)));
                         unsigned int le = 0;
-                        for (int j = 0; j < (int)count; ++j) le += f2key(__uint_as_float(hist[ka_list<LS>(myslot, j, cell)])) <= ki;
+                        for (int j = 0; j < (int)count; ++j)
+                            le += f2key(__uint_as_float(*reinterpret_cast<const unsigned int *>(lp + j * 256))) <= ki;
                         if (le > myr) ans = min(ans, ki);
                     }
                 }
@@ -1205,10 +1265,6 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             const long long c = c0 + cell;
             if (state && c < M && (!C32 || lane < 32))
                 outp[(long long)kl.o[wave] * pl.OS + c] = nancell ? __uint_as_float(0x7fc00000u) : key2f(ans);
-            if (first) {                                            // leave the map and the counters as they were found
-                map[myrow * KA_MAPROW + lane] = 0;
-                cnt[wave * 64 + cell] = (unsigned)((wave * LS * 64 + cell) * 4);
-            }
         } else if (wave == 0 && kt_lane() == 0) {
             // not finished by the fast form (a bucket above CAP: ties, an outlier stretching the window; an infinite
             // window): the tile is MARKED - a NaN pattern no result can have, in the first rank's output of its first
@@ -1216,7 +1272,9 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             // data registers)
             outp[(long long)kl.o[0] * pl.OS + c0] = __uint_as_float(KT_MARK);
         }
-        lds_barrier();
+        // NO barrier here: the pool and its pointers are not touched again before the next tile's narrowing, three barriers
+        // from now (the tags go with that tile's histogram clear), and the waves that own no rank are already taking its window
+        KT_STAMP(6);
         plane = nplane;
         c0 = nc0;
     }
@@ -1617,6 +1675,13 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     return launch_kth<9, false>(KA_ARGS);
 #undef KA_ARGS
 }
+
+#ifdef KT_CLOCK
+extern "C" int pre_debug_kt_clock(void *dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(kt_clock_buf), bytes < sizeof(kt_clock_buf) ? bytes : sizeof(kt_clock_buf));
+}
+#endif
 
 extern "C" int pre_kth_axis0_strided_f32(const float *scores, int64_t row_stride, int64_t n, int64_t M, const int32_t *ks, int nk,
                                          float *out, void *stream)

@@ -1,11 +1,19 @@
 #!/bin/bash
-# Experiment builds of libcp_pre_hip.so that differ in star_march.hip's knobs for the six-field functors:
-#   tools/exp/build_variants.sh name "-DMARCH6_NR=8 -DMARCH6_TYQ=32 ..."  ->  tools/exp/var/libcp_pre_hip.<name>.so
+# Experiment builds of libcp_pre_hip.so that differ in one source file's -D knobs:
+#   tools/exp/build_variants.sh name "-DMARCH6_NR=8 -DMARCH6_TYQ=32 ..." [source.hip]  ->  tools/exp/var/libcp_pre_hip.<name>.so
 set -e
 cd "$(dirname "$0")/../../cp_pre_amd/csrc"
 mkdir -p ../../tools/exp/var
-name=$1; shift
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $@ -c star_march.hip -o ../../tools/exp/var/star_march.$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp/var/libcp_pre_hip.$name.so ../../tools/exp/var/star_march.$name.o acc_march.o stencil_generic.o calib.o kth_axis0.o
-rm -f ../../tools/exp/var/star_march.$name.o
+name=$1; flags=$2; src=${3:-star_march.hip}
+base=${src%.hip}
+objs=""
+for o in star_march acc_march stencil_generic calib kth_axis0; do
+  if [ "$o" != "$base" ]; then objs="$objs $o.o"; fi
+done
+extra=""
+[ "$base" = "kth_axis0" ] && extra="-Wno-pass-failed"
+[ "$base" = "calib" ] && extra="-ffp-contract=off"
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $extra $flags -c $src -o ../../tools/exp/var/$base.$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp/var/libcp_pre_hip.$name.so ../../tools/exp/var/$base.$name.o $objs
+rm -f ../../tools/exp/var/$base.$name.o
 echo built $name
