@@ -804,7 +804,7 @@ struct KTCfg {
     // side arrays: window (min key, max key per cell), list fill pointers, pool pointers, per-wave flags
     static constexpr int SIDE_AT = LIST_AT + LIST_WORDS;
     static constexpr int WIN_AT = 0, CNT_AT = 128, PTR_AT = CNT_AT + KA_MAXK * 64, FLG_AT = PTR_AT + 64, SIDE_WORDS = FLG_AT + KA_WAVES;
-    static constexpr int HOT_WORDS = SIDE_AT + SIDE_WORDS;
+    static constexpr int HOT_WORDS = SIDE_AT + SIDE_WORDS + 64;            // (+ a scratch word per lane)
     // (the marked tiles are redone by the streaming form with 512 buckets: 80 KiB from the start of the same block)
     static constexpr int TOTAL = HOT_WORDS > KACfg<9, false>::WORDS ? HOT_WORDS : KACfg<9, false>::WORDS;
     static_assert(TOTAL * 4 * WGS <= 160 * 1024, "does not fit the 160 KiB LDS");
@@ -873,10 +873,20 @@ __device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsign
     const int l31 = lane & 31, sh = C32 ? 0 : 16 * (lane >> 5);
     // 16 groups of GB bins (rows 1 + d) are summed by all 1024 threads first; the two cells of a word are added
     // together (no carry: a sum is at most n < 65536) and taken apart at the end
+    // (8 / 16 / 8 reads in flight per wait: the walks are chains of LDS round trips - round 5, 1-3 % of a tile over 4 / 4 / 4)
+#ifndef KT_UNROLL_A
+#define KT_UNROLL_A 8
+#endif
+#ifndef KT_UNROLL_G
+#define KT_UNROLL_G 16
+#endif
+#ifndef KT_UNROLL_B
+#define KT_UNROLL_B 8
+#endif
     {
         unsigned int gs = 0;
         const unsigned int *h = hist + (1 + wave * GB) * 32 + l31;
-#pragma unroll 4
+#pragma unroll KT_UNROLL_A
         for (int u = 0; u < GB; ++u) gs += h[u * 32];
         hist[GROUPS_AT + wave * 64 + lane] = (gs >> sh) & MSK;
     }
@@ -888,7 +898,7 @@ __device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsign
         row0 = (hist[l31] >> sh) & MSK;
         unsigned int run = 0, cum = 0;
         int g = 0;
-#pragma unroll 4
+#pragma unroll KT_UNROLL_G
         for (int u = 0; u < KA_WAVES; ++u) {
             run += hist[GROUPS_AT + u * 64 + lane];
             const bool le = run <= myr;
@@ -899,7 +909,7 @@ __device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsign
         const unsigned int *h = hist + (1 + g * GB) * 32 + l31;
         run = cum;
         int d = 0;
-#pragma unroll 4
+#pragma unroll KT_UNROLL_B
         for (int u = 0; u < GB; ++u) {
             run += (h[u * 32] >> sh) & MSK;
             const bool le = run <= myr;
@@ -1190,6 +1200,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             const unsigned int tsh = C32 ? 16u : 12u + 16u * (unsigned)(lane >> 5);
             char *cb = reinterpret_cast<char *>(cnt + cell) - 256;             // fill pointer of list m - 1 of my cell: cb + m * 256
             char *lb = reinterpret_cast<char *>(lists);
+            char *dummy = reinterpret_cast<char *>(side + Cfg::SIDE_WORDS + lane);      // (64 scratch words behind the side arrays)
             // BATCH rows at a time: their histogram words are read together (one LDS latency per batch, not per element); an
             // element whose row is tagged joins the list - a position below CAP always: the histogram counted the list's
             // elements.  No row is tested: padding and NaNs look up row 0, which is never tagged, and a tile that is not
@@ -1209,19 +1220,25 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
                     asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]));
                 else
                     asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]));
-                // (issuing the batch's returning atomics together before the stores was measured: eight more live registers,
-                // spills under the 64-register cap of the two-workgroup form - n = 512 1.21 -> 1.86 ms - and no gain with one)
+                // (round 4 measured the batch's returning adds issued together, each under its own test: eight more live
+                // registers, spills under the 64-register cap of the two-workgroup form, no gain with one)
+                // branch-free (round 5: -1..-4 % of a tile over a test, a returning add, a wait and a store per element): every
+                // element issues its returning add - of 0 for an unwanted one, on a word of the window array, which ignores it -
+                // and its store - to a scratch word of its lane: the batch's adds are in flight together, ONE wait per batch.
+                // A wanted element joins its list at a position inside the list's segment always: the histogram counted them.
+                bool hit[BATCH];
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    m[i] = __builtin_amdgcn_ubfe(m[i], tsh, 4u);
+                    hit[i] = m[i] != 0u;
+                    // (the list's fill pointer IS the byte offset of its next free entry, 256 bytes = one entry across the
+                    // cells further each time; raw bits: the owners transform the few they pick from)
+                    m[i] = atomicAdd(reinterpret_cast<unsigned int *>(cb + (m[i] << 8)), hit[i] ? 256u : 0u);
+                }
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) {
                     const int u = u0 + i;
-                    m[i] = __builtin_amdgcn_ubfe(m[i], tsh, 4u);
-                    if (m[i]) {
-                        // (the list's fill pointer IS the byte offset of its next free entry, 256 bytes = one entry across
-                        // the cells further each time: nothing to multiply; raw bits: the owners transform the few they
-                        // pick from)
-                        const unsigned int pos = atomicAdd(reinterpret_cast<unsigned int *>(cb + (m[i] << 8)), 256u);
-                        *reinterpret_cast<float *>(lb + pos) = v[u];
-                    }
+                    *reinterpret_cast<float *>(hit[i] ? lb + m[i] : dummy) = v[u];
                     // the next tile, row by row into the register just consumed.  An unconditional load - rows beyond n, or
                     // beyond the last tile, through an empty descriptor - and the ONLY one in the loop, whether the tile is
                     // being finished or not: no copy has to wait for it here, no second definition to reconcile
