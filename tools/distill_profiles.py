@@ -30,9 +30,12 @@ def bench_line(log):
     return lines[-1].strip() if lines else "(bench line not captured)"
 
 
-CMDS = {"trace": ("c3_joint", "--no-secondary --steps 3 --warmup 1"), "trace_m": ("c3_marginal", "--no-secondary --steps 2 --warmup 1 --mode marginal"),
-        "trace_c2": ("c2", "--config c2 --steps 3 --warmup 1"), "trace_c4": ("c4", "--config c4 --steps 3 --warmup 1"),
-        "trace_c5": ("c5", "--config c5 --steps 3 --warmup 1")}
+CMDS = {"trace": ("c3_joint", "--no-secondary --no-parity --steps 3 --warmup 1"),
+        "trace_m": ("c3_marginal", "--no-secondary --no-parity --steps 2 --warmup 1 --mode marginal"),
+        "trace_c2": ("c2", "--config c2 --steps 3 --warmup 1"), "trace_c5": ("c5", "--config c5 --steps 3 --warmup 1")}
+EQS = ("induction", "continuity", "momentum", "energy", "gauss")
+for e in EQS:
+    CMDS[f"trace_c4_{e}"] = (f"c4_{e}", f"--config c4 --equation {e} --steps 3 --warmup 1")
 for src, (tag, cmd) in CMDS.items():
     f = newest(f"gpurun_out/prof/{src}/**/*_kernel_stats.csv")
     if not f:
@@ -115,15 +118,21 @@ try:
     axis = json.loads(bench_line("gpurun_out/prof/bench_fetch.log"))["config"].get("slab_axis", "t")
 except Exception:
     pass
-slabs = bench.split_slabs(c3[2] if axis == "x" else c3[1], slab)
+slabs = bench.split_slabs(c3[2] - 2 if axis == "x" else c3[1], slab)      # x-slabs: the reference's interior rows 1 .. Nx-2
 cells_xy = c3[0] * (c3[1] * c3[3] if axis == "x" else c3[2] * c3[3])        # batch x cells per row (x-slabs) / plane (t-slabs)
-hbm_report("c3", "fetch", "write", MK, "--steps 1 --warmup 0 --no-cpu-baseline",
-           {"batch": c3[0], "nt": c3[1], "nx": c3[2], "ny": c3[3], "slab": slab, "slab_axis": axis},
+hbm_report("c3", "fetch", "write", MK, "--steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-parity",
+           {"batch": c3[0], "nt": c3[1], "nx": c3[2], "ny": c3[3], "slab": slab, "slab_axis": axis, "rows": "interior"},
            sum(16 * sl * cells_xy for sl in slabs) / len(slabs),
            sum((12 * (sl + 2) + 4 * sl) * cells_xy for sl in slabs) / len(slabs),
            note=(f" [4096,64,S+2,512] x3 -> [4096,64,S,512], S in {slabs}" if axis == "x" else
                  f" [4096,S+2,512,512] x3 -> [4096,S,512,512], S in {slabs}"))
-for c in ("c2", "c4", "c5"):
+for e in EQS:
+    cfg = bench.mhd_config(e)
+    shp = cfg["shape"]
+    cells = shp[0] * shp[1] * shp[2] * shp[3]
+    hbm_report(f"c4_{e}", f"fetch_c4_{e}", f"write_c4_{e}", cfg["kernel"], f"--config c4 --equation {e} --steps 1 --warmup 0 --no-cpu-baseline",
+               {"batch": shp[0], "nt": shp[1], "nx": shp[2], "ny": shp[3]}, cfg["bpc"] * cells, note=f" {list(shp)} ({e})")
+for c in ("c2", "c5"):
     cfg = bench.CONFIGS[c]
     shp = cfg["shape"]
     cells = 1
@@ -147,6 +156,28 @@ for tag, srcs, mode in (("pmc_sq_c3.txt", ("sq1", "sq2"), "joint"), ("pmc_sq_c3_
                 f" FETCH_SIZE in KiB, x2 for bytes on gfx950)\n\n")
         kernels = sorted({k for (_, k) in sq if k.startswith(OURS)})
         for k in kernels:
+            o.write(k + "\n")
+            vals = {c: v for (c, kk), (n, v) in sq.items() if kk == k}
+            for c, v in sorted(vals.items()):
+                o.write(f"    {c:24s} {v:16.6g}\n")
+            wv = vals.get("SQ_WAVES")
+            if wv:
+                for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
+                    if c in vals:
+                        o.write(f"    {c + ' / wave':24s} {vals[c] / wv:16.1f}\n")
+            if vals.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in vals:
+                o.write(f"    {'ACTIVE_INST_VALU / BUSY_CYCLES':32s} {vals['SQ_ACTIVE_INST_VALU'] / vals['SQ_BUSY_CYCLES']:8.3f}\n")
+            o.write("\n")
+for e in ("momentum", "energy"):
+    sq = {}
+    for src in (f"sq1_c4_{e}", f"sq2_c4_{e}"):
+        sq.update(counters(src))
+    if not sq:
+        continue
+    with open(f"{out}/pmc_sq_c4_{e}.txt", "w") as o:
+        o.write(f"rocprofv3 --pmc <counters, one group per pass> --kernel-trace -- python3 bench.py --config c4 --equation {e} --steps 1 --warmup 0 --no-cpu-baseline\n"
+                f"(per-dispatch sums over all SEs/XCDs, averaged over dispatches)\n\n")
+        for k in sorted({k for (_, k) in sq if k.startswith(OURS)}):
             o.write(k + "\n")
             vals = {c: v for (c, kk), (n, v) in sq.items() if kk == k}
             for c, v in sorted(vals.items()):

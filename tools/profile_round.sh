@@ -1,19 +1,22 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
 #   gpurun --timeout 1100 -- 'bash tools/profile_round.sh'
-# then   python tools/distill_profiles.py r04   turns gpurun_out/prof/* into profiles/r04/*.
+# then   python tools/distill_profiles.py r05   turns gpurun_out/prof/* into profiles/r04/*.
 # Trace and counter passes are separate runs (PMC is never combined with other trace domains).
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 P=$R/gpurun_out/prof
-rm -rf "$P"; mkdir -p "$P"
+PART=${PART:-all}       # a: the C3 passes, b: the other configs (a gpurun call is at most 20 minutes: run the two apart)
+[ "$PART" != "b" ] && rm -rf "$P"
+mkdir -p "$P"
 cd /tmp && export TMPDIR=/tmp
 run() {  # tag, rocprof args..., -- bench args
     tag=$1; shift
     echo "== $tag" >&2
     timeout -k 10 500 rocprofv3 "$@" > "$P/bench_$tag.log" 2>&1
 }
-B="python3 $R/bench.py --no-cpu-baseline --no-secondary"
+B="python3 $R/bench.py --no-cpu-baseline --no-secondary --no-parity"
+if [ "$PART" != "b" ]; then
 run trace    --kernel-trace --stats --output-format csv -d "$P/trace"   -- $B --steps 3 --warmup 1
 run trace_m  --kernel-trace --stats --output-format csv -d "$P/trace_m" -- $B --steps 2 --warmup 1 --mode marginal
 run fetch    --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch" -- $B --steps 1 --warmup 0
@@ -25,11 +28,25 @@ run sq2      --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BA
 run sq1m     --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d "$P/sq1m" -- $B --steps 1 --warmup 0 --batch 1024 --mode marginal
 run sq2m     --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d "$P/sq2m" -- $B --steps 1 --warmup 0 --batch 1024 --mode marginal
 run fetchm   --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetchm" -- $B --steps 1 --warmup 0 --batch 1024 --mode marginal
-for c in c2 c4 c5; do
+fi
+if [ "$PART" != "a" ]; then
+for c in c2 c5; do
     run trace_$c --kernel-trace --stats --output-format csv -d "$P/trace_$c" -- $B --config $c --steps 3 --warmup 1
     run fetch_$c --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch_$c" -- $B --config $c --steps 1 --warmup 0
     run write_$c --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write_$c" -- $B --config $c --steps 1 --warmup 0
 done
+# C4: each of its five equations (Marginal/MHD_Residuals_CP.py:225-278)
+for e in induction continuity momentum energy gauss; do
+    run trace_c4_$e --kernel-trace --stats --output-format csv -d "$P/trace_c4_$e" -- $B --config c4 --equation $e --steps 3 --warmup 1
+    run fetch_c4_$e --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch_c4_$e" -- $B --config c4 --equation $e --steps 1 --warmup 0
+    run write_c4_$e --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write_c4_$e" -- $B --config c4 --equation $e --steps 1 --warmup 0
+done
+# the six-field functors: instruction mix and waits
+for e in momentum energy; do
+    run sq1_c4_$e --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d "$P/sq1_c4_$e" -- $B --config c4 --equation $e --steps 1 --warmup 0
+    run sq2_c4_$e --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d "$P/sq2_c4_$e" -- $B --config c4 --equation $e --steps 1 --warmup 0
+done
+fi
 # gpurun copies back at most 64 MiB: the per-dispatch traces are not needed once rocprofv3 has written the statistics
 find "$P" -name "*_kernel_trace.csv" -delete
 echo done >&2
