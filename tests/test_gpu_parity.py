@@ -2065,6 +2065,30 @@ def test_constant_and_nan_columns_alone_in_their_tile(gpu, n):
     assert torch.equal(got[:, ok], want[:, ok]), (n, (got[:, ok] != want[:, ok]).nonzero()[:5].tolist())
 
 
+@pytest.mark.parametrize("n", [250, 384, 512, 700, 1000, 1500, 2048])
+def test_register_tile_lists_share_a_pool(gpu, n):
+    """Round 5: the candidate lists of a cell are segments of ONE pool (exactly `count` entries each, taken with an atomic
+    add on the cell's pool pointer; 144 / 288 entries per cell), tagged in the histogram word of their row.  Quantised
+    scores put 12-30 equal-bucket elements behind every rank: lists of every length up to the pick's 31, cells whose ten
+    lists together exhaust the pool (the tile then goes to the streaming form), ranks of a cell that share a row (one list,
+    two owners), next to ordinary cells - bit-exact against torch.sort in all of them."""
+    from cp_pre_amd import inductive_cp as icp
+    g = torch.Generator(device=gpu).manual_seed(9100 + n)
+    M = 64 * 12 + 5
+    s = torch.randn(n, M, device=gpu, generator=g).abs_()
+    for j, levels in enumerate((n // 12, n // 20, n // 28, n // 34, 3, 9)):          # elements per level: 12, 20, 28, 34, n/3, n/9
+        cols = slice(64 * (2 * j) + 3, 64 * (2 * j) + 40)                               # a run of cells in every other tile
+        q = torch.rand(n, cols.stop - cols.start, device=gpu, generator=g)
+        s[:, cols] = torch.floor(q * max(levels, 1)) / max(levels, 1) + 0.25
+    alphas = [float(a) for a in icp.ALPHA_LEVELS]
+    ks = [icp.kth_index(n, n, a) for a in alphas]
+    got = icp.kth_axis0(s, ks)
+    want = torch.sort(s, dim=0).values[ks]
+    assert torch.equal(got, want), (n, (got != want).nonzero()[:5].tolist())
+    ks2 = sorted({0, 1, 2, n // 2, n // 2 + 1, n - 3, n - 2, n - 1})                     # neighbouring ranks: shared rows
+    assert torch.equal(icp.kth_axis0(s, ks2), torch.sort(s, dim=0).values[ks2])
+
+
 @pytest.mark.parametrize("n,S", [(300, 20_000_000), (300, 23_000_000), (1100, 10_000_000), (1100, 11_500_000),
                                  (200, 5_000_000), (200, 5_600_000), (512, 21_000_000)])
 def test_select_rows_many_megabytes_apart(gpu, n, S):
