@@ -962,7 +962,7 @@ __device__ __forceinline__ unsigned int kt_pick(const unsigned int *pool, unsign
 // through an empty descriptor), and from there on NOTHING tests a row again: the hardware min / max skip a NaN, a NaN's
 // histogram row is 0 (v_cvt_u32_f32), which no rank reads and no list wants.  Row 0 thereby counts padding + NaNs, so
 // "does the column hold a NaN" is one comparison per cell (row 0 != the tile's padding) instead of a test per element.
-// The last quarter of the registers is skipped as a block when no thread has a row in it (n <= 3/4 of the capacity).
+// Registers beyond the LIVE ones (a thread's rows rounded up to whole batches) are skipped batch by batch.
 template <int LOG_NB1, int R, int WGS, bool C32>
 __global__ void __launch_bounds__(1024, 4 * WGS)
 kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, long long ntiles, const KAList kl,
@@ -972,10 +972,10 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     constexpr int NB1 = Cfg::NB1, CAP = Cfg::CAP, POOL = Cfg::POOL;
     constexpr int W = C32 ? 32 : 64;                  // cells per tile
     constexpr int RPT = C32 ? 32 : KA_WAVES;          // rows between a thread's registers u and u + 1
-    constexpr int Q = R / 4, RLO = R / 2 + Q;         // registers [RLO, R): skipped when n <= RLO * RPT
+    constexpr int Q = R / 4;
     constexpr int BATCH = Q % 8 == 0 ? 8 : Q % 6 == 0 ? 6 : 4;
     constexpr int GRP = BATCH == 6 ? 3 : 4;           // rows that share a descriptor base (host: (GRP - 1) rows' stride < 2^32 bytes)
-    static_assert(Q % 2 == 0 && RLO % BATCH == 0 && Q % BATCH == 0 && BATCH % GRP == 0, "register blocks");
+    static_assert(Q % 2 == 0 && (R / 2) % BATCH == 0 && Q % BATCH == 0 && BATCH % GRP == 0 && BATCH % 2 == 0, "register blocks");
     __shared__ unsigned int lds[Cfg::TOTAL];
     unsigned int *hist = lds, *lists = lds + Cfg::LIST_AT, *side = lds + Cfg::SIDE_AT;
     unsigned int *win = side + Cfg::WIN_AT, *cnt = side + Cfg::CNT_AT, *ptr = side + Cfg::PTR_AT, *flg = side + Cfg::FLG_AT;
@@ -983,8 +983,16 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     const int nk = kl.nk;
     const int S4 = (int)(S * 4);                       // (C32: the second row of a load, in bytes; host: S < 2^29)
     const unsigned int step4 = (unsigned int)(S * 4 * RPT);      // bytes from a thread's register u to u + 1 (host: 3 of them + a row pair < 2^32)
-    const bool hiq = (n + RPT - 1) / RPT > RLO;        // some thread has a row in the last quarter (block-uniform)
-    const unsigned int pads = (unsigned)((hiq ? R : RLO) * RPT - n);       // padding rows per cell
+    // LIVE registers (block-uniform): a thread's rows, rounded up to whole batches - the sweeps run over these and skip the
+    // rest batch by batch (rounds 3-4 skipped the last quarter of the registers or nothing: just above a register size a
+    // quarter of every sweep was padding - n = 600: 42 of 48 registers live, n = 1200: 40 of 64)
+    // FIRST: the registers every n this instantiation serves fills (no test); STEP: the granularity of the skipping beyond
+    // (two workgroups per CU: the last quarter or nothing - a batch there IS a quarter, and the extra tests cost 2-3 %)
+    constexpr int STEP = WGS == 2 ? Q : BATCH;
+    constexpr int FIRST = C32 ? R / 2 + BATCH : R / 2 + Q;
+    static_assert(FIRST % BATCH == 0 && (R - FIRST) % STEP == 0 && STEP % BATCH == 0, "live-register blocks");
+    const int live = max(FIRST, min(R, ((n + RPT - 1) / RPT + STEP - 1) / STEP * STEP));
+    const unsigned int pads = (unsigned)(live * RPT - n);                  // padding rows per cell
 
     // one-time LDS state: empty window (the list fill pointers and the pool pointers are set tile by tile)
     for (int i = tid0; i < Cfg::SIDE_WORDS; i += 1024) side[i] = i < 64 ? 0xffffffffu : 0u;
@@ -1021,7 +1029,7 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
         const int loff = lane_off(tid0 & 63, vb);
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            v[u] = (u < RLO || hiq) ? kt_row(p, records(wave0, u, vb), loff) : 0.f;
+            v[u] = (u < FIRST || u < live) ? kt_row(p, records(wave0, u, vb), loff) : 0.f;
             p += (long long)RPT * S;
         }
     }
@@ -1057,19 +1065,22 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
                 mx = kt_max3(mx, v[u], v[u + 1]);
             }
 #pragma unroll
-            for (int u = R / 2; u < RLO; u += 2) {
+            for (int u = R / 2; u < FIRST; u += 2) {
                 pad(u);
                 pad(u + 1);
                 mn = kt_min3(mn, v[u], v[u + 1]);
                 mx = kt_max3(mx, v[u], v[u + 1]);
             }
-            if (hiq) {
 #pragma unroll
-                for (int u = RLO; u < R; u += 2) {
-                    pad(u);
-                    pad(u + 1);
-                    mn = kt_min3(mn, v[u], v[u + 1]);
-                    mx = kt_max3(mx, v[u], v[u + 1]);
+            for (int u0 = FIRST; u0 < R; u0 += STEP) {
+                if (u0 < live) {
+#pragma unroll
+                    for (int u = u0; u < u0 + STEP; u += 2) {
+                        pad(u);
+                        pad(u + 1);
+                        mn = kt_min3(mn, v[u], v[u + 1]);
+                        mx = kt_max3(mx, v[u], v[u + 1]);
+                    }
                 }
             }
             // (a column of NaNs leaves a NaN, whose key is above every number's: "not a finite window" below)
@@ -1106,15 +1117,18 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             const unsigned int inc = C32 ? 1u : Ctr<false>::inc(lane);
             char *hb = reinterpret_cast<char *>(hist + (lane & 31));
 #pragma unroll
-            for (int u = 0; u < RLO; ++u) {
+            for (int u = 0; u < FIRST; ++u) {
                 const unsigned int row = kt_frow(v[u], sf, vlo);
                 atomicAdd(reinterpret_cast<unsigned int *>(hb + (row << 7)), inc);          // word row * 32 + (lane & 31)
             }
-            if (hiq) {
 #pragma unroll
-                for (int u = RLO; u < R; ++u) {
-                    const unsigned int row = kt_frow(v[u], sf, vlo);
-                    atomicAdd(reinterpret_cast<unsigned int *>(hb + (row << 7)), inc);
+            for (int u0 = FIRST; u0 < R; u0 += STEP) {
+                if (u0 < live) {
+#pragma unroll
+                    for (int u = u0; u < u0 + STEP; ++u) {
+                        const unsigned int row = kt_frow(v[u], sf, vlo);
+                        atomicAdd(reinterpret_cast<unsigned int *>(hb + (row << 7)), inc);
+                    }
                 }
             }
         }
@@ -1247,10 +1261,13 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
                 }
             };
 #pragma unroll
-            for (int u0 = 0; u0 < RLO; u0 += BATCH) batch(u0);
-            if (hiq) {
+            for (int u0 = 0; u0 < FIRST; u0 += BATCH) batch(u0);
 #pragma unroll
-                for (int u0 = RLO; u0 < R; u0 += BATCH) batch(u0);
+            for (int u0 = FIRST; u0 < R; u0 += STEP) {
+                if (u0 < live) {
+#pragma unroll
+                    for (int u1 = u0; u1 < u0 + STEP; u1 += BATCH) batch(u1);
+                }
             }
         }
         lds_barrier();
