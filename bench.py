@@ -449,10 +449,56 @@ def measure_others(dev):
                                slab_axis="x")
         if batch is not None:
             cfg = dict(cfg, title="C5 1D Burgers residual (Joint/Burgers_Residuals_CP.py) at its single-GPU size")
-        line = run_secondary(a, cfg, dev, None, 0, 1, {})
-        found[key] = secondary_entry(line)
+        try:
+            line = run_secondary(a, cfg, dev, None, 0, 1, {})
+            found[key] = secondary_entry(line)
+        except Exception as e:                                    # (a secondary must never cost the contract line)
+            found[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
         torch.cuda.empty_cache()
     return found
+
+
+def measure_c1_graph(dev, reps=200):
+    """C1 is launch-bound (a 40 us kernel + a 40 us select behind ~10 host launches): the same step - fused residual with
+    the |.| epilogue -> per-cell q-hat at the 10 levels - recorded ONCE into a HIP graph and replayed
+    (tests/test_gpu_parity.py::test_marginal_step_is_hip_graph_capturable checks a replay against an eager run)."""
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    from cp_pre_amd import residuals as R
+    B, T, X = CONFIGS["c1"]["shape"]
+    alphas = [float(a) for a in icp.ALPHA_LEVELS]
+    u = synth_(torch.empty(B, T, X, device=dev), 1) + 1.0
+    op = R.Advection(1.0, 0.005, 0.01, disc=2)
+
+    def step():
+        return pipeline.marginal_qhat(op.residual(u, boundary=True, absolute=True), alphas)
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    eager = timed(step, reps)
+    cur = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        step()
+    cur.wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        q = step()
+    graph.replay()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(q, step()))
+    replay = timed(graph.replay, reps)
+    return {"workload": f"C1 [{B},{T},{X}] marginal step (residual + per-cell q-hat x10) as ONE HIP graph replay", "steps": reps,
+            "ms_per_step_eager": eager, "ms_per_step_graph": replay, "cells_per_s_graph": B * T * X / (replay * 1e-3),
+            "replay_equals_eager": same}
 
 
 def one_rank_group(dev):
@@ -922,6 +968,11 @@ def main():
                 sec["c3_strong_rank8"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 torch.cuda.empty_cache()
             sec.update(measure_others(dev))
+            try:                                                  # (last: a capture that fails must not cost the others)
+                note("secondary c1_graph")
+                sec["c1_graph"] = measure_c1_graph(dev)
+            except Exception as e:
+                sec["c1_graph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline (the oracle on the host cores)")
