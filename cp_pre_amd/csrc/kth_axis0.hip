@@ -144,7 +144,11 @@ struct KACfg {
     static constexpr int BM_AT = KA_MAXK * LS * 64;
     static constexpr int COLLECT_WORDS = BM_AT + BM_WORDS;
     static constexpr int W1 = FIRST_WORDS > COLLECT_WORDS ? FIRST_WORDS : COLLECT_WORDS;
-    static constexpr int WORDS = W1 > KA_LATE_WORDS ? W1 : KA_LATE_WORDS;
+    // TAGS (round 5, n <= 4096 with 1024 buckets): the fast form keeps "which list wants this row" in the histogram words
+    // and its lists in a pool behind them (ka_fast_tags below) - it takes all 160 KiB the CU has
+    static constexpr bool TAGS = LOG_NB1 == 10 && !WIDE && LSX == 0;
+    static constexpr int WORDS0 = W1 > KA_LATE_WORDS ? W1 : KA_LATE_WORDS;
+    static constexpr int WORDS = TAGS ? 40960 : WORDS0;
     static constexpr int U = WG_PER_CU == 2 ? KA_U_A : KA_U_B;             // rows per batch of loads
     static constexpr int BITS = WIDE ? 5 : 6;                               // 10 slots x 2^BITS bins x CW words = 80 KiB
     static_assert(WORDS * 4 * WG_PER_CU <= 160 * 1024, "does not fit the 160 KiB LDS");
@@ -538,6 +542,202 @@ __device__ __forceinline__ bool ka_fast(const float *__restrict__ col, bool cok,
     return true;
 }
 
+// ---- the fast form with the register tiles' bookkeeping (round 5; 2048 < n <= 4096, 1024 buckets, one workgroup per CU).
+// Same two sweeps as ka_fast, same window, same rows; what changed is everything between and around them:
+//   * "which list, if any, wants this row of this cell" is a 4-bit tag above the count in the histogram word of the row (a
+//     count is at most n - 1 <= 4095 here: the sample that defines the window is part of the column, so two rows are
+//     occupied) - written by the rank's owner with a compare-and-swap, read back by the collect sweep from the word the
+//     first sweep incremented: conflict-free (the byte map's reads fell on random banks: a third of the LDS cycles), and no
+//     70 KB map to clear, no published rows, no prefix compaction (three barriers less);
+//   * the lists are exact-size segments of one pool per cell (the histogram knows the sizes): no 80 KB of lists to
+//     initialise; the pool lies behind the histogram (which stays live through the collect sweep) and shares its first
+//     words with the group sums of the narrowing (dead by then);
+//   * the owner sorts its <= 31 candidates in registers (a network) instead of counting them against each other in LDS.
+// Returns as ka_fast does; nothing it leaves behind matters to the general form, which clears what it uses.
+template <int N, int P, int NW> __device__ __forceinline__ void ks_sort(unsigned int (&v)[NW]);
+template <int N>
+__device__ __forceinline__ unsigned int ka_pick_net(const unsigned int *pool, unsigned int base, unsigned int count, unsigned int myr)
+{
+    unsigned int c[N];
+    const char *p = reinterpret_cast<const char *>(pool) + base;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const unsigned int j = min((unsigned)i, count - 1u);                  // (never beyond my own segment: the pool has no slack)
+        const unsigned int x = f2key(__uint_as_float(*reinterpret_cast<const unsigned int *>(p + j * 256u)));
+        c[i] = (unsigned)i < count ? x : 0xffffffffu;
+    }
+    ks_sort<N, 1, N>(c);
+    unsigned int ans = c[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) ans = myr == (unsigned)i ? c[i] : ans;
+    return ans;
+}
+
+#ifdef KA_DEBUG_FAIL
+__device__ unsigned long long ka_debug_fail[8];
+#endif
+template <int LOG_NB1>
+__device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool cok, int n, long long M, int nk, float sf, float vlo,
+                                             unsigned int *hist, unsigned int k0, unsigned int &ans, bool &below, int lane,
+                                             int wave, int tid)
+{
+    using Cfg = KACfg<LOG_NB1, false, 0>;
+    // 896 buckets, not 1024: the 16 KB that frees take the pool from 116 to 180 entries per cell.  With 116, 20 % of the
+    // tiles of n = 4096 |N(0,1)| scores exhausted some cell's pool (ten lists of ~9 around the mode: 75 on average, 125
+    // in the fullest of a tile's 64 cells; tools/exp/stream_fail_probe.py) and went to the general form - slower than the
+    // byte-map form this replaces; a bucket is 14 % fuller for it, far below the 31 a list may hold.
+    constexpr int NB1 = 896, U = Cfg::U, CAP = 31, GB = NB1 / KA_WAVES;
+    static_assert(NB1 % KA_WAVES == 0 && NB1 <= (1 << LOG_NB1), "buckets");
+    sf = sf > 0.f ? sf * ((float)(NB1 - 1) / (float)((1 << LOG_NB1) - 1)) : sf;      // (ka_window scaled the window to 2^LOG_NB1 - 1 rows)
+    constexpr int HIST_WORDS = (NB1 + 1) * 32;                 // rows 0 (below the window) .. NB1 (at or beyond its end)
+    constexpr int POOL_AT = HIST_WORDS;                        // (its first 1024 words: the narrowing's group sums)
+    constexpr int SIDE_WORDS = KA_MAXK * 64 + 64 + KA_WAVES;   // list fill pointers, pool pointers, per-wave flags
+    constexpr int POOL = (Cfg::WORDS - HIST_WORDS - SIDE_WORDS) / 64;
+    constexpr int SIDE_AT = POOL_AT + POOL * 64;
+    static_assert(POOL >= 96 && SIDE_AT + SIDE_WORDS <= Cfg::WORDS, "pool");
+    unsigned int *pool = hist + POOL_AT, *cnt = hist + SIDE_AT, *ptr = cnt + KA_MAXK * 64, *flg = ptr + 64;
+    const bool state = wave < nk;
+    const int l31 = lane & 31, sh = 16 * (lane >> 5), tsh = 12 + sh;
+    for (int i = tid; i < HIST_WORDS; i += 1024) hist[i] = 0u;
+    if (tid < 64) ptr[tid] = 0u;
+    __syncthreads();
+    const unsigned int inc = 1u << sh;
+    unsigned long long nan = 0ull;
+    constexpr int KEEP = KA_KEEP;
+    static_assert(KEEP * KA_WAVES <= 2048 && KEEP % U == 0, "kept rows");
+    float kept[KEEP];
+    char *hb = reinterpret_cast<char *>(hist + l31);           // word (row, my cell): hb + row * 128
+    auto count1 = [&](float v) __attribute__((always_inline)) {
+        nan |= __ballot(v != v);
+        atomicAdd(reinterpret_cast<unsigned int *>(hb + (ka_frow<NB1>(v, sf, vlo) << 7)), inc);
+    };
+    if (cok) {
+        const int loff = lane * 4;
+        const float *p = col + (long long)wave * M;
+#pragma unroll
+        for (int u0 = 0; u0 < KEEP; u0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { kept[u0 + u] = ka_row(p, loff); p += (long long)KA_WAVES * M; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) count1(kept[u0 + u]);
+        }
+    }
+    ka_sweep<U>(col, cok, n, M, wave, count1, KEEP);
+    __syncthreads();
+
+    // ---- narrowing (ka_narrow_first with 12-bit counts: an owner that is done may already have tagged a word)
+    unsigned int myr = k0, count = 0;
+    int digit = 0;
+    bool outside = false;
+    {
+        unsigned int gs = 0;
+        const unsigned int *h = hist + (1 + wave * GB) * 32 + l31;
+#pragma unroll 8
+        for (int u = 0; u < GB; ++u) gs += h[u * 32];          // (both cells of the word at once: a sum is at most n)
+        pool[wave * 64 + lane] = (gs >> sh) & 0xffffu;
+    }
+    __syncthreads();
+    if (state) {
+        const unsigned int under = (hist[l31] >> sh) & 0xfffu;
+        outside = myr < under;
+        const unsigned int r = outside ? 0u : myr - under;
+        unsigned int run = 0, cum = 0;
+        int g = 0;
+#pragma unroll
+        for (int u = 0; u < KA_WAVES; ++u) {
+            run += pool[u * 64 + lane];
+            const bool le = run <= r;
+            g += le;
+            cum = le ? run : cum;
+        }
+        g = min(g, KA_WAVES - 1);
+        const unsigned int *h = hist + (1 + g * GB) * 32 + l31;
+        run = cum;
+        int d = 0;
+#pragma unroll 8
+        for (int u = 0; u < GB; ++u) {
+            run += (h[u * 32] >> sh) & 0xfffu;
+            const bool le = run <= r;
+            d += le;
+            cum = le ? run : cum;
+        }
+        digit = g * GB + min(d, GB - 1);                       // bucket digit lives in row 1 + digit
+        outside = outside || digit == NB1 - 1;                 // (row NB1: at or beyond the window's end)
+        count = (h[min(d, GB - 1) * 32] >> sh) & 0xfffu;
+        myr = r - cum;
+    }
+    bool many = state && count > (unsigned)CAP;
+    const bool bad = state && (outside || sf < 0.f);
+    __syncthreads();                                           // every owner has read the group sums: the pool is free
+    unsigned int *a = hist + (digit + 1) * 32 + l31;
+    if (state && !many && !bad) {
+        unsigned int old = *a;
+        if (((old >> tsh) & 15u) == 0u) {
+            const unsigned int start = atomicAdd(&ptr[lane], count);
+            if (start + count > (unsigned)POOL) {
+                many = true;                                   // (pool exhausted: ties - the general form)
+            } else {
+                cnt[wave * 64 + lane] = (start * 64u + (unsigned)lane) * 4u;
+                for (;;) {
+                    const unsigned int prev = atomicCAS(a, old, old | ((unsigned)(wave + 1) << tsh));
+                    if (prev == old || ((prev >> tsh) & 15u) != 0u) break;
+                    old = prev;
+                }
+            }
+        }
+    }
+    const unsigned int w = (__ballot(many) != 0 ? 1u : 0u) | (__ballot(bad) != 0 ? 2u : 0u) | (nan != 0ull ? 4u : 0u);
+    if (lane == 0) flg[wave] = w;
+    int cmax = state ? (int)count : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+    cmax = __builtin_amdgcn_readfirstlane(cmax);
+    __syncthreads();
+    unsigned int fl = flg[lane & (KA_WAVES - 1)];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) fl |= __shfl_xor(fl, o);
+    fl = __builtin_amdgcn_readfirstlane(fl);
+    below = (fl & 2u) != 0u;
+#ifdef KA_DEBUG_FAIL
+    if (tid == 0) {
+        atomicAdd(&ka_debug_fail[0], 1ull);
+        if (fl & 1u) atomicAdd(&ka_debug_fail[1], 1ull);
+        if (fl & 2u) atomicAdd(&ka_debug_fail[2], 1ull);
+        if (fl & 4u) atomicAdd(&ka_debug_fail[3], 1ull);
+        atomicAdd(&ka_debug_fail[4], (unsigned long long)cmax);
+        atomicMax(&ka_debug_fail[5], (unsigned long long)cmax);
+        atomicMax(&ka_debug_fail[6], (unsigned long long)ptr[0]);
+    }
+#endif
+    if (fl) return false;
+    const int myslot = state ? (int)((*a >> tsh) & 15u) - 1 : 0;
+
+    // ---- collect: an element whose row is tagged joins the tagged list (inside its segment always: the histogram counted)
+    char *cb = reinterpret_cast<char *>(cnt + lane) - 256;     // fill pointer of list m - 1 of my cell: cb + m * 256
+    char *lb = reinterpret_cast<char *>(pool);
+    auto collect = [&](float v) __attribute__((always_inline)) {
+        const unsigned int m = __builtin_amdgcn_ubfe(*reinterpret_cast<const unsigned int *>(hb + (ka_frow<NB1>(v, sf, vlo) << 7)), (unsigned)tsh, 4u);
+        if (m) {
+            const unsigned int pos = atomicAdd(reinterpret_cast<unsigned int *>(cb + (m << 8)), 256u);
+            *reinterpret_cast<float *>(lb + pos) = v;
+        }
+    };
+    if (cok) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) collect(kept[u]);
+    }
+    ka_sweep<U>(col, cok, n, M, wave, collect, KEEP);
+    __syncthreads();
+    if (state) {                                               // (whole waves: cmax is theirs)
+        const unsigned int base = cnt[myslot * 64 + lane] - count * 256u;
+        if (count == 0u) ans = 0u;                             // (cannot happen for a rank inside its window; defined anyway)
+        else if (cmax <= 8) ans = ka_pick_net<8>(pool, base, count, myr);
+        else if (cmax <= 16) ans = ka_pick_net<16>(pool, base, count, myr);
+        else ans = ka_pick_net<32>(pool, base, count, myr);
+    }
+    return true;
+}
+
 // ---- step 1, general form: buckets (key - klo) >> shift (clamped to the overflow bucket NB1-1) in rows
 // 0..NB1-1, row NB1 = key < klo.  `window`: a rank that lands in the overflow bucket or below the window is
 // reported through `outside`.  Returns (block-uniform) whether some pair has more than CAP elements left.
@@ -683,7 +883,14 @@ __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long
     bool outside = false;
     if (fast) {
         unsigned int key = 0u;
-        if (ka_fast<LOG_NB1, WIDE, LSX>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid)) {
+        bool done;
+        if constexpr (Cfg::TAGS) {
+            if (n <= 4096) done = ka_fast_tags<LOG_NB1>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
+            else done = ka_fast<LOG_NB1, WIDE, LSX>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
+        } else {
+            done = ka_fast<LOG_NB1, WIDE, LSX>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
+        }
+        if (done) {
             if (state && cok) out[(long long)kl.o[wave] * OS + c] = key2f(key);
             return;
         }
@@ -1695,8 +1902,11 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     // (rows up to three register steps apart share a descriptor base and are told apart by a 32-bit scalar byte offset: 48 S x 4
     // bytes < 2^32, i.e. rows of up to 22 M cells; beyond, the streaming form)
     const bool tile_ok = S * 192 + 256 < (1LL << 32);
-    if (n <= 256 && tile_ok) return launch_kth_tile<8, 16, 2>(KA_ARGS);
-    if (n <= 384 && tile_ok) return launch_kth_tile<8, 24, 2>(KA_ARGS);
+#ifndef KT_NB_SMALL
+#define KT_NB_SMALL 8
+#endif
+    if (n <= 256 && tile_ok) return launch_kth_tile<KT_NB_SMALL, 16, 2>(KA_ARGS);
+    if (n <= 384 && tile_ok) return launch_kth_tile<KT_NB_SMALL, 24, 2>(KA_ARGS);
     if (n <= 512 && tile_ok) return launch_kth_tile<8, 32, 2>(KA_ARGS);
     if (n <= 768 && tile_ok) return launch_kth_tile<9, 48, 1>(KA_ARGS);
     if (n <= 1024 && tile_ok) return launch_kth_tile<9, 64, 1>(KA_ARGS);
@@ -1714,6 +1924,12 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
 #undef KA_ARGS
 }
 
+#ifdef KA_DEBUG_FAIL
+extern "C" int pre_debug_ka_fail(void *dst)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ka_debug_fail), sizeof(ka_debug_fail));
+}
+#endif
 #ifdef KT_CLOCK
 extern "C" int pre_debug_kt_clock(void *dst, size_t bytes)
 {

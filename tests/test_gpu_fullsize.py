@@ -28,6 +28,7 @@ RES_TOL = 1e-5          # north_star: residuals within 1e-5 rel fp32 (tensor-sca
 def gpu():
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
+    torch.cuda.empty_cache()                 # (what earlier tests of the session left in the caching allocator is not "in use")
     free = torch.cuda.mem_get_info()[0]
     # three BASELINE configurations ride on these tests: a box that cannot hold them is a FAILED run, not a skipped one
     # (under `-m gpu` a skip would silently un-exercise C3, C4 and C5)
