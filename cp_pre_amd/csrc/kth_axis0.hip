@@ -249,6 +249,40 @@ __device__ __forceinline__ void ka_sweep(const float *__restrict__ col, bool cok
     }
 }
 
+// the same sweep handing the functor H rows at a time: g(v, nv) with v[0 .. nv) inside the column (nv wave-uniform)
+template <int U, int H, class G>
+__device__ __forceinline__ void ka_sweep_h(const float *__restrict__ col, bool cok, int n, long long M, int wave, G &&g, int first = 0)
+{
+    static_assert(U % H == 0, "half batches");
+    if (!cok) return;
+    constexpr int STEP = U * KA_WAVES, SPAN = (U - 1) * KA_WAVES;
+    const int loff = (int)(threadIdx.x & 63u) * 4;
+    const long long stride = (long long)KA_WAVES * M;
+    int i = wave + first * KA_WAVES;
+    const float *p = col + (long long)i * M;
+    for (; i + SPAN < n; i += STEP) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { v[u] = ka_row(p, loff); p += stride; }
+#pragma unroll
+        for (int h = 0; h < U; h += H) g(*reinterpret_cast<float(*)[H]>(&v[h]), H);
+    }
+    if (i < n) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const __amdgpu_buffer_rsrc_t r =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, i + u * KA_WAVES < n ? 256 : 0, 0x00020000);
+            v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, loff, 0, 0));
+            p += stride;
+        }
+        const int left = (n - i + KA_WAVES - 1) / KA_WAVES;       // rows of mine in this batch (wave-uniform)
+#pragma unroll
+        for (int h = 0; h < U; h += H)
+            if (h < left) g(*reinterpret_cast<float(*)[H]>(&v[h]), left - h < H ? left - h : H);
+    }
+}
+
 // where a sweep takes the tile's elements from: memory (every sweep re-reads the column tile)
 struct HbmSrc {
     const float *col;
@@ -591,7 +625,7 @@ __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool
     sf = sf > 0.f ? sf * ((float)(NB1 - 1) / (float)((1 << LOG_NB1) - 1)) : sf;      // (ka_window scaled the window to 2^LOG_NB1 - 1 rows)
     constexpr int HIST_WORDS = (NB1 + 1) * 32;                 // rows 0 (below the window) .. NB1 (at or beyond its end)
     constexpr int POOL_AT = HIST_WORDS;                        // (its first 1024 words: the narrowing's group sums)
-    constexpr int SIDE_WORDS = KA_MAXK * 64 + 64 + KA_WAVES;   // list fill pointers, pool pointers, per-wave flags
+    constexpr int SIDE_WORDS = KA_MAXK * 64 + 64 + KA_WAVES + 64;      // list fill pointers, pool pointers, per-wave flags, scratch
     constexpr int POOL = (Cfg::WORDS - HIST_WORDS - SIDE_WORDS) / 64;
     constexpr int SIDE_AT = POOL_AT + POOL * 64;
     static_assert(POOL >= 96 && SIDE_AT + SIDE_WORDS <= Cfg::WORDS, "pool");
@@ -715,18 +749,30 @@ __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool
     // ---- collect: an element whose row is tagged joins the tagged list (inside its segment always: the histogram counted)
     char *cb = reinterpret_cast<char *>(cnt + lane) - 256;     // fill pointer of list m - 1 of my cell: cb + m * 256
     char *lb = reinterpret_cast<char *>(pool);
-    auto collect = [&](float v) __attribute__((always_inline)) {
-        const unsigned int m = __builtin_amdgcn_ubfe(*reinterpret_cast<const unsigned int *>(hb + (ka_frow<NB1>(v, sf, vlo) << 7)), (unsigned)tsh, 4u);
-        if (m) {
-            const unsigned int pos = atomicAdd(reinterpret_cast<unsigned int *>(cb + (m << 8)), 256u);
-            *reinterpret_cast<float *>(lb + pos) = v;
+    // H rows at a time, branch-free (as in the register tiles): the H histogram words are read together, every element issues
+    // its returning add (of 0, on a word that ignores it, when its row is untagged) and its store (to a scratch word of its
+    // lane): one LDS round trip per phase and half batch instead of two per element
+    constexpr int H = 8;
+    char *dummy = reinterpret_cast<char *>(flg + KA_WAVES + lane);
+    auto collect = [&](float (&v)[H], int nv) __attribute__((always_inline)) {
+        unsigned int m[H];
+#pragma unroll
+        for (int u = 0; u < H; ++u) m[u] = *reinterpret_cast<const unsigned int *>(hb + (ka_frow<NB1>(v[u], sf, vlo) << 7));
+        bool hit[H];
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            m[u] = __builtin_amdgcn_ubfe(m[u], (unsigned)tsh, 4u);
+            hit[u] = m[u] != 0u && u < nv;                         // (rows beyond n came back 0.0 through an empty descriptor)
+            m[u] = atomicAdd(reinterpret_cast<unsigned int *>(cb + ((hit[u] ? m[u] : 0u) << 8)), hit[u] ? 256u : 0u);
         }
+#pragma unroll
+        for (int u = 0; u < H; ++u) *reinterpret_cast<float *>(hit[u] ? lb + m[u] : dummy) = v[u];
     };
     if (cok) {
 #pragma unroll
-        for (int u = 0; u < KEEP; ++u) collect(kept[u]);
+        for (int u = 0; u < KEEP; u += H) collect(*reinterpret_cast<float(*)[H]>(&kept[u]), H);
     }
-    ka_sweep<U>(col, cok, n, M, wave, collect, KEEP);
+    ka_sweep_h<U, H>(col, cok, n, M, wave, collect, KEEP);
     __syncthreads();
     if (state) {                                               // (whole waves: cmax is theirs)
         const unsigned int base = cnt[myslot * 64 + lane] - count * 256u;
