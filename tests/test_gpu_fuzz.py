@@ -266,6 +266,54 @@ def test_fuzz_round2_select_paths(gpu):
         assert torch.equal(got, ref), (case, n, M, kind, ks)
 
 
+def test_fuzz_round5_select_tags_and_pools(gpu):
+    """Round 5 moved the "which list wants this row" bookkeeping of the register tiles (241 <= n <= 2048) and of the
+    streaming form between 2049 and 4096 rows into the histogram words (a tag above the count) and made the candidate
+    lists exact-size segments of a pool: random n across both ranges and their edges, partial last tiles, distributions
+    that fill lists of every length (quantised, bimodal, heavy-tailed, nearly constant), ties that exhaust pools, NaN /
+    +-inf sprinkled in a few cells, random and neighbouring ranks - against torch.sort (NaN cells: every rank NaN)."""
+    from cp_pre_amd import inductive_cp as icp
+    rng = np.random.default_rng(5005)
+    g = torch.Generator(device=gpu).manual_seed(5005)
+    ns = [241, 255, 256, 257, 300, 383, 384, 385, 500, 512, 513, 600, 767, 768, 769, 1000, 1024, 1025, 1200, 1536, 1537, 2000, 2047,
+          2048, 2049, 2100, 2500, 3000, 3333, 3840, 4000, 4095, 4096]
+    for case in range(max(24, CASES)):
+        n = int(rng.choice(ns))
+        M = int(rng.choice([33, 64, 65, 130, 200, 641]))
+        kind = str(rng.choice(["abs", "quant", "bimodal", "log", "narrow", "ties", "sorted"]))
+        s = torch.randn(n, M, device=gpu, generator=g)
+        if kind == "abs":
+            s = s.abs() * (0.1 + 10 * torch.rand(M, device=gpu, generator=g))
+        elif kind == "quant":                                   # levels with 8 .. 40 elements each: long lists, full pools
+            lv = max(2, n // int(rng.choice([8, 14, 22, 30, 40])))
+            s = torch.floor(torch.rand(n, M, device=gpu, generator=g) * lv) / lv - 0.3
+        elif kind == "bimodal":
+            s = s * 0.05 + (torch.rand(n, M, device=gpu, generator=g) < 0.5).float() * 7.0
+        elif kind == "log":
+            s = torch.exp(s * float(rng.choice([1.0, 6.0, 20.0])))
+        elif kind == "narrow":
+            s = 3.0 + 1e-5 * s
+        elif kind == "ties":
+            s = torch.round(s * 2.0) / 2.0
+        elif kind == "sorted":
+            s = torch.sort(s.abs(), dim=0, descending=bool(rng.integers(0, 2))).values
+        if rng.random() < 0.4:                                  # a few special cells
+            s[int(rng.integers(0, n)), 1] = float("nan")
+            s[int(rng.integers(0, n)), min(7, M - 1)] = float("inf")
+            s[int(rng.integers(0, n)), min(9, M - 1)] = float("-inf")
+        nk = int(rng.integers(1, 11))
+        ks = sorted(int(k) for k in rng.integers(0, n, size=nk))
+        if rng.random() < 0.4:
+            k0 = int(rng.integers(0, n - 3))
+            ks = sorted(set(ks[:7]) | {k0, k0 + 1, k0 + 2})    # neighbouring ranks: shared rows, shared lists
+        got = icp.kth_axis0(s, ks)
+        ref = torch.sort(s, dim=0).values[ks]
+        nanmask = torch.isnan(s).any(dim=0)
+        assert torch.isnan(got[:, nanmask]).all(), (case, n, M, kind)
+        ok = ~nanmask
+        assert torch.equal(got[:, ok], ref[:, ok]), (case, n, M, kind, ks, (got[:, ok] != ref[:, ok]).nonzero()[:4].tolist())
+
+
 def test_fuzz_round2_flat_tap_list_and_joint_score(gpu):
     """Random tap sets on random SHORT-Nt surrogate layouts (flat tap-list kernel; 3-D and 1-D operators), and the
     cropped joint score on the same memory order (flat quad walk), against the C / numpy oracles."""
