@@ -70,6 +70,18 @@ def bench_eval():
         del xo, crop
 
 
+def bench_ceilings():
+    """What plain streaming kernels reach on this box (torch elementwise / reduction kernels, 10.7 GB per tensor): the yardsticks
+    the fused kernels' traffic is held against.  1R+1W: copy; 3R+1W (the NS momentum mix): addcmul; read-only: sum."""
+    n = 1 << 31                                            # 2^31 floats = 8.6 GB per tensor
+    a, b, c, d = (torch.empty(n, device=dev).uniform_(0.5, 1.5) for _ in range(4))
+    report("ceiling: copy d <- a (1R + 1W) 8B/elem", timeit(lambda: d.copy_(a)), 8 * n)
+    report("ceiling: add d <- a + b (2R + 1W) 12B/elem", timeit(lambda: torch.add(a, b, out=d)), 12 * n)
+    report("ceiling: addcmul d <- a + b*c (3R + 1W) 16B/elem", timeit(lambda: torch.addcmul(a, b, c, out=d)), 16 * n)
+    report("ceiling: sum(a) (1R) 4B/elem", timeit(lambda: a.sum()), 4 * n)
+    del a, b, c, d
+
+
 def bench_generic():
     """Tap sets off the 7-point star: the L1/L2-served tap-list kernel."""
     x = torch.randn(256, 10, 512, 512, device=dev)
@@ -204,5 +216,7 @@ if __name__ == "__main__" and "spatial" in sys.argv[1:]:
     bench_spatial()
 if __name__ == "__main__" and "copy" in sys.argv[1:]:
     bench_copy()
+if __name__ == "__main__" and "ceilings" in sys.argv[1:]:
+    bench_ceilings()
 if __name__ == "__main__" and "permuted" in sys.argv[1:]:
     bench_permuted()
