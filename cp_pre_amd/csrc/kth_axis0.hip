@@ -11,7 +11,8 @@
 //                     thread), exact window, every sweep out of registers, next tile prefetched in place: one read;
 //   1024 < n <= 2048  the same on 32-cell tiles, two rows per load: one read;
 //   n > 2048          kth_axis0_kernel, the STREAMING form described next: sample + 2 sweeps on typical data
-//                     (31-entry lists to n = 4096, 47-entry lists to 9216, the general radix form beyond).
+//                     (to n = 4096 with the register tiles' bookkeeping - tags in the histogram words, pooled lists:
+//                     ka_fast_tags; 47-entry lists and a bitmap to 9216; the general radix form beyond).
 //
 // A 1024-thread workgroup owns 64 adjacent cells (256 B of every sample row - narrower column tiles lose DRAM
 // efficiency fast: 128 B -> 0.7x, 64 B -> 0.3x, tools/exp/colread.hip).  lane = cell everywhere, one wave = one
@@ -998,8 +999,8 @@ kth_axis0_kernel(const float *__restrict__ s, int n, long long M, long long S, l
 // them (row u is re-loaded right after its element has been collected), so the loads are in flight during the rest
 // of that sweep, the pick and the next tile's set-up; the barriers in between fence the LDS only and leave vmcnt
 // alone.  The arithmetic is the fast form's: NB1 value-linear buckets over the window (16-bit counters, two cells
-// per word), narrow, then every element looks its row up in a byte map "which list wants this row" and the owner
-// picks its rank among the <= CAP candidates; cells whose column is constant, or holds a NaN, are settled by the window
+// per word), narrow, then every element reads "which list wants this row" from a tag above the count in the histogram word
+// of its row (KTCfg below) and the owner picks its rank among the <= CAP candidates; cells whose column is constant, or holds a NaN, are settled by the window
 // alone.  Tiles the fast form cannot finish (a bucket above CAP: ties, one huge outlier stretching the window; an
 // infinite window) are marked and redone by the streaming form above once the workgroup has finished its loop.
 __device__ __forceinline__ void lds_barrier()
@@ -1208,7 +1209,7 @@ __device__ __forceinline__ unsigned int kt_pick(const unsigned int *pool, unsign
 // bytes each), so R = 64 registers per thread hold n <= 2048 rows: the calibration sets between 1024 and 2048 samples are
 // read once too (the streaming form read them 2.13 times).  Half-width row segments cost DRAM efficiency (128 B: 0.7x,
 // tools/exp/colread.hip), but one read at 0.7 beats two at 1.  Everything per cell - window, histogram (a full 32-bit
-// counter per cell: the two half-waves of an instruction meet the LDS in different cycles), map, lists - is addressed by
+// counter per cell: the two half-waves of an instruction meet the LDS in different cycles), tags, lists - is addressed by
 // cell = lane & 31; what a rank's owner computes it computes in both half-waves alike, and the lower one writes it.
 //
 // Rows beyond n: a thread's registers u >= its row count are set to NaN when the window is taken (their loads came back 0
@@ -1483,8 +1484,8 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
                     const unsigned int row = kt_frow(v[u0 + i], sf2, vlo2);
                     m[i] = *reinterpret_cast<const unsigned int *>(hb + (row << 7));
                 }
-                // (full registers from here on: no 16-bit re-masking at the tests.  AFTER the batch's loads are issued - the
-                // same barrier inside the loop above made every map read wait for the one before it)
+                // (opaque AFTER the batch's loads are issued - the same barrier inside the loop above made every read wait
+                // for the one before it)
                 if constexpr (BATCH == 8)
                     asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]));
                 else if constexpr (BATCH == 6)
