@@ -490,6 +490,16 @@ def marginal_qhat(scores, alphas, group=None, ops=None, stage_bytes=4 << 30, ove
         return ops.kth(scores, ks)
     if tmajor:
         return _marginal_planes(scores, alphas, group, ops, overlap, stage_bytes)
+    return _marginal_cells(scores, alphas, group, ops, overlap, stage_bytes)
+
+
+def _marginal_cells(scores, alphas, group, ops, overlap, stage_bytes):
+    """The cell-run form of the sharded per-cell q-hat (any layout): runs of cells are packed into a [world, n_local,
+    cells-per-rank] send buffer, exchanged with one all-to-all per run (batch-sharded -> cell-sharded) and selected over all
+    ``n_local * world`` samples; ONE all-gather of the result at the end.  (A group of one rank exchanges with itself:
+    ``marginal_qhat`` skips this function then; the tests call it directly to run the exchange on RCCL at world size 1.)"""
+    n_local, cells = scores.shape[0], tuple(scores.shape[1:])
+    world = torch.distributed.get_world_size(group)
     if n_local * world > 0x7fffffff:
         raise ValueError(f"{n_local} x {world} calibration samples exceed the select's 32-bit sample count")
     flat = scores.reshape(n_local, -1)

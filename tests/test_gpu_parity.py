@@ -2185,6 +2185,46 @@ def test_sharded_calibration_two_ranks_on_one_gpu(gpu, tmp_path):
         assert np.array_equal(np.load(tmp_path / f"qm_{r}.npy"), qm_ref)           # order statistics: exact
 
 
+def test_marginal_exchange_overlap_on_rccl_at_world_size_one(gpu):
+    """The double-buffered, asynchronous form of the sharded marginal exchange (`overlap=True`) on REAL RCCL - at world size
+    one, the only size a one-GPU box offers: `all_to_all_single(async_op=True)` then runs on RCCL's own stream, the select
+    of run k - 1 on the compute stream, and what orders them is what orders them at any size - the collective waits for the
+    work enqueued before it (so a staging buffer is not overwritten under the select that still reads it), `Work.wait()`
+    makes the compute stream wait for the collective.  Several runs per tensor (small staging), both layouts; against the
+    group-less select, bit for bit.  (`marginal_qhat` itself skips the exchange for a group of one: `_marginal_planes` and
+    `_marginal_cells` are called directly.)"""
+    import socket
+    import torch.distributed as dist
+    from cp_pre_amd import pipeline
+    assert not dist.is_initialized()
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=gpu)
+    try:
+        group = dist.group.WORLD
+        g = torch.Generator(device=gpu).manual_seed(77)
+        alphas = [0.1, 0.5, 0.9]
+        n, T, X, Y = 300, 12, 20, 64
+        tm = pipeline.time_major(n, (T, X, Y), pad=64, device=gpu)
+        tm.copy_(torch.randn(n, T, X, Y, device=gpu, generator=g).abs_())
+        want = pipeline.marginal_qhat(tm.contiguous(), alphas)
+        one_plane = 4 * n * tm.stride(0)                                   # staging for ONE plane per run: T runs
+        for ov in (False, True):
+            for stage in (one_plane, 3 * one_plane, 1 << 30):
+                got = pipeline._marginal_planes(tm, alphas, group, pipeline.HipOps, ov, stage)
+                assert torch.equal(got, want), (ov, stage)
+        # the cell-run form (any other layout): pack -> all-to-all -> select, runs of 1000 cells
+        dense = tm.contiguous()
+        flat_want = want.reshape(len(alphas), -1)
+        for ov in (False, True):
+            q = pipeline._marginal_cells(dense, alphas, group, pipeline.HipOps, ov, 4 * n * 1000)
+            assert torch.equal(q.reshape(len(alphas), -1), flat_want), ov
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("T", [10, 20, 30, 64])
 def test_short_nt_surrogate_layout_flat_form(gpu, T):
     """The surrogate's native [BS,F,Nx,Ny,Nt] layout with the reference's T_out values (20, 30, 40; 10 = a C3 slab):
