@@ -148,8 +148,10 @@ struct KACfg {
     // TAGS (round 5, n <= 4096 with 1024 buckets): the fast form keeps "which list wants this row" in the histogram words
     // and its lists in a pool behind them (ka_fast_tags below) - it takes all 160 KiB the CU has
     static constexpr bool TAGS = LOG_NB1 == 10 && !WIDE && LSX == 0;
+    // TAGS_ARR (4096 < n <= 12288): the same with the tags in an array of their own (ka_fast_tags<.., true>): 151 KB
+    static constexpr bool TAGS_ARR = LOG_NB1 == 10 && !WIDE && LSX == 48;
     static constexpr int WORDS0 = W1 > KA_LATE_WORDS ? W1 : KA_LATE_WORDS;
-    static constexpr int WORDS = TAGS ? 40960 : WORDS0;
+    static constexpr int WORDS = TAGS ? 40960 : TAGS_ARR ? 38400 : WORDS0;
     static constexpr int U = WG_PER_CU == 2 ? KA_U_A : KA_U_B;             // rows per batch of loads
     static constexpr int BITS = WIDE ? 5 : 6;                               // 10 slots x 2^BITS bins x CW words = 80 KiB
     static_assert(WORDS * 4 * WG_PER_CU <= 160 * 1024, "does not fit the 160 KiB LDS");
@@ -611,29 +613,41 @@ __device__ __forceinline__ unsigned int ka_pick_net(const unsigned int *pool, un
 #ifdef KA_DEBUG_FAIL
 __device__ unsigned long long ka_debug_fail[8];
 #endif
-template <int LOG_NB1>
+// ARR = false (2048 < n <= 4096): the tags live in the histogram words as described above; lists of up to 31, pool behind the
+// histogram.  ARR = true (4096 < n <= 12288: a count no longer leaves a 16-bit counter four spare bits): the tags have
+// their own array - a nibble per (row, cell), word [row >> 3][cell]: as conflict-free as the histogram - and the pool
+// takes the histogram's place once the narrowing has read it (448 entries per cell); lists of up to 63 (the bucket at the
+// mode of n = 9216 |N(0,1)| scores holds 25, at n = 12288 it holds 33), sorted by a 64-input network.  This form replaces
+// the 47-entry lists + bitmap of rounds 3-4 between 4097 and 9216 rows (published rows, prefix compaction, 123 KB of lists
+// to initialise, a pick that counts through LDS) and the general radix form's third sweep between 9217 and 12288.
+template <int LOG_NB1, bool ARR>
 __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool cok, int n, long long M, int nk, float sf, float vlo,
                                              unsigned int *hist, unsigned int k0, unsigned int &ans, bool &below, int lane,
                                              int wave, int tid)
 {
-    using Cfg = KACfg<LOG_NB1, false, 0>;
-    // 896 buckets, not 1024: the 16 KB that frees take the pool from 116 to 180 entries per cell.  With 116, 20 % of the
-    // tiles of n = 4096 |N(0,1)| scores exhausted some cell's pool (ten lists of ~9 around the mode: 75 on average, 125
-    // in the fullest of a tile's 64 cells; tools/exp/stream_fail_probe.py) and went to the general form - slower than the
-    // byte-map form this replaces; a bucket is 14 % fuller for it, far below the 31 a list may hold.
-    constexpr int NB1 = 896, U = Cfg::U, CAP = 31, GB = NB1 / KA_WAVES;
+    using Cfg = KACfg<LOG_NB1, false, ARR ? 48 : 0>;
+    // 896 buckets, not 1024: the 16 KB that frees take the pool (ARR = false) from 116 to 179 entries per cell.  With 116,
+    // 20 % of the tiles of n = 4096 |N(0,1)| scores exhausted some cell's pool (ten lists of ~9 around the mode: 75 on
+    // average, 125 in the fullest of a tile's 64 cells; tools/exp/stream_fail_probe.py) and went to the general form -
+    // slower than the byte-map form this replaces; a bucket is 14 % fuller for it, far below the 31 a list may hold.
+    // (ARR = true: the same 896 leave room for the tag array.)
+    constexpr int NB1 = 896, U = Cfg::U, CAP = ARR ? 63 : 31, GB = NB1 / KA_WAVES;
+    constexpr unsigned int CMASK = ARR ? 0xffffu : 0xfffu;     // a count (ARR = false: at most n - 1 <= 4095, the tag above it)
     static_assert(NB1 % KA_WAVES == 0 && NB1 <= (1 << LOG_NB1), "buckets");
     sf = sf > 0.f ? sf * ((float)(NB1 - 1) / (float)((1 << LOG_NB1) - 1)) : sf;      // (ka_window scaled the window to 2^LOG_NB1 - 1 rows)
     constexpr int HIST_WORDS = (NB1 + 1) * 32;                 // rows 0 (below the window) .. NB1 (at or beyond its end)
-    constexpr int POOL_AT = HIST_WORDS;                        // (its first 1024 words: the narrowing's group sums)
-    constexpr int SIDE_WORDS = KA_MAXK * 64 + 64 + KA_WAVES + 64;      // list fill pointers, pool pointers, per-wave flags, scratch
-    constexpr int POOL = (Cfg::WORDS - HIST_WORDS - SIDE_WORDS) / 64;
-    constexpr int SIDE_AT = POOL_AT + POOL * 64;
+    constexpr int TAG_WORDS = ARR ? ((NB1 + 1 + 7) / 8) * 64 : 0;
+    // side: list fill pointers, pool pointers, per-wave flags, a scratch word per lane, (ARR) the narrowing's group sums
+    constexpr int SIDE_WORDS = KA_MAXK * 64 + 64 + KA_WAVES + 64 + (ARR ? KA_WAVES * 64 : 0);
+    constexpr int POOL = ARR ? HIST_WORDS / 64 : (Cfg::WORDS - HIST_WORDS - SIDE_WORDS) / 64;
+    constexpr int POOL_AT = ARR ? 0 : HIST_WORDS;              // (ARR = false: its first 1024 words are the group sums)
+    constexpr int SIDE_AT = ARR ? HIST_WORDS + TAG_WORDS : POOL_AT + POOL * 64;
     static_assert(POOL >= 96 && SIDE_AT + SIDE_WORDS <= Cfg::WORDS, "pool");
-    unsigned int *pool = hist + POOL_AT, *cnt = hist + SIDE_AT, *ptr = cnt + KA_MAXK * 64, *flg = ptr + 64;
+    unsigned int *pool = hist + POOL_AT, *tags = hist + HIST_WORDS, *cnt = hist + SIDE_AT, *ptr = cnt + KA_MAXK * 64, *flg = ptr + 64;
+    unsigned int *grp = ARR ? flg + KA_WAVES + 64 : pool;
     const bool state = wave < nk;
     const int l31 = lane & 31, sh = 16 * (lane >> 5), tsh = 12 + sh;
-    for (int i = tid; i < HIST_WORDS; i += 1024) hist[i] = 0u;
+    for (int i = tid; i < HIST_WORDS + TAG_WORDS; i += 1024) hist[i] = 0u;
     if (tid < 64) ptr[tid] = 0u;
     __syncthreads();
     const unsigned int inc = 1u << sh;
@@ -660,7 +674,7 @@ __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool
     ka_sweep<U>(col, cok, n, M, wave, count1, KEEP);
     __syncthreads();
 
-    // ---- narrowing (ka_narrow_first with 12-bit counts: an owner that is done may already have tagged a word)
+    // ---- narrowing (ka_narrow_first's walks; ARR = false: 12-bit counts)
     unsigned int myr = k0, count = 0;
     int digit = 0;
     bool outside = false;
@@ -669,18 +683,18 @@ __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool
         const unsigned int *h = hist + (1 + wave * GB) * 32 + l31;
 #pragma unroll 8
         for (int u = 0; u < GB; ++u) gs += h[u * 32];          // (both cells of the word at once: a sum is at most n)
-        pool[wave * 64 + lane] = (gs >> sh) & 0xffffu;
+        grp[wave * 64 + lane] = (gs >> sh) & 0xffffu;
     }
     __syncthreads();
     if (state) {
-        const unsigned int under = (hist[l31] >> sh) & 0xfffu;
+        const unsigned int under = (hist[l31] >> sh) & CMASK;
         outside = myr < under;
         const unsigned int r = outside ? 0u : myr - under;
         unsigned int run = 0, cum = 0;
         int g = 0;
 #pragma unroll
         for (int u = 0; u < KA_WAVES; ++u) {
-            run += pool[u * 64 + lane];
+            run += grp[u * 64 + lane];
             const bool le = run <= r;
             g += le;
             cum = le ? run : cum;
@@ -691,32 +705,35 @@ __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool
         int d = 0;
 #pragma unroll 8
         for (int u = 0; u < GB; ++u) {
-            run += (h[u * 32] >> sh) & 0xfffu;
+            run += (h[u * 32] >> sh) & CMASK;
             const bool le = run <= r;
             d += le;
             cum = le ? run : cum;
         }
         digit = g * GB + min(d, GB - 1);                       // bucket digit lives in row 1 + digit
         outside = outside || digit == NB1 - 1;                 // (row NB1: at or beyond the window's end)
-        count = (h[min(d, GB - 1) * 32] >> sh) & 0xfffu;
+        count = (h[min(d, GB - 1) * 32] >> sh) & CMASK;
         myr = r - cum;
     }
     bool many = state && count > (unsigned)CAP;
     const bool bad = state && (outside || sf < 0.f);
-    __syncthreads();                                           // every owner has read the group sums: the pool is free
-    unsigned int *a = hist + (digit + 1) * 32 + l31;
+    __syncthreads();                                           // every owner has read what it needs: the pool is free
+    // the word that carries my row's tag, and where in it
+    const int myrow = digit + 1;
+    unsigned int *a = ARR ? tags + (myrow >> 3) * 64 + lane : hist + myrow * 32 + l31;
+    const int ash = ARR ? (myrow & 7) * 4 : tsh;
     if (state && !many && !bad) {
         unsigned int old = *a;
-        if (((old >> tsh) & 15u) == 0u) {
+        if (((old >> ash) & 15u) == 0u) {
             const unsigned int start = atomicAdd(&ptr[lane], count);
             if (start + count > (unsigned)POOL) {
                 many = true;                                   // (pool exhausted: ties - the general form)
             } else {
                 cnt[wave * 64 + lane] = (start * 64u + (unsigned)lane) * 4u;
                 for (;;) {
-                    const unsigned int prev = atomicCAS(a, old, old | ((unsigned)(wave + 1) << tsh));
-                    if (prev == old || ((prev >> tsh) & 15u) != 0u) break;
-                    old = prev;
+                    const unsigned int prev = atomicCAS(a, old, old | ((unsigned)(wave + 1) << ash));
+                    if (prev == old || ((prev >> ash) & 15u) != 0u) break;
+                    old = prev;                                // (another tag of the word was set meanwhile)
                 }
             }
         }
@@ -745,26 +762,40 @@ __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool
     }
 #endif
     if (fl) return false;
-    const int myslot = state ? (int)((*a >> tsh) & 15u) - 1 : 0;
+    const int myslot = state ? (int)((*a >> ash) & 15u) - 1 : 0;
 
-    // ---- collect: an element whose row is tagged joins the tagged list (inside its segment always: the histogram counted)
+    // ---- collect: an element whose row is tagged joins the tagged list (inside its segment always: the histogram counted).
+    // (ARR: the appends overwrite the histogram - nothing reads it any more.)
     char *cb = reinterpret_cast<char *>(cnt + lane) - 256;     // fill pointer of list m - 1 of my cell: cb + m * 256
     char *lb = reinterpret_cast<char *>(pool);
-    // H rows at a time, branch-free (as in the register tiles): the H histogram words are read together, every element issues
+    const char *tb = reinterpret_cast<const char *>(tags + lane);      // (ARR) word ((row >> 3), my cell): tb + (row >> 3) * 256
+    // H rows at a time, branch-free (as in the register tiles): the H tag words are read together, every element issues
     // its returning add (of 0, on a word that ignores it, when its row is untagged) and its store (to a scratch word of its
     // lane): one LDS round trip per phase and half batch instead of two per element
     constexpr int H = 8;
     char *dummy = reinterpret_cast<char *>(flg + KA_WAVES + lane);
+    unsigned int *dummy_cnt = reinterpret_cast<unsigned int *>(dummy);          // (an add of 0 changes nothing wherever it lands)
     auto collect = [&](float (&v)[H], int nv) __attribute__((always_inline)) {
         unsigned int m[H];
+        unsigned int rsh[H];
 #pragma unroll
-        for (int u = 0; u < H; ++u) m[u] = *reinterpret_cast<const unsigned int *>(hb + (ka_frow<NB1>(v[u], sf, vlo) << 7));
+        for (int u = 0; u < H; ++u) {
+            const int row = ka_frow<NB1>(v[u], sf, vlo);
+            if constexpr (ARR) {
+                m[u] = *reinterpret_cast<const unsigned int *>(tb + ((row >> 3) << 8));
+                rsh[u] = (unsigned)(row & 7) << 2;
+            } else {
+                m[u] = *reinterpret_cast<const unsigned int *>(hb + (row << 7));
+                rsh[u] = (unsigned)tsh;
+            }
+        }
         bool hit[H];
 #pragma unroll
         for (int u = 0; u < H; ++u) {
-            m[u] = __builtin_amdgcn_ubfe(m[u], (unsigned)tsh, 4u);
+            m[u] = __builtin_amdgcn_ubfe(m[u], rsh[u], 4u);
             hit[u] = m[u] != 0u && u < nv;                         // (rows beyond n came back 0.0 through an empty descriptor)
-            m[u] = atomicAdd(reinterpret_cast<unsigned int *>(cb + ((hit[u] ? m[u] : 0u) << 8)), hit[u] ? 256u : 0u);
+            unsigned int *fp = hit[u] ? reinterpret_cast<unsigned int *>(cb + (m[u] << 8)) : dummy_cnt;
+            m[u] = atomicAdd(fp, hit[u] ? 256u : 0u);
         }
 #pragma unroll
         for (int u = 0; u < H; ++u) *reinterpret_cast<float *>(hit[u] ? lb + m[u] : dummy) = v[u];
@@ -780,7 +811,8 @@ __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool
         if (count == 0u) ans = 0u;                             // (cannot happen for a rank inside its window; defined anyway)
         else if (cmax <= 8) ans = ka_pick_net<8>(pool, base, count, myr);
         else if (cmax <= 16) ans = ka_pick_net<16>(pool, base, count, myr);
-        else ans = ka_pick_net<32>(pool, base, count, myr);
+        else if (!ARR || cmax <= 32) ans = ka_pick_net<32>(pool, base, count, myr);
+        else ans = ka_pick_net<64>(pool, base, count, myr);
     }
     return true;
 }
@@ -932,8 +964,10 @@ __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long
         unsigned int key = 0u;
         bool done;
         if constexpr (Cfg::TAGS) {
-            if (n <= 4096) done = ka_fast_tags<LOG_NB1>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
+            if (n <= 4096) done = ka_fast_tags<LOG_NB1, false>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
             else done = ka_fast<LOG_NB1, WIDE, LSX>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
+        } else if constexpr (Cfg::TAGS_ARR) {
+            done = ka_fast_tags<LOG_NB1, true>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
         } else {
             done = ka_fast<LOG_NB1, WIDE, LSX>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
         }
@@ -1841,9 +1875,9 @@ int launch_kth(const float *scores, int n, long long M, long long S, const int32
         for (long long t0 = 0; t0 < tiles; t0 += per_launch) {
             const long long nt = tiles - t0 < per_launch ? tiles - t0 : per_launch;
             // the fast first digit pays while a full bucket holds well under CAP elements (n <= ~6 NB1 on
-            // bell-shaped scores with 31-entry lists, 9 NB1 with 47); beyond that it would be a wasted sweep
+            // bell-shaped scores with 31-entry lists, 12 NB1 with the tag-array form's 63); beyond that it would be a wasted sweep
             hipLaunchKernelGGL((kth_axis0_kernel<LOG_NB1, WIDE, LSX>), dim3((unsigned)nt), dim3(1024), 0, st, scores, n, M, S, t0, kl,
-                               n <= (LSX ? 9 : 6) * (1 << LOG_NB1) ? 1 : 0, out, pl);
+                               n <= (LSX ? 12 : 6) * (1 << LOG_NB1) ? 1 : 0, out, pl);
             PRE_LAUNCH_CHECK();
         }
     }
@@ -1965,7 +1999,10 @@ extern "C" int pre_kth_axis0_planes_f32(const float *scores, int64_t plane_strid
     if (n <= 2048 && S * 388 + 128 < (1LL << 32)) return launch_kth_tile<9, 64, 1, true>(KA_ARGS);     // (... 96 S x 4 bytes + a row pair: 11 M cells)
 #endif
     if (n >= 65536) return launch_kth<9, true>(KA_ARGS);
-    if (n > 4096 && n <= 9216) return launch_kth<10, false, 48>(KA_ARGS);      // (measured: ahead of the 31-entry form from n = 4608 on, 2-3 % behind it at n <= 4096)
+    // 4096 < n <= 12288: the tag-array form (lists of up to 63 from a pool of 448 per cell; round 5 - rounds 3-4: 47-entry
+    // lists and a bitmap to 9216, the general form beyond; measured: +20-25 % to 9216, +33-63 % to 12000, -6 % at 14336,
+    // where buckets above 63 send too many tiles to the general form)
+    if (n > 4096 && n <= 12288) return launch_kth<10, false, 48>(KA_ARGS);
     if (n > 2048) return launch_kth<10, false>(KA_ARGS);
     return launch_kth<9, false>(KA_ARGS);
 #undef KA_ARGS

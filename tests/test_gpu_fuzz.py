@@ -276,7 +276,7 @@ def test_fuzz_round5_select_tags_and_pools(gpu):
     rng = np.random.default_rng(5005)
     g = torch.Generator(device=gpu).manual_seed(5005)
     ns = [241, 255, 256, 257, 300, 383, 384, 385, 500, 512, 513, 600, 767, 768, 769, 1000, 1024, 1025, 1200, 1536, 1537, 2000, 2047,
-          2048, 2049, 2100, 2500, 3000, 3333, 3840, 4000, 4095, 4096]
+          2048, 2049, 2100, 2500, 3000, 3333, 3840, 4000, 4095, 4096, 4097, 5000, 6144, 8192, 9216, 9217, 11000, 12288, 12289]
     for case in range(max(24, CASES)):
         n = int(rng.choice(ns))
         M = int(rng.choice([33, 64, 65, 130, 200, 641]))

@@ -2035,7 +2035,8 @@ def test_multi_plane_select_one_launch(gpu, n):
         assert torch.equal(pipeline.marginal_qhat(tm, alphas), pipeline.marginal_qhat(tm.contiguous(), alphas))
 
 
-@pytest.mark.parametrize("n", [20, 100, 130, 168, 169, 170, 183, 200, 255, 256, 257, 300, 512, 700, 1000, 1500, 2048, 3000, 7000, 8192, 9216, 9217])
+@pytest.mark.parametrize("n", [20, 100, 130, 168, 169, 170, 183, 200, 255, 256, 257, 300, 512, 700, 1000, 1500, 2048, 3000, 4096, 4097,
+                               7000, 8192, 9216, 9217, 12000, 12288, 12289])
 def test_constant_and_nan_columns_alone_in_their_tile(gpu, n):
     """A constant column (settled by its window: an empty candidate list) and a column with one NaN, each in a tile whose
     other cells are ordinary - so that nothing sends the tile to the streaming form - with SMALL ranks among the requested
@@ -2065,7 +2066,7 @@ def test_constant_and_nan_columns_alone_in_their_tile(gpu, n):
     assert torch.equal(got[:, ok], want[:, ok]), (n, (got[:, ok] != want[:, ok]).nonzero()[:5].tolist())
 
 
-@pytest.mark.parametrize("n", [250, 384, 512, 700, 1000, 1500, 2048])
+@pytest.mark.parametrize("n", [250, 384, 512, 700, 1000, 1500, 2048, 3000, 4096, 6000, 9000, 12000])
 def test_register_tile_lists_share_a_pool(gpu, n):
     """Round 5: the candidate lists of a cell are segments of ONE pool (exactly `count` entries each, taken with an atomic
     add on the cell's pool pointer; 144 / 288 entries per cell), tagged in the histogram word of their row.  Quantised
