@@ -938,9 +938,19 @@ def main():
             sync()
             t2 = time.perf_counter()
             for k in range(k0 + 2, k0 + n2):
-                step(k, mres, mode="marginal")
+                qm = step(k, mres, mode="marginal")
             sync()
             ms = 1e3 * (time.perf_counter() - t2) / 5
+            # CHECKER (outside the timed region): the last slab's |res| is still in the buffer - three cells of its q-hat
+            # field against torch.sort of their 4096-sample columns, bit for bit
+            a_last, ks_m = mres[slabs[-1]], [icp.kth_index(B, B, a) for a in alphas]
+            cells_ok = True
+            for (t, x, y) in ((0, 0, 0), (a_last.shape[1] // 2, a_last.shape[2] // 2, Y // 2 + 1), (a_last.shape[1] - 1, a_last.shape[2] - 1, Y - 1)):
+                col = torch.sort(a_last[:, t, x, y].contiguous()).values
+                cells_ok = cells_ok and bool(torch.equal(qm[:, t, x, y], col[ks_m]))
+            if not cells_ok:
+                code = 3
+            del a_last, qm
             mt = [(sl, e0.elapsed_time(e1), e1.elapsed_time(e2)) for (k, sl, e0, e1, e2) in ev_used if k >= k0 + 2]
             kms_m = sum(d for _, d, _ in mt) / len(mt)
             sel_m = sum(d for _, _, d in mt) / len(mt)
@@ -950,7 +960,8 @@ def main():
                 "ms_per_step": ms, "cells_per_s": cells_per_step / (ms * 1e-3), "steps": 5, "warmup": 2,
                 "kernel": "march_kernel<NSMomentum<0>,8,64>", "kernel_ms": kms_m, "achieved_gbs": ach, "frac": ach / HBM_PEAK_GBS,
                 "traffic": None, "select_ms_per_slab": sel_m,
-                "select_one_read_gbs": 4.0 * B * sum(slabs) / n_slabs * other / (sel_m * 1e-3) / 1e9}
+                "select_one_read_gbs": 4.0 * B * sum(slabs) / n_slabs * other / (sel_m * 1e-3) / 1e9,
+                "qhat_cells_equal_sorted_columns": cells_ok}
             del mres
         del res_main
         ev_used.clear()
