@@ -61,3 +61,20 @@ def test_world_size_mismatch_exits_2():
     r = _run(["--gpus", "2", "--plumbing-check", "--scaling", "strong", "--batch", "255"],
              {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "divisible" in r.stderr
+
+
+def test_c3_interior_row_slabs_and_c4_equations():
+    """The C3 job streams the reference's interior rows 1 .. Nx-2 (Marginal/NS_Residuals_CP.py:240): 510 rows in runs of 128
+    are 128, 128, 127, 127 - the same bytes resident as for 4 x 128; and each of C4's five equations
+    (Marginal/MHD_Residuals_CP.py:225-278) has its bytes per cell = 4 (fields read + 1) and a kernel the library instantiates."""
+    assert bench.split_slabs(510, 128) == [128, 128, 127, 127]
+    assert bench.split_slabs(510, 510) == [510] and bench.split_slabs(510, 255) == [255, 255]
+    other = 64 * 512
+    assert bench.resident_bytes(4096, 510, 128, other) == ((4096 + 3) * 3 * 130 + 4096 * 128) * other * 4 + 4096 * 256
+    fields = {"continuity": 3, "momentum": 6, "energy": 6, "induction": 4, "gauss": 2}
+    src = open(os.path.join(ROOT, "cp_pre_amd", "csrc", "star_march.hip")).read()
+    for eq, f in fields.items():
+        cfg = bench.mhd_config(eq)
+        assert cfg["bpc"] == 4 * (f + 1) and cfg["equation"] == eq and cfg["shape"] == (1024, 64, 256, 256)
+        functor = cfg["kernel"].split("<")[1].split("<")[0].split(",")[0]
+        assert f"struct {functor} " in src or f"struct {functor}\n" in src, functor
