@@ -1161,15 +1161,16 @@ __device__ __forceinline__ void kt_narrow(unsigned int *hist, bool state, unsign
     const int l31 = lane & 31, sh = C32 ? 0 : 16 * (lane >> 5);
     // 16 groups of GB bins (rows 1 + d) are summed by all 1024 threads first; the two cells of a word are added
     // together (no carry: a sum is at most n < 65536) and taken apart at the end
-    // (8 / 16 / 8 reads in flight per wait: the walks are chains of LDS round trips - round 5, 1-3 % of a tile over 4 / 4 / 4)
+    // (16 reads in flight per wait in all three walks: they are chains of LDS round trips - round 5: 8 / 16 / 8 gave 1-3 % of
+    // a tile over round 4's 4 / 4 / 4, 16 / 16 / 16 another 0.7-2.4 %)
 #ifndef KT_UNROLL_A
-#define KT_UNROLL_A 8
+#define KT_UNROLL_A 16
 #endif
 #ifndef KT_UNROLL_G
 #define KT_UNROLL_G 16
 #endif
 #ifndef KT_UNROLL_B
-#define KT_UNROLL_B 8
+#define KT_UNROLL_B 16
 #endif
     {
         unsigned int gs = 0;
