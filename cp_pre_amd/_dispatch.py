@@ -219,7 +219,7 @@ def _xcorr_impl(field, kernel, nd, flags=0, out=None):
     lib = _lib.load()
     dev, origin = to_device(field)
     if out is None:
-        out = _lib.empty_like_layout(dev)
+        out = _lib.empty_like_layout(dev, score_rows=bool(flags & _lib.PRE_FLAG_ABS) and origin is None)
     elif not (out.is_cuda and out.shape == dev.shape and out.dtype == torch.float32):
         raise ValueError("out must be an fp32 device tensor of the field's shape")
     if out.numel() == 0:

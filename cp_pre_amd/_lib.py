@@ -159,13 +159,37 @@ def field(t):
     return PreField(t.data_ptr(), s[0], s[1], s[2], s[3])
 
 
-def empty_like_layout(t):
+# A row pitch that is a multiple of a large power of two puts every row of a per-cell select's column tile on the same HBM
+# channels: the same kernel on the same bytes runs 2.5 instead of 3.4 TB/s at n = 1200-2048 rows, 2.8 / 2.5 instead of
+# 3.3 / 3.0 at n = 4096 / 8192 (profiles/r05/select_scan.txt, column "pitch M"; the register-sort forms below 241 rows do
+# not care, and rows up to 32 KiB long lose nothing: profiles/r04/rowpage.txt).  Score matrices THIS package allocates
+# (|residual| outputs, device copies of host score arrays) therefore get rows PAD floats further apart than they are
+# long; tensors the caller owns are selected where they lie.
+PAD_MIN_ROWS, PAD_ROW_MULTIPLE, PAD = 241, 1 << 14, 64
+
+
+def wants_row_pad(n, M):
+    return n >= PAD_MIN_ROWS and M >= PAD_ROW_MULTIPLE and M % PAD_ROW_MULTIPLE == 0
+
+
+def empty_like_layout(t, score_rows=False):
     """Uninitialised fp32 tensor with ``t``'s shape and ``t``'s axis order in memory (dense): a
     [BS,Nt,Nx,Ny] view of a [BS,Nx,Ny,Nt] buffer gets an output laid out the same way, so the
-    streaming kernels read and write along the same contiguous axis."""
+    streaming kernels read and write along the same contiguous axis.
+    ``score_rows``: the result is a score matrix [n, *cells] (an |residual| output, about to be selected along axis 0):
+    its rows are PAD floats further apart than they are long when ``wants_row_pad`` says that pays."""
+    order = sorted(range(t.dim()), key=lambda d: (-t.stride(d), d))         # slowest axis first
+    if score_rows and t.dim() >= 2 and order[0] == 0 and wants_row_pad(t.shape[0], t[0].numel()):
+        M = t[0].numel()
+        strides, acc = [0] * t.dim(), 1
+        for d in reversed(order[1:]):
+            strides[d] = acc
+            acc *= t.shape[d]
+        strides[0] = M + PAD
+        buf = torch.empty(t.shape[0] * (M + PAD), dtype=torch.float32, device=t.device)
+        return buf.as_strided(tuple(t.shape), tuple(strides))
     if t.is_contiguous():
         return torch.empty(t.shape, dtype=torch.float32, device=t.device)
-    order = sorted(range(t.dim()), key=lambda d: (-t.stride(d), d))         # slowest axis first
     strides, acc = [0] * t.dim(), 1
     for d in reversed(order):
         strides[d] = acc

@@ -77,6 +77,7 @@ namespace {
 #define KA_KEEP_BIG 80        // rows kept by the 47-entry-list instantiation
 #endif
 constexpr int KA_W = 64, KA_MAXK = 10, KA_WAVES = 16, KA_MAPROW = 68;
+constexpr int KA_TAGS_MAX_N = 4096;                       // rows up to which the list tags fit above a 12-bit count (ka_fast_tags<.., false>)
 constexpr int KA_LATE_WORDS = KA_MAXK * 64 * 32;          // later sweeps (and up to 31-entry collect lists): 80 KiB
 constexpr int KA_FLAGS_AT = 1008;                         // per-wave flags (words 640..1023 are never used otherwise)
 struct KAList { int nk; int k[KA_MAXK]; int o[KA_MAXK]; };    // ranks (ascending) and the output row of each
@@ -633,6 +634,9 @@ __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool
     // (ARR = true: the same 896 leave room for the tag array.)
     constexpr int NB1 = 896, U = Cfg::U, CAP = ARR ? 63 : 31, GB = NB1 / KA_WAVES;
     constexpr unsigned int CMASK = ARR ? 0xffffu : 0xfffu;     // a count (ARR = false: at most n - 1 <= 4095, the tag above it)
+    // (ARR = false: the caller sends only n <= KA_TAGS_MAX_N here; a count of 4096 would read as 0 under a set tag bit.
+    // n - 1 because a window that is not flat has at least two occupied rows; a flat one is `bad` and redone.)
+    static_assert(ARR || KA_TAGS_MAX_N - 1 <= (int)CMASK, "a 12-bit count under the tag");
     static_assert(NB1 % KA_WAVES == 0 && NB1 <= (1 << LOG_NB1), "buckets");
     sf = sf > 0.f ? sf * ((float)(NB1 - 1) / (float)((1 << LOG_NB1) - 1)) : sf;      // (ka_window scaled the window to 2^LOG_NB1 - 1 rows)
     constexpr int HIST_WORDS = (NB1 + 1) * 32;                 // rows 0 (below the window) .. NB1 (at or beyond its end)
@@ -715,32 +719,39 @@ __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool
         count = (h[min(d, GB - 1) * 32] >> sh) & CMASK;
         myr = r - cum;
     }
-    bool many = state && count > (unsigned)CAP;
-    const bool bad = state && (outside || sf < 0.f);
+    // lanes beyond the last cell of a partial tile (!cok) hold an all-zero histogram: their narrowing ends in the overflow
+    // row, which must not send the whole tile to the general form (round-5 advice: every plane whose M is not a multiple of
+    // 64 paid that on its last tile) - they neither fail, nor tag, nor allocate, and their pick is never written
+    const bool owner = state && cok;
+    if (!cok) count = 0u;
+    bool many = owner && count > (unsigned)CAP;
+    const bool bad = owner && (outside || sf < 0.f);
     __syncthreads();                                           // every owner has read what it needs: the pool is free
     // the word that carries my row's tag, and where in it
     const int myrow = digit + 1;
     unsigned int *a = ARR ? tags + (myrow >> 3) * 64 + lane : hist + myrow * 32 + l31;
     const int ash = ARR ? (myrow & 7) * 4 : tsh;
-    if (state && !many && !bad) {
+    if (owner && !many && !bad) {
+        // win the tag FIRST, then take the entries: two ranks of a cell that share a row may both see it untagged, and an
+        // allocation before the compare-and-swap would charge the pool once per rank instead of once per distinct row
+        // (round-5 advice: on quantised data that exhausts pools spuriously, and whether it does depends on wave timing).
+        // The loser adopts the winner's list; `cnt` and the tag are read only after the next barrier.
         unsigned int old = *a;
-        if (((old >> ash) & 15u) == 0u) {
+        bool won = false;
+        while (((old >> ash) & 15u) == 0u) {
+            const unsigned int prev = atomicCAS(a, old, old | ((unsigned)(wave + 1) << ash));
+            if (prev == old) { won = true; break; }
+            old = prev;                                        // (another tag of the word was set meanwhile)
+        }
+        if (won) {
             const unsigned int start = atomicAdd(&ptr[lane], count);
-            if (start + count > (unsigned)POOL) {
-                many = true;                                   // (pool exhausted: ties - the general form)
-            } else {
-                cnt[wave * 64 + lane] = (start * 64u + (unsigned)lane) * 4u;
-                for (;;) {
-                    const unsigned int prev = atomicCAS(a, old, old | ((unsigned)(wave + 1) << ash));
-                    if (prev == old || ((prev >> ash) & 15u) != 0u) break;
-                    old = prev;                                // (another tag of the word was set meanwhile)
-                }
-            }
+            if (start + count > (unsigned)POOL) many = true;   // (pool exhausted: ties - the general form)
+            else cnt[wave * 64 + lane] = (start * 64u + (unsigned)lane) * 4u;
         }
     }
     const unsigned int w = (__ballot(many) != 0 ? 1u : 0u) | (__ballot(bad) != 0 ? 2u : 0u) | (nan != 0ull ? 4u : 0u);
     if (lane == 0) flg[wave] = w;
-    int cmax = state ? (int)count : 0;
+    int cmax = owner ? (int)count : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
     cmax = __builtin_amdgcn_readfirstlane(cmax);
@@ -762,7 +773,7 @@ __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool
     }
 #endif
     if (fl) return false;
-    const int myslot = state ? (int)((*a >> ash) & 15u) - 1 : 0;
+    const int myslot = owner ? (int)((*a >> ash) & 15u) - 1 : 0;
 
     // ---- collect: an element whose row is tagged joins the tagged list (inside its segment always: the histogram counted).
     // (ARR: the appends overwrite the histogram - nothing reads it any more.)
@@ -964,7 +975,7 @@ __device__ __forceinline__ void ka_tile(const float *__restrict__ s, int n, long
         unsigned int key = 0u;
         bool done;
         if constexpr (Cfg::TAGS) {
-            if (n <= 4096) done = ka_fast_tags<LOG_NB1, false>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
+            if (n <= KA_TAGS_MAX_N) done = ka_fast_tags<LOG_NB1, false>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
             else done = ka_fast<LOG_NB1, WIDE, LSX>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
         } else if constexpr (Cfg::TAGS_ARR) {
             done = ka_fast_tags<LOG_NB1, true>(col, cok, n, S, nk, sf, vlo, hist, k0, key, outside, lane, wave, tid);
@@ -1265,6 +1276,8 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
     constexpr int BATCH = Q % 8 == 0 ? 8 : Q % 6 == 0 ? 6 : 4;
     constexpr int GRP = BATCH == 6 ? 3 : 4;           // rows that share a descriptor base (host: (GRP - 1) rows' stride < 2^32 bytes)
     static_assert(Q % 2 == 0 && (R / 2) % BATCH == 0 && Q % BATCH == 0 && BATCH % GRP == 0 && BATCH % 2 == 0, "register blocks");
+    // the list tag sits above the count in the histogram word (kt_narrow's MSK): a tile's rows must fit under it
+    static_assert(C32 ? R * 32 <= 0xffff : R * KA_WAVES <= 0xfff + 1, "a row count must stay below the tag bits");
     __shared__ unsigned int lds[Cfg::TOTAL];
     unsigned int *hist = lds, *lists = lds + Cfg::LIST_AT, *side = lds + Cfg::SIDE_AT;
     unsigned int *win = side + Cfg::WIN_AT, *cnt = side + Cfg::CNT_AT, *ptr = side + Cfg::PTR_AT, *flg = side + Cfg::FLG_AT;
@@ -1454,19 +1467,20 @@ kth_tile_kernel(const float *__restrict__ s, int n, long long M, long long S, lo
             const int tsh = C32 ? 16 : 12 + 16 * (lane >> 5);
             unsigned int *a = hist + (digit + 1) * 32 + (lane & 31);
             if (open && !many && (!C32 || lane < 32)) {
+                // the tag is won FIRST and only the winner takes entries (round-5 advice: allocating before the
+                // compare-and-swap charged the pool once per rank instead of once per distinct row - spurious exhaustion
+                // on quantised data, dependent on wave timing); `cnt` and the tags are read after the next barrier
                 unsigned int old = *a;
-                if (((old >> tsh) & 15u) == 0u) {
+                bool won = false;
+                while (((old >> tsh) & 15u) == 0u) {
+                    const unsigned int prev = atomicCAS(a, old, old | ((unsigned)(wave + 1) << tsh));
+                    if (prev == old) { won = true; break; }          // (else: another rank's of my cell, or ...
+                    old = prev;                                      //  ... the other cell of the word was tagged meanwhile)
+                }
+                if (won) {
                     const unsigned int start = atomicAdd(&ptr[cell], count);
-                    if (start + count > (unsigned)POOL) {
-                        many = true;                                 // (the pool is exhausted: ties - left to the streaming form)
-                    } else {
-                        cnt[wave * 64 + cell] = (start * 64u + (unsigned)cell) * 4u;
-                        for (;;) {
-                            const unsigned int prev = atomicCAS(a, old, old | ((unsigned)(wave + 1) << tsh));
-                            if (prev == old || ((prev >> tsh) & 15u) != 0u) break;      // mine / another rank's of my cell
-                            old = prev;                              // (the other cell of the word was tagged meanwhile)
-                        }
-                    }
+                    if (start + count > (unsigned)POOL) many = true; // (the pool is exhausted: ties - left to the streaming form)
+                    else cnt[wave * 64 + cell] = (start * 64u + (unsigned)cell) * 4u;
                 }
             }
             const unsigned int w = (__ballot(many) != 0 ? 1u : 0u) | (__ballot(bad) != 0 ? 2u : 0u);

@@ -61,18 +61,46 @@ def uncanon(r, order, lead):
     return r.permute(*range(lead), *[lead + i for i in inv])
 
 
-def _dev(x, like=None):
-    """fp32 device tensor (layout untouched) + a function that converts results back."""
+# (why and when score rows are padded: _lib.wants_row_pad)
+wants_row_pad, PAD = _lib.wants_row_pad, _lib.PAD
+
+
+def upload_rows(host, device=None):
+    """Device copy [n, *cells] of a host fp32 tensor for a per-cell select: row-padded (``pipeline.row_padded``'s layout)
+    when the row length asks for it - the H2D transfer happens anyway, into the strided view instead of a dense one."""
+    n = host.shape[0] if host.dim() >= 2 else 0
+    M = host[0].numel() if n else 0
+    if not (host.dim() >= 2 and wants_row_pad(n, M)):
+        return host.to(device or "cuda")
+    buf = torch.empty(n * (M + PAD), dtype=torch.float32, device=device or "cuda")
+    view = buf.as_strided((n, M), (M + PAD, 1))
+    view.copy_(host.reshape(n, M))                          # ONE strided H2D copy (hipMemcpy2D under torch)
+    strides, acc = [], 1
+    for d in reversed(host.shape[1:]):
+        strides.append(acc)
+        acc *= d
+    return buf.as_strided(tuple(host.shape), (M + PAD,) + tuple(reversed(strides)))
+
+
+def _dev(x, like=None, rows=False):
+    """fp32 device tensor (layout untouched) + a function that converts results back.  ``rows``: the tensor is a score
+    matrix about to be selected along axis 0 - a HOST input is uploaded row-padded when that pays (``upload_rows``); a
+    device tensor is the caller's and is selected where it lies."""
     if isinstance(x, torch.Tensor):
         if x.dtype != torch.float32:
             raise RuntimeError("cp_pre_amd.inductive_cp works on float32 tensors")
+        if rows and not x.is_cuda and x.dim() >= 2:
+            _lib.require_gpu()
+            origin = x.device
+            return upload_rows(x.contiguous()), (lambda r: _dispatch.from_device(r, origin))
         d, origin = _dispatch.to_device(x)
         return d, (lambda r: _dispatch.from_device(r, origin))
     arr = np.asarray(x)
     if arr.dtype != np.float32:
         arr = arr.astype(np.float32)
     _lib.require_gpu()
-    return torch.from_numpy(np.ascontiguousarray(arr)).cuda(), (lambda r: r.cpu().numpy())
+    host = torch.from_numpy(np.ascontiguousarray(arr))
+    return (upload_rows(host) if rows else host.cuda()), (lambda r: r.cpu().numpy())
 
 
 def _is_zero_like(b):
@@ -97,16 +125,33 @@ def kth_index(n_rows, n, alpha):
     return int(np.ceil((n_rows - 1) * q))
 
 
+def rows_where_they_lie(scores):
+    """(view [n, *cells in MEMORY order], row pitch or None, cell order or None) of a score tensor whose rows can be
+    selected in place: dense, or dense rows a fixed pitch >= their length apart (``pipeline.row_padded``; a driver pads
+    its residual buffer so that the rows of a cell's column are not a power of two apart), with the cell axes in any
+    order in memory (a residual computed in the surrogate's [BS,Nx,Ny,Nt] layout).  Anything else: None (copied)."""
+    if scores.is_contiguous():
+        return scores, None, None
+    if scores.dim() < 2:
+        return None
+    order = sorted(range(1, scores.dim()), key=lambda k: (-scores.stride(k), k))
+    v = scores.permute(0, *order)
+    M = v[0].numel()
+    if not v[0].is_contiguous() or not (v.shape[0] == 1 or v.stride(0) >= M):
+        return None
+    pitch = v.stride(0) if (v.shape[0] > 1 and v.stride(0) != M) else None
+    return v, pitch, (None if order == list(range(1, scores.dim())) else order)
+
+
 def kth_axis0(scores, ks):
     """Order statistics ``ks`` (0-based ranks, any order) along axis 0 of a device tensor
     [n, ...] -> [len(ks), ...].  1-D scores use the scalar radix select."""
     lib = _lib.load()
-    pitch = None
-    if scores.dim() >= 2 and not scores.is_contiguous() and scores[0].is_contiguous() and scores.stride(0) > scores[0].numel():
-        # rows with a pitch (a driver that pads its residual buffer so that the rows of a cell's column are not a power
-        # of two apart, pipeline.row_padded): selected where they lie
-        pitch, cell_order = scores.stride(0), None
+    lie = rows_where_they_lie(scores)
+    if lie is not None:
+        scores, pitch, cell_order = lie
     else:
+        pitch = None
         scores, cell_order = canon(scores)
     n = scores.shape[0]
     with torch.cuda.device(scores.device):
@@ -132,7 +177,7 @@ def kth_axis0(scores, ks):
 # ------------------------------------------------------------------ the five functions
 def calibrate(scores, n, alpha):
     """q-hat over axis 0; array of shape ``scores.shape[1:]`` (scalar for 1-D scores)."""
-    d, back = _dev(scores)
+    d, back = _dev(scores, rows=True)
     k = kth_index(d.shape[0], n, alpha)
     res = back(kth_axis0(d, [k])[0])
     if d.dim() == 1 and not isinstance(scores, torch.Tensor):
@@ -143,7 +188,7 @@ def calibrate(scores, n, alpha):
 def calibrate_multi(scores, n, alphas):
     """All levels in ONE radix sweep (the reference loops ``calibrate`` over 10 alphas,
     Marginal/Wave_Residuals_CP.py:284-288).  Returns [len(alphas), ...]."""
-    d, back = _dev(scores)
+    d, back = _dev(scores, rows=True)
     ks = [kth_index(d.shape[0], n, a) for a in alphas]
     return back(kth_axis0(d, ks))
 

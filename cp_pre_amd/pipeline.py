@@ -221,14 +221,25 @@ class JointCalibration:
     # of its segments (measured, profiles/r03/prune_ab.txt: beyond it the segment maxima cost more than they save)
     PRUNE_GIVE_UP = 0.25
 
-    def __init__(self, n_local, device, eps=0.0, group=None, ops=None, prune=True):
-        """``prune``: True / "adaptive" (bounds on the first slab, kept or dropped for the rest of the stream by what they
+    def __init__(self, n_local, device, eps=0.0, group=None, ops=None, prune=True, moments="reduce_scatter"):
+        """``moments`` (only with a group): how the per-cell moments of a slab become the modulation every rank needs.
+        "reduce_scatter" (default): every rank needs sigma-hat (fp32), not the sums (2 x fp64) - the two moment vectors
+        are REDUCE-SCATTERED (rank r receives the group's sums for its 1/W of the cells), each rank finishes sigma-hat for
+        its own cells, and ONE all-gather of the fp32 sigma-hat hands every rank the whole field: (W-1)/W x (16 + 4) B
+        per cell on the wire per rank instead of the all-reduce's 2 x (W-1)/W x 16 B (C3 strong-scaled, W = 8: 284 MB
+        instead of 453 MB per rank and step), and sigma-hat is bit-identical on every rank by construction (each cell's
+        is computed once).  "all_reduce": the sums are all-reduced and every rank finishes every cell (rounds 1-5).
+        Either way the collectives' sizes follow from the slab's shape, layout and crop alone (see ``add_slab``).
+        ``prune``: True / "adaptive" (bounds on the first slab, kept or dropped for the rest of the stream by what they
         saved there: ONE host read of two device counters when the second slab arrives - and, in a group, one 16-byte
         all-reduce of them, so that every rank takes the same route), "always" (no host read, no extra collective:
         ``add_slab`` never synchronises and can be captured in a HIP graph), False / "never" (the full score pass)."""
         self.ops = ops or HipOps
         if prune not in (True, False, "adaptive", "always", "never"):
             raise ValueError(f"prune={prune!r}: True / 'adaptive', 'always', False / 'never'")
+        if moments not in ("reduce_scatter", "all_reduce"):
+            raise ValueError(f"moments={moments!r}: 'reduce_scatter' or 'all_reduce'")
+        self.moments = moments
         self.prune = prune not in (False, "never")
         self.prune_checked = prune == "always"     # nothing left to decide
         self.prune_stats = None        # device [segments read, segments, samples swept whole] over the pruned slabs
@@ -263,7 +274,9 @@ class JointCalibration:
         passes from its second slab on.
 
         Collectives issued per slab, in this order on every rank: [second slab of an adaptive stream only: all-reduce of
-        2 int64], all-reduce of the fp64 moments [2, cells reduced].  ``cells reduced`` follows from the slab's shape,
+        2 int64], then the moments: two reduce-scatters of the fp64 sums / sums of squares [cells reduced, padded to a
+        multiple of the group size] + one all-gather of the fp32 sigma-hat (``moments="all_reduce"``: one all-reduce of
+        [2, cells reduced]).  ``cells reduced`` follows from the slab's shape,
         its memory layout and ``crop`` ALONE (the planes of the slowest memory axis inside its crop), never from the
         route or from anything a rank measured: ranks may only be grouped if they stream slabs of the same shape and
         layout, and then their collectives match whatever their data."""
@@ -280,14 +293,21 @@ class JointCalibration:
             resc, cropc = view                                           # cell axes in memory order
             assert skip == cropc[0], (skip, cropc)                       # (prune_view only takes dense slabs)
         kw = {"skip_t": skip} if skip else {}
-        mom = ops.zeros_moments(M - (2 * skip * self._plane_cells(res) if skip else 0), self.device)
+        Mm = M - (2 * skip * self._plane_cells(res) if skip else 0)     # cells reduced
+        scatter = self.group is not None and self.moments == "reduce_scatter"
+        chunk = -(-Mm // self.world)                                    # cells per rank of the scattered form
+        momp = ops.zeros_moments(chunk * self.world if scatter else Mm, self.device)
+        mom = momp[:, :Mm]                                              # (the pad stays zero: nobody's cells)
         if view is not None:
             segmax = ops.add_moments_segmax(resc, mom, cropc)
         else:
             ops.add_moments(res, mom, **kw)
-        if self.group is not None:
-            torch.distributed.all_reduce(mom, group=self.group)          # RCCL: sum of (sum, sumsq) per cell
-        mod = ops.std_from_moments(mom, self.n_total, tuple(res.shape[1:]), self.eps, like=res, **kw)
+        if scatter:
+            mod = self._modulation_scattered(momp, Mm, chunk, res, skip)
+        else:
+            if self.group is not None:
+                torch.distributed.all_reduce(mom, group=self.group)      # RCCL: sum of (sum, sumsq) per cell
+            mod = ops.std_from_moments(mom, self.n_total, tuple(res.shape[1:]), self.eps, like=res, **kw)
         if view is not None:
             if self.prune_stats is None and getattr(ops, "zeros_prune_stats", None):
                 self.prune_stats = ops.zeros_prune_stats(self.device)
@@ -297,6 +317,31 @@ class JointCalibration:
             ops.max_scores(res, mod, crop, self.scores)
         self.modulation.append(mod)
         return mod
+
+    def _modulation_scattered(self, momp, Mm, chunk, res, skip):
+        """sigma-hat of a slab from the ranks' local moments ``momp`` [2, chunk * world] (fp64, cells in memory order, zero
+        beyond ``Mm``): reduce-scatter of the sums and of the sums of squares (rank r: cells [r * chunk, (r+1) * chunk)),
+        the std of the rank's own cells, ONE all-gather of the fp32 result - straight into the modulation's own memory,
+        ``skip`` planes of the slowest memory axis in (those planes, inside the crop, are NaN as on the all-reduce route)."""
+        dist, g, ops = torch.distributed, self.group, self.ops
+        own = momp.new_empty(2, chunk)
+        dist.reduce_scatter_tensor(own[0], momp[0], group=g)           # RCCL: (W-1)/W x 8 B per cell out per rank, twice
+        dist.reduce_scatter_tensor(own[1], momp[1], group=g)
+        sig_own = ops.std_from_moments(own, self.n_total, (chunk,), self.eps)      # fp32 [chunk]: this rank's cells
+        shape = tuple(res.shape[1:])
+        order = HipOps.dense_order(res)[0]                              # (pure layout arithmetic, any back end)
+        mshape = shape if order is None else tuple(shape[o - 1] for o in order)
+        plane = 1
+        for d in mshape[1:]:
+            plane *= d
+        head = skip * plane
+        buf = sig_own.new_empty(2 * head + chunk * self.world)
+        dist.all_gather_into_tensor(buf[head:head + chunk * self.world], sig_own, group=g)   # (W-1)/W x 4 B per cell
+        mod = buf[:mshape[0] * plane].view(mshape)
+        if skip:
+            mod[:skip] = float("nan")
+            mod[mshape[0] - skip:] = float("nan")
+        return icp.uncanon(mod, order, 0)
 
     @staticmethod
     def _plane_cells(res):
@@ -474,7 +519,8 @@ def marginal_qhat(scores, alphas, group=None, ops=None, stage_bytes=4 << 30, ove
     (RCCL runs it on its own stream) before the select of run k-1 is enqueued, so the xGMI transfer of one run hides
     behind the select of the previous one; nothing else is ordered differently, the result is identical.  Off by
     default: the stream ordering it relies on (RCCL's stream against the compute stream, reuse of the staging
-    buffers) has only ever run under gloo, whose collectives block the host."""
+    buffers) has run under gloo at 2-3 ranks (whose collectives block the host) and on real RCCL at world size ONE only
+    (tests/test_gpu_parity.py::test_marginal_exchange_overlap_on_rccl_at_world_size_one) - never across GPUs."""
     ops = ops or HipOps
     n_local, cells = scores.shape[0], tuple(scores.shape[1:])
     world = torch.distributed.get_world_size(group) if group is not None else 1

@@ -149,7 +149,7 @@ class NavierStokes(_Residual2D):
             with torch.no_grad():
                 (du, dv, dp), origin = _stage((u, v, p))
                 if out is None:
-                    out = _lib.empty_like_layout(du)
+                    out = _lib.empty_like_layout(du, score_rows=absolute and origin is None)
                 interior = (skip_t_rim and out.dim() == 4 and du.shape[1] >= 3 and
                             tuple(out.shape) == (du.shape[0], du.shape[1] - 2, du.shape[2], du.shape[3]))
                 if not (out.is_cuda and out.dtype == torch.float32 and (out.shape == du.shape or interior)):
@@ -228,43 +228,52 @@ class MHD(_Residual2D):
         super().__init__(**kw)
         self.gamma = gamma
 
-    def _fused(self, eq, vars, absolute, halo_x=False):
+    def _fused(self, eq, vars, absolute, halo_x=False, out=None):
         """``halo_x`` (every ``residual_*`` below takes it): ``vars`` is an x-slab ``full[:, :, :, x0:x1]`` whose rows
         x0 - 1 and x1 lie in the same memory and are read as x-neighbours instead of the zero padding
-        (``PRE_FLAG_HALO_X``, see ``NavierStokes.residual_momentum``); fused route only."""
+        (``PRE_FLAG_HALO_X``, see ``NavierStokes.residual_momentum``); fused route only.
+        ``out`` (likewise): a preallocated fp32 device tensor [BS,Nt,Nx,Ny] for the uncropped residual - any batch / plane
+        strides over rows that share the fields' contiguous axis (``pipeline.row_padded`` / ``time_major`` buffers: the
+        sharded marginal calibration's send blocks); fused route only (raises otherwise)."""
         ks = self._k27(self.D_t, self.D_x, self.D_y) if self._want_fused(vars) else None
         if ks is None or vars.shape[1] < 6:
-            if halo_x:
-                raise RuntimeError("halo_x: only the fused route reads the halo rows")
+            if halo_x or out is not None:
+                raise RuntimeError("halo_x / out: only the fused route reads the halo rows / writes a caller's buffer")
             return None
         with torch.no_grad():
             fields, origin = _stage([vars[:, i] for i in range(6)])
         if halo_x and (origin is not None or _dispatch.needs_grad(vars) or
                        any(d.data_ptr() != vars[:, i].data_ptr() or d.stride(3) != 1 for i, d in enumerate(fields))):
             raise ValueError("halo_x needs device-resident, Ny-contiguous views of a larger grid and no autograd")
-        out = _lib.empty_like_layout(fields[0])
+        given = out is not None
+        if given and not (out.is_cuda and out.dtype == torch.float32 and out.shape == fields[0].shape and origin is None
+                          and not _dispatch.needs_grad(vars)):
+            raise ValueError("out must be an fp32 device tensor of the field shape, the fields device-resident, no autograd")
+        if not given:
+            out = _lib.empty_like_layout(fields[0], score_rows=absolute and origin is None)
         arr = (_lib.PreField * 6)(*[_lib.field(f) for f in fields])
         fo = _lib.field(out)
         flags = (_lib.PRE_FLAG_ABS if absolute else 0) | (_lib.PRE_FLAG_HALO_X if halo_x else 0)
         with torch.cuda.device(out.device):
             ok = _fused_call("pre_residual_mhd_f32", lambda: _lib.load().pre_residual_mhd_f32(
                 _MHD_EQ[eq], arr, ctypes.byref(fo), *ks, float(self.gamma), *out.shape, flags, _lib.stream()))
-        if halo_x and not ok:
-            raise RuntimeError("pre_residual_mhd_f32: halo_x needs Ny-contiguous views and star-shaped operator kernels")
+        if (halo_x or given) and not ok:
+            raise RuntimeError("pre_residual_mhd_f32: halo_x / out need views that share a contiguous axis with the fields "
+                               "and star-shaped operator kernels")
         return _dispatch.from_device(out, origin) if ok else None
 
-    def residual_continuity(self, vars, boundary=False, absolute=False, halo_x=False):
+    def residual_continuity(self, vars, boundary=False, absolute=False, halo_x=False, out=None):
         D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
         fields = (vars[:, 0], vars[:, 1], vars[:, 2])
 
         def composed(rho, u, v):
             return D_t(rho) + u*D_x(rho) + rho*D_x(u) + v*D_y(rho) + rho*D_y(v)
-        res = _attach(self._fused('continuity', vars, absolute, halo_x), fields, composed, absolute)
+        res = _attach(self._fused('continuity', vars, absolute, halo_x, out), fields, composed, absolute)
         if res is None:
             return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)
 
-    def residual_momentum(self, vars, boundary=False, absolute=False, halo_x=False):
+    def residual_momentum(self, vars, boundary=False, absolute=False, halo_x=False, out=None):
         D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
         fields = tuple(vars[:, i] for i in range(6))
 
@@ -272,12 +281,12 @@ class MHD(_Residual2D):
             res_x = D_t(u) + u*D_x(u) + (1/rho)*D_x(p) - 2*(Bx/rho)*D_x(Bx) + v*D_y(u) - (By/rho)*D_y(Bx) - (Bx/rho)*D_y(By)
             res_y = D_t(v) + u*D_x(v) + (1/rho)*D_y(p) - 2*(By/rho)*D_y(By) + v*D_y(v) - (By/rho)*D_x(Bx) - (Bx/rho)*D_x(By)
             return res_x + res_y
-        res = _attach(self._fused('momentum', vars, absolute, halo_x), fields, composed, absolute)
+        res = _attach(self._fused('momentum', vars, absolute, halo_x, out), fields, composed, absolute)
         if res is None:
             return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)
 
-    def residual_energy(self, vars, boundary=False, absolute=False, halo_x=False):
+    def residual_energy(self, vars, boundary=False, absolute=False, halo_x=False, out=None):
         D_t, D_x, D_y, gamma = self.D_t, self.D_x, self.D_y, self.gamma
         fields = tuple(vars[:, i] for i in range(6))
 
@@ -285,12 +294,12 @@ class MHD(_Residual2D):
             p_gas = p - 0.5*(Bx**2 + By**2)
             return (D_t(rho) + u*D_x(p) + v*D_y(p) + (gamma-2)*(u*Bx+v*By)*(D_x(Bx) + D_y(By))
                     + (gamma*p_gas+By**2)*D_x(u) + (gamma*p_gas+Bx**2)*D_y(v) - Bx*By*(D_y(u) + D_x(v)))
-        res = _attach(self._fused('energy', vars, absolute, halo_x), fields, composed, absolute)
+        res = _attach(self._fused('energy', vars, absolute, halo_x, out), fields, composed, absolute)
         if res is None:
             return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)
 
-    def residual_induction(self, vars, boundary=False, absolute=False, halo_x=False):
+    def residual_induction(self, vars, boundary=False, absolute=False, halo_x=False, out=None):
         D_t, D_x, D_y = self.D_t, self.D_x, self.D_y
         fields = (vars[:, 1], vars[:, 2], vars[:, 4], vars[:, 5])
 
@@ -298,7 +307,7 @@ class MHD(_Residual2D):
             res_x = D_t(Bx) - By*D_y(u) + Bx*D_y(v) - v*D_y(Bx) + u*D_y(By)
             res_y = D_t(By) + By*D_x(u) - Bx*D_x(v) - v*D_x(Bx) + u*D_x(By)
             return res_x + res_y
-        res = _attach(self._fused('induction', vars, absolute, halo_x), fields, composed, absolute)
+        res = _attach(self._fused('induction', vars, absolute, halo_x, out), fields, composed, absolute)
         if res is None:
             return _finish(_on_device(fields, composed), boundary, _CROP3, absolute, False)
         return _finish(res, boundary, _CROP3, absolute, True)
@@ -375,7 +384,7 @@ class JOREK:
             Rb = Rd.view(-1, 1).expand(-1, f0.shape[1]).contiguous().as_strided(tuple(f0.shape), (0, 1, 0, f0.shape[1]))
         else:
             return None
-        out = _lib.empty_like_layout(f0)
+        out = _lib.empty_like_layout(f0, score_rows=absolute and origin is None)
         arr = (_lib.PreField * 3)(*[_lib.field(devs[i] if i < len(devs) else devs[0]) for i in range(3)])
         fo, fr = _lib.field(out), _lib.field(Rb)
         with torch.cuda.device(out.device):
@@ -509,7 +518,7 @@ class Burgers:
         if all(k is not None for k in ks) and uu.dim() == 3:
             with torch.no_grad():
                 (du,), origin = _stage((uu,))
-            out = _lib.empty_like_layout(du)
+            out = _lib.empty_like_layout(du, score_rows=absolute and origin is None)
             c3 = float(2 * dt / dx)                       # evaluated in fp32 like the reference
             with torch.cuda.device(du.device):
                 ok = _fused_call("pre_residual_burgers_f32", lambda: _lib.load().pre_residual_burgers_f32(

@@ -40,7 +40,7 @@ def _linear2_fused(f0, k0, f1, k1, ratio, flags):
     b, _ = _dispatch.to_device(f1)
     if not _lib.streamable(a, b):
         a, b = a.contiguous(), b.contiguous()
-    out = _lib.empty_like_layout(a)
+    out = _lib.empty_like_layout(a, score_rows=bool(flags & _lib.PRE_FLAG_ABS) and origin is None)
     fa, fb, fo = _lib.field(a), _lib.field(b), _lib.field(out)
     with torch.cuda.device(a.device):
         rc = _lib.load().pre_residual_linear2_f32(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(fo), d0, d1,

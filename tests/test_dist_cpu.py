@@ -111,7 +111,7 @@ class PruneOps(CpuOps):
 
     @staticmethod
     def std_from_moments(mom, n_total, shape, eps, like=None, skip_t=0):
-        _, order = PruneOps._canon(like)
+        order = PruneOps._canon(like)[1] if like is not None else None      # (like=None: a flat run of cells)
         mshape = tuple(shape) if order is None else tuple(shape[o - 1] for o in order)
         mean = mom[0] / n_total
         std = (mom[1] / n_total - mean * mean).clamp_min(0).sqrt().float() + eps
@@ -150,6 +150,17 @@ def _worker(rank, world, port, n_local, shape, slabs, out_dir):
         for s in range(slabs):                                            # t-slabs with one halo plane each side
             jc.add_slab(mine[:, s * step:s * step + step + 2].contiguous(), crop=(1, 1, 1))
         q = jc.finish(ALPHAS)
+        # the default moments exchange is reduce-scatter + all-gather of sigma-hat; the all-reduce form (rounds 1-5) must
+        # give the same modulation, scores and q-hat bit for bit (each cell's sums are added in rank order either way
+        # under gloo; on RCCL the ring order may differ in the last bit of an fp64 sum)
+        assert jc.moments == "reduce_scatter"
+        ar = pipeline.JointCalibration(n_local, "cpu", eps=0.0, group=dist.group.WORLD, ops=CpuOps, moments="all_reduce")
+        for s in range(slabs):
+            ar.add_slab(mine[:, s * step:s * step + step + 2].contiguous(), crop=(1, 1, 1))
+        q_ar = ar.finish(ALPHAS)
+        assert torch.equal(q, q_ar) and torch.equal(jc.all_scores, ar.all_scores)
+        for m_rs, m_ar in zip(jc.modulation, ar.modulation):
+            assert m_rs.shape == m_ar.shape and torch.equal(m_rs, m_ar)
         qm = pipeline.marginal_qhat(mine.abs().contiguous(), ALPHAS, group=dist.group.WORLD, ops=CpuOps)
         # bounded staging: 100 cells per rank per exchange -> 3 full runs and a ragged one (170 of 200 cells)
         qm_runs = pipeline.marginal_qhat(mine.abs().contiguous(), ALPHAS, group=dist.group.WORLD, ops=CpuOps,
@@ -268,18 +279,28 @@ def _prune_worker(rank, world, port, n_local, shape, case, out_dir):
     try:
         full = torch.from_numpy(np.load(os.path.join(out_dir, "res.npy")))
         mine = full[rank * n_local:(rank + 1) * n_local]
-        jc = pipeline.JointCalibration(n_local, "cpu", group=dist.group.WORLD, ops=PruneOps, prune=case["prune"])
         T = shape[0]
         step = (T - 2) // 3
-        for s in range(3):
-            slab = mine[:, s * step:s * step + step + 2]
-            if case["layout"] == "nt_fastest":            # the surrogate's [n, Nx, Ny, Nt] memory seen as [n, Nt, Nx, Ny]
-                slab = slab.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-                assert not slab.is_contiguous() and PruneOps.interior_planes(slab, (1, 1, 1)) == 1
-            else:
-                slab = slab.contiguous()
-            jc.add_slab(slab, crop=(1, 1, 1))
-        q = jc.finish(ALPHAS)
+
+        def stream(moments):
+            jc = pipeline.JointCalibration(n_local, "cpu", group=dist.group.WORLD, ops=PruneOps, prune=case["prune"], moments=moments)
+            for s in range(3):
+                slab = mine[:, s * step:s * step + step + 2]
+                if case["layout"] == "nt_fastest":            # the surrogate's [n, Nx, Ny, Nt] memory seen as [n, Nt, Nx, Ny]
+                    slab = slab.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+                    assert not slab.is_contiguous() and PruneOps.interior_planes(slab, (1, 1, 1)) == 1
+                else:
+                    slab = slab.contiguous()
+                jc.add_slab(slab, crop=(1, 1, 1))
+            return jc, jc.finish(ALPHAS)
+        # the all-reduce form of the moments exchange first (its routes are not the ones recorded), then the default
+        # reduce-scatter + all-gather form: same routes, bit-identical modulation (NaN rim planes included), scores, q-hat
+        ar, q_ar = stream("all_reduce")
+        PruneOps.routes.clear()
+        jc, q = stream("reduce_scatter")
+        assert torch.equal(q, q_ar) and torch.equal(jc.all_scores, ar.all_scores)
+        for m_rs, m_ar in zip(jc.modulation, ar.modulation):
+            assert m_rs.shape == m_ar.shape and m_rs.stride() == m_ar.stride() and torch.equal(m_rs.nan_to_num(-1.0), m_ar.nan_to_num(-1.0))
         np.save(os.path.join(out_dir, f"q_{rank}.npy"), q.numpy())
         np.save(os.path.join(out_dir, f"scores_{rank}.npy"), jc.all_scores.numpy())
         with open(os.path.join(out_dir, f"routes_{rank}.txt"), "w") as f:
@@ -326,6 +347,8 @@ def test_adaptive_prune_decision_is_collective(tmp_path, case):
 def test_prune_policy_argument():
     with pytest.raises(ValueError):
         pipeline.JointCalibration(4, "cpu", ops=CpuOps, prune="sometimes")
+    with pytest.raises(ValueError):
+        pipeline.JointCalibration(4, "cpu", ops=CpuOps, moments="gossip")
     assert pipeline.JointCalibration(4, "cpu", ops=CpuOps, prune="always").prune_checked
     assert not pipeline.JointCalibration(4, "cpu", ops=CpuOps, prune="never").prune
 

@@ -5,7 +5,9 @@ are beyond what it can check in a test, two or three samples take seconds) + siz
   C1 whole [256,100,200]                 advection additive kernel (Marginal/Advection_Residuals_CP.py:156-164,234-237): ALL of it vs the oracle
   C3 x-slab [4096,64,128+2,512] x3       THE BENCHMARKED JOB, call for call (bench.C3Stream): NS momentum, joint + marginal CP
   C3 slab  [4096,10,512,512] x3 fields   NS momentum residual (Marginal/NS_Residuals_CP.py:231-240), joint + marginal CP
-  C4 shard [1024,64,256,256] x6 fields   MHD induction residual (Marginal/MHD_Residuals_CP.py:259-268), joint CP
+  C4 shard [1024,64,256,256] x6 fields   each of the five MHD residuals (Marginal/MHD_Residuals_CP.py:225-278), joint CP;
+                                         the reference script's own recipe - Nt-fastest views + marginal CP at n = 8192 -
+                                         in test_full_size_c4_marginal_ntfast
   C5 shard [8192,200,512]                Burgers residual (Joint/Burgers_Residuals_CP.py:182-187), joint + marginal CP
   C5 whole [65536,200,512]               the same at its N = 1 size (27 GB in, 27 GB residual): the anchor of the 1 -> 8 curve
 
@@ -207,26 +209,40 @@ def test_full_size_c3_slab(gpu):
         assert torch.equal(q[:, t, x, y], col[[icp.kth_index(B, B, a) for a in alphas]])
 
 
+@pytest.fixture(scope="module")
+def c4_fields(gpu):
+    """The C4 shard's six fields [1024,6,64,256,256] (103 GB), shared by the five equations' tests."""
+    v = torch.empty(1024, 6, 64, 256, 256, device=gpu)
+    v.uniform_(0.5, 1.5, generator=torch.Generator(device=gpu).manual_seed(12))
+    yield v
+    del v
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.timeout(300)
-def test_full_size_c4_shard(gpu):
+@pytest.mark.parametrize("eq", ["induction", "continuity", "momentum", "energy", "gauss"])
+def test_full_size_c4_shard(gpu, c4_fields, eq):
+    """Each of C4's five equations (Marginal/MHD_Residuals_CP.py:225-231 continuity, :234-243 momentum, :247-256 energy,
+    :259-268 induction, :271-278 gauss) on the per-rank shard [1024,6,64,256,256]: samples 511 and 1023 against the CPU
+    oracle, the |.| epilogue, the reference's crop, joint CP with its guarantees."""
     from cp_pre_amd import inductive_cp as icp
     from cp_pre_amd import pipeline
     from cp_pre_amd.residuals import MHD
-    B, T, X, Y = 1024, 64, 256, 256
-    v = torch.empty(B, 6, T, X, Y, device=gpu)
-    v.uniform_(0.5, 1.5, generator=torch.Generator(device=gpu).manual_seed(12))
-    mhd = MHD()
-    res = mhd.residual_induction(v, boundary=True)
-    assert res.shape == (B, T, X, Y) and torch.isfinite(res[::128]).all()
     from oracle import residuals as orr
+    B, T, X, Y = 1024, 64, 256, 256
+    v = c4_fields
+    mhd = MHD()
+    fn, ofn = getattr(mhd, "residual_" + eq), getattr(orr, "mhd_" + eq)
+    res = fn(v, boundary=True)
+    assert res.shape == (B, T, X, Y) and torch.isfinite(res[::128]).all()
     for b0 in (511, B - 1):                                                 # two samples against the CPU oracle
-        assert _oracle_err(res[b0], orr.mhd_induction(v[b0:b0 + 1].cpu(), boundary=True)[0]) <= RES_TOL
-    assert torch.equal(res[-2:], mhd.residual_induction(v[-2:].clone(), boundary=True))
-    a = mhd.residual_induction(v, boundary=True, absolute=True)
+        assert _oracle_err(res[b0], ofn(v[b0:b0 + 1].cpu(), boundary=True)[0]) <= RES_TOL
+    assert torch.equal(res[-2:], fn(v[-2:].clone(), boundary=True))
+    a = fn(v, boundary=True, absolute=True)
     assert torch.equal(a, res.abs())
-    crop_view = mhd.residual_induction(v[:4])                               # boundary=False: the reference's crop
+    crop_view = fn(v[:4])                                                   # boundary=False: the reference's crop
     assert torch.equal(crop_view, res[:4, 1:-1, 1:-1, 1:-1])
-    del a, v
+    del a
     q, mod, sc = _check_joint(icp, pipeline, res, (1, 1, 1), B, gpu)
     # bounds +-q*mod cover at least the guaranteed share of the calibration samples jointly
     alphas = _alphas()
@@ -235,6 +251,23 @@ def test_full_size_c4_shard(gpu):
     for j in (0, 9):
         cov = icp.emp_cov_joint([-(q[j] * m), q[j] * m], inner)
         assert cov >= (icp.kth_index(B, B, alphas[j]) + 1) / B - 2.0 / B    # knife-edge samples sit exactly on the bound
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("layout", ["nt", "ny"])
+def test_full_size_c4_marginal_as_the_script_runs_it(gpu, layout):
+    """BASELINE config 4 the way Marginal/MHD_Residuals_CP.py runs it: residual_induction(cal_pred.permute(0,1,4,2,3))
+    (:323-350: Nt-fastest views; "ny": the synthetic benchmark's contiguous fields) -> ncf_scores = |res| -> per-cell
+    calibrate over the n_cal = 8192 samples (:408-418), as the per-rank job of the 8-way sharded flow that bench.py times
+    (`secondary.c4_marginal_rank8[_ntfast]`, same function): |residual| of the rank's [1024,6,64,256,256] written
+    plane-major, two samples against the CPU oracle; the select at n = 1024 over all planes and at n = 8192 over the
+    planes a rank owns (at the receive staging's shape and pitch), three cells each against torch.sort, bit for bit."""
+    import bench
+    out = bench.measure_c4_marginal(gpu, _alphas(), layout, steps=1, warmup=0)
+    par = out["parity"]
+    assert par["residual_rel_err"] <= RES_TOL and par["ok"], par
+    assert par["qhat_cells_equal_sorted_columns"], par
+    assert out["layout"] == layout and out["select_ms"] > 0 and out["kernel_ms"] > 0
 
 
 @pytest.mark.timeout(300)

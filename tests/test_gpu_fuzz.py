@@ -314,6 +314,28 @@ def test_fuzz_round5_select_tags_and_pools(gpu):
         assert torch.equal(got[:, ok], ref[:, ok]), (case, n, M, kind, ks, (got[:, ok] != ref[:, ok]).nonzero()[:4].tolist())
 
 
+@pytest.mark.parametrize("n", [1024, 2048, 4095, 4096, 4097, 8192])
+@pytest.mark.parametrize("M", [64, 130, 200])
+def test_select_count_boundary_under_the_list_tag(gpu, n, M):
+    """The list tag sits above a 12-bit count in the histogram words of the register tiles (n <= 1024 rows) and of the
+    streaming tag form (n <= 4096): a column of n - 2 identical values and two outliers puts n - 2 elements in ONE bucket -
+    the largest count the window can produce (the column's extremes occupy other rows) - at the sizes where it meets the
+    mask (round-5 advice).  Mixed with ordinary cells in the same tiles; M = 130, 200: partial last tiles (whose idle
+    lanes must not send the tile to the general form).  Bit-exact against torch.sort, every rank."""
+    from cp_pre_amd import inductive_cp as icp
+    g = torch.Generator(device=gpu).manual_seed(n + M)
+    s = torch.randn(n, M, device=gpu, generator=g).abs_()
+    for c, (lo, hi) in ((3, (-5.0, 9.0)), (M - 1, (0.25, 0.75)), (M // 2, (-1e30, 1e30))):
+        s[:, c] = 0.5
+        s[int(torch.randint(0, n, (1,), generator=torch.Generator().manual_seed(c)).item()), c] = lo
+        s[(int(torch.randint(0, n - 1, (1,), generator=torch.Generator().manual_seed(c + 1)).item()) + 1) % n, c] = hi
+    s[:, 5] = 0.5                                                            # a flat column next to them
+    ks = sorted({0, 1, 2, n // 2, n - 3, n - 2, n - 1} | {icp.kth_index(n, n, 0.1), icp.kth_index(n, n, 0.9)})
+    got = icp.kth_axis0(s, ks)
+    ref = torch.sort(s, dim=0).values[ks]
+    assert torch.equal(got, ref), (n, M, (got != ref).nonzero()[:4].tolist())
+
+
 def test_fuzz_round2_flat_tap_list_and_joint_score(gpu):
     """Random tap sets on random SHORT-Nt surrogate layouts (flat tap-list kernel; 3-D and 1-D operators), and the
     cropped joint score on the same memory order (flat quad walk), against the C / numpy oracles."""

@@ -2197,11 +2197,14 @@ def test_marginal_exchange_overlap_on_rccl_at_world_size_one(gpu):
     import socket
     import torch.distributed as dist
     from cp_pre_amd import pipeline
-    assert not dist.is_initialized()
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=gpu)
+    created = not dist.is_initialized()
+    if created:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=gpu)
+    elif not (dist.get_backend() == "nccl" and dist.get_world_size() == 1):
+        pytest.skip("a process group of another kind is already up in this process (earlier in-process code left it)")
     try:
         group = dist.group.WORLD
         g = torch.Generator(device=gpu).manual_seed(77)
@@ -2221,9 +2224,115 @@ def test_marginal_exchange_overlap_on_rccl_at_world_size_one(gpu):
         for ov in (False, True):
             q = pipeline._marginal_cells(dense, alphas, group, pipeline.HipOps, ov, 4 * n * 1000)
             assert torch.equal(q.reshape(len(alphas), -1), flat_want), ov
+        # joint CP through the same one-rank RCCL group: the default moments exchange (two reduce-scatters + one all-gather
+        # of sigma-hat, issued on RCCL with nothing on the wire) against the all-reduce form and against no group at all
+        res = torch.randn(n, T, X, Y, device=gpu, generator=g)
+        qs = []
+        for kw in (dict(group=group), dict(group=group, moments="all_reduce"), dict()):
+            jc = pipeline.JointCalibration(n, gpu, prune=False, **kw)
+            mod = jc.add_slab(res, crop=(1, 1, 1))
+            qs.append((jc.finish(alphas), mod, jc.all_scores))
+        for q, mod, sc in qs[1:]:
+            assert torch.equal(q, qs[0][0]) and torch.equal(sc, qs[0][2])
+            assert torch.equal(mod[1:-1], qs[0][1][1:-1]) and mod.shape == qs[0][1].shape
         torch.cuda.synchronize()
     finally:
-        dist.destroy_process_group()
+        if created:                                                        # (only what this test created)
+            dist.destroy_process_group()
+
+
+def test_host_scores_reach_the_select_row_padded(gpu, monkeypatch):
+    """The reference scripts hand `calibrate` HOST arrays (`ncf_scores = np.abs(res.numpy())`,
+    Marginal/Wave_Residuals_CP.py:280-290): the device copy is this package's, so it is uploaded into rows 64 floats further
+    apart than they are long whenever the row length is a multiple of a large power of two (the per-cell select runs 2.5
+    instead of 3.4 TB/s on such a pitch at n = 2048: profiles/r05/select_scan.txt) - through the compat import path, a numpy
+    [2048, 2^19] array: bit-exact against numpy's own quantile, and the select is entered on the strided view (pitch M + 64).
+    Caller-owned DEVICE tensors are selected where they lie (dense pitch), row-padded ones with their pad."""
+    import sys
+    from conftest import ROOT
+    from cp_pre_amd import inductive_cp as icp
+    from oracle import conformal as oc
+    sys.path.insert(0, os.path.join(ROOT, "cp_pre_amd", "compat"))
+    try:
+        from Neural_PDE.UQ.inductive_cp import calibrate
+    finally:
+        sys.path.remove(os.path.join(ROOT, "cp_pre_amd", "compat"))
+    seen = []
+    real = icp.rows_where_they_lie
+
+    def spy(scores):
+        r = real(scores)
+        seen.append((tuple(scores.shape), scores.stride(0), None if r is None else r[1]))
+        return r
+    monkeypatch.setattr(icp, "rows_where_they_lie", spy)
+    n, M = 2048, 1 << 19
+    rng = np.random.default_rng(19)
+    host = np.abs(rng.standard_normal((n, M), dtype=np.float32))
+    q = calibrate(scores=host, n=len(host), alpha=0.1)
+    assert isinstance(q, np.ndarray) and q.shape == (M,) and q.dtype == np.float32
+    assert seen[-1] == ((n, M), M + 64, M + 64), seen[-1]                   # entered on the padded rows
+    k = icp.kth_index(n, n, 0.1)
+    cols = rng.integers(0, M, size=64)
+    assert np.array_equal(q[cols], np.sort(host[:, cols], axis=0)[k])       # (numpy's quantile on all 2^19 columns takes minutes)
+    assert np.array_equal(q[:4096], oc.calibrate(host[:, :4096], n, 0.1))
+    # a CPU torch tensor [n, T, X, Y] takes the same road and comes back on the CPU
+    t4 = torch.from_numpy(host[:512]).reshape(512, 8, 256, 256)
+    q4 = icp.calibrate_multi(t4, 512, [0.1, 0.5])
+    assert seen[-1][1:] == (M + 64, M + 64) and q4.device.type == "cpu" and q4.shape == (2, 8, 256, 256)
+    assert torch.equal(q4.reshape(2, -1)[:, cols], torch.sort(t4.reshape(512, -1)[:, cols], dim=0).values[[icp.kth_index(512, 512, 0.1), icp.kth_index(512, 512, 0.5)]])
+    # short rows, few rows, odd row lengths: dense upload (nothing to gain)
+    for shape in ((2048, 1000), (200, 1 << 19), (300, 3 * (1 << 14) + 4)):
+        h = np.abs(rng.standard_normal(shape, dtype=np.float32))
+        qh = calibrate(h, shape[0], 0.5)
+        assert seen[-1][2] is None and np.array_equal(qh[:50], oc.calibrate(h[:, :50], shape[0], 0.5)), shape
+    # the caller's dense device tensor: selected where it lies
+    dev = torch.from_numpy(host[:600]).to(gpu)
+    qd = calibrate(dev, 600, 0.1)
+    assert seen[-1] == ((600, M), M, None) and qd.is_cuda
+    assert torch.equal(qd.cpu()[cols], torch.sort(torch.from_numpy(host[:600][:, cols]), dim=0).values[icp.kth_index(600, 600, 0.1)])
+
+
+def test_score_outputs_of_the_residuals_are_row_padded_and_selected_in_place(gpu):
+    """`residual(..., absolute=True)` is this package's own extension (the |.| epilogue of the marginal score): its output is
+    a score matrix about to be selected along the batch axis, so it is allocated row-padded when the row length asks for
+    it - in the fields' own memory order (Ny fastest, or the surrogate's Nt fastest) - and `kth_axis0` / `marginal_qhat`
+    select it where it lies (no copy: `rows_where_they_lie`).  Values identical to |signed residual|."""
+    from cp_pre_amd import _lib
+    from cp_pre_amd import inductive_cp as icp
+    from cp_pre_amd import pipeline
+    from cp_pre_amd import residuals as R
+    B, T, X, Y = 256, 8, 64, 64                                               # M = 2^15 cells per sample
+    g = torch.Generator(device=gpu).manual_seed(3)
+    M = T * X * Y
+    assert _lib.wants_row_pad(B, M) and not _lib.wants_row_pad(240, M) and not _lib.wants_row_pad(B, M + 4)
+    alphas = [0.1, 0.5, 0.9]
+    for layout in ("ny", "nt"):
+        sur = torch.rand(B, 6, X, Y, T, device=gpu, generator=g) + 0.5
+        v = sur.permute(0, 1, 4, 2, 3) if layout == "nt" else sur.permute(0, 1, 4, 2, 3).contiguous()
+        for name, fn in (("ns", lambda a: R.NavierStokes(0.01, 1 / X, 1 / Y).residual_momentum(v[:, :3], True, absolute=a)),
+                         ("induction", lambda a: R.MHD().residual_induction(v, True, absolute=a)),
+                         ("gauss", lambda a: R.MHD().residual_gauss(v, True, absolute=a)),
+                         ("wave", lambda a: R.PRE_Wave(0.01, 0.02).residual(v[:, 0], True, absolute=a))):
+            signed, a = fn(False), fn(True)
+            assert signed.stride(0) == M and a.stride(0) == M + 64, (layout, name)
+            assert a.stride()[1:] == signed.stride()[1:] and torch.equal(a, signed.abs()), (layout, name)
+            lie = icp.rows_where_they_lie(a)
+            assert lie is not None and lie[1] == M + 64 and lie[0].data_ptr() == a.data_ptr()
+            q = pipeline.marginal_qhat(a, alphas)
+            want = torch.sort(signed.abs().contiguous(), dim=0).values[[icp.kth_index(B, B, al) for al in alphas]]
+            assert q.shape == want.shape and torch.equal(q, want), (layout, name)
+    # a batch below the register-tile sizes stays dense; so does a CPU input's result (it goes home as a dense tensor)
+    small = R.MHD().residual_induction(v[:200], True, absolute=True)
+    assert small.stride(0) == M
+    home = R.MHD().residual_induction(v.cpu(), True, absolute=True)
+    assert home.device.type == "cpu" and torch.equal(home, R.MHD().residual_induction(v, True).abs().cpu())
+    # out= on the MHD entries: a plane-major (time-major) buffer, the send blocks of the sharded marginal exchange
+    vc = v.contiguous()
+    tm = pipeline.time_major(B, (T, X, Y), pad=64, device=gpu)
+    got = R.MHD().residual_induction(vc, True, absolute=True, out=tm)
+    assert got.data_ptr() == tm.data_ptr() and torch.equal(tm, R.MHD().residual_induction(vc, True).abs())
+    with pytest.raises(ValueError):
+        R.MHD().residual_induction(vc, True, out=torch.empty(B, T, X, Y + 4, device=gpu))
 
 
 @pytest.mark.parametrize("T", [10, 20, 30, 64])
