@@ -128,6 +128,9 @@ def parse():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--equation", choices=sorted(MHD_EQUATIONS), default="induction",
                     help="c4: which of the five MHD residuals (default: the script's own, induction)")
+    ap.add_argument("--layout", choices=["ny", "nt"], default="ny",
+                    help="c4: nt = the fields in the surrogate's Nt-fastest layout, [BS,F,Nx,Ny,Nt].permute(0,1,4,2,3), as the "
+                         "reference script passes them (Marginal/MHD_Residuals_CP.py:326-346); ny = contiguous [BS,F,Nt,Nx,Ny]")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -967,6 +970,10 @@ def main():
 
     if args.config != "c3":
         cfg = mhd_config(args.equation) if args.config == "c4" else CONFIGS[args.config]
+        if args.config == "c4" and args.layout == "nt":
+            cfg = dict(cfg, layout="nt", pmc_key=args.equation + "_ntfast",
+                       kernel=cfg["kernel"].replace("march_kernel<", "flat_march_kernel<").replace("<0>,8,64>", "<3>>"),
+                       title=cfg["title"] + ", fields in the surrogate's Nt-fastest layout [BS,F,Nx,Ny,Nt].permute(0,1,4,2,3) (:326-346)")
         line = run_secondary(args, cfg, dev, group, rank, world, par)
         if line is not None:
             emit(line)

@@ -259,6 +259,7 @@ struct JorekParams { Star Dt, DR, DZ, DRR, DZZ; float a0, a1, a2, a3; };
 template <int MODE>
 struct JorekContinuity {
     static constexpr int F = 3;        // rho, phi, R
+    static constexpr unsigned XMASK = xmask_of<MODE>(O_DT | O_DX | O_DY, O_DX | O_DY, 0);      // (R: its centre value only)
     using Params = JorekParams;
     static __device__ __forceinline__ float4 eval(const Nbr (&n)[3], const Params &p)
     {
@@ -279,6 +280,7 @@ struct JorekContinuity {
 template <int MODE>
 struct JorekTemperature {
     static constexpr int F = 4;        // rho, phi, T, R
+    static constexpr unsigned XMASK = xmask_of<MODE>(O_DT | O_DX | O_DY, O_DX | O_DY, O_DT | O_DX | O_DY, 0);
     using Params = JorekParams;
     static __device__ __forceinline__ float4 eval(const Nbr (&n)[4], const Params &p)
     {
@@ -310,6 +312,30 @@ __device__ __forceinline__ float4 ldg4(const float *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void stg4(float *p, const float4 &r) { *reinterpret_cast<F4u *>(p) = F4u{r.x, r.y, r.z, r.w}; }
+
+// y-neighbours from the adjacent lane: the value of lane - 1 / lane + 1 of the 64-wide wave (a wave's first / last lane
+// gets something unspecified: the callers give those lanes their edge scalar).  MARCH_DPP: one `v_mov_b32_dpp wave_shr:1 /
+// wave_shl:1` each (gfx9 DPP wave shifts: tools/exp/dpp_probe.hip) instead of `__shfl_up / __shfl_down`, which compile to
+// ds_bpermute_b32 - a trip through the LDS crossbar and an lgkmcnt wait per neighbour.
+#ifndef MARCH_DPP
+#define MARCH_DPP 0
+#endif
+__device__ __forceinline__ float lane_below(float x)
+{
+#if MARCH_DPP
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, false));
+#else
+    return __shfl_up(x, 1);
+#endif
+}
+__device__ __forceinline__ float lane_above(float x)
+{
+#if MARCH_DPP
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, false));
+#else
+    return __shfl_down(x, 1);
+#endif
+}
 
 // Barrier that orders LDS traffic only: __syncthreads() would also drain vmcnt and with it
 // the global prefetches that are meant to stay in flight across the barrier.
@@ -542,8 +568,8 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
             } else {
                 n[i].xm = n[i].xp = f4(__builtin_nanf(""));      // never read by the functor (or the result says so)
             }
-            float lft = __shfl_up(C[i].w, 1);
-            float rgt = __shfl_down(C[i].x, 1);
+            float lft = lane_below(C[i].w);
+            float rgt = lane_above(C[i].x);
             lft = ledge ? hc.ye[i] : lft;
             rgt = redge ? (BC ? hc.yr[i] : hc.ye[i]) : rgt;
             n[i].ym = make_float4(lft, C[i].x, C[i].y, C[i].z);
@@ -606,6 +632,48 @@ int pick_mode(const Star &Dt, const Star &Dx, const Star &Dy, const Star *L)
     return 2;
 }
 
+// ---- how finely to cut the marched axis (round 6) ------------------------------------------------------------------
+// A workgroup marches a whole t segment; the chip holds `slots` workgroups at once, so a launch runs in rounds and the
+// last round is as full as it happens to be: 3200 workgroups on 768 slots are 4.2 rounds - the fifth runs a sixth full
+// and the launch takes 5 rounds' time (NS momentum on [800,20,256,256] Nt-fastest: 4.1 instead of 3.4 ms when a
+// different chunk width changed nothing but that).  Segments cost their window prologue (two planes loaded without an
+// output).  Chosen: the segment length that minimises (1 + 3 / tSeg) x (ceil(rounds) + 1/2) / rounds; rounds below 1 = the
+// share of the chip that is busy at all (small problems: as many segments as the 16-plane floor allows, as before).
+int chip_cus()
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
+
+template <class K> int resident_per_cu(K kernel, int threads)
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) n = 1;
+    return n;
+}
+
+int pick_tseg(long long tiles, int T, long long slots)
+{
+    int best = T;
+    double bestc = 1e300;
+    for (int tSeg = T;; tSeg = (tSeg + 1) / 2) {
+        const long long wgs = tiles * ((T + tSeg - 1) / tSeg);
+        const double rounds = (double)wgs / (double)slots;
+        // (+ half a round: workgroups do not finish in lockstep, and the fewer the rounds the more of the launch is its ragged
+        // end - [200,20,512,512] Nt-fastest: 1000 workgroups of 512 planes on 512 slots, "two full rounds", ran 3.6 % slower
+        // than 4000 of 128)
+        const double full = (rounds <= 1.0 ? 1.0 : (double)((wgs + slots - 1) / slots)) + 0.5;
+        const double cost = (1.0 + 3.0 / tSeg) * full / rounds;     // (planes t0 - 1, t1 and the prefetched t1 + 1 are read for nothing)
+        if (cost < bestc * 0.99) { best = tSeg; bestc = cost; }       // (near-ties go to the longer segments)
+        if (tSeg <= 16) break;
+    }
+    return best;
+}
+
 template <class Fn, int NR, int TYQ, bool BC = false>
 int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const BCInfo *bc = nullptr)
 {
@@ -615,11 +683,11 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const 
     g.nYT = (g.Yc + 4 * TYQ - 1) / (4 * TYQ);
     for (int i = 0; i < Fn::F; ++i)            // a thread's place in a plane is a 32-bit byte offset (from one row before row 0)
         if (g.sX[i] < 0 || ((long long)(g.X + 2 + NR) * g.sX[i] + g.Y + 8) * 4 >= (1LL << 32)) return PRE_E_UNSUPPORTED;
-    // split long T axes so the grid fills the chip (>= ~4 workgroups per CU) without
-    // paying the 2-plane window prologue too often
+    // split long T axes so that the grid fills the chip and its last round of workgroups is nearly full, without paying
+    // the 2-plane window prologue too often (pick_tseg)
     long long tiles = (long long)g.B * g.nXT * g.nYT;
-    int tSeg = g.T;
-    while (tiles * ((g.T + tSeg - 1) / tSeg) < 2048 && tSeg > 16) tSeg = (tSeg + 1) / 2;
+    static const int per_cu = resident_per_cu(march_kernel<Fn, NR, TYQ, BC>, NR * TYQ);
+    const int tSeg = pick_tseg(tiles, g.T, (long long)per_cu * chip_cus());
     g.tSeg = tSeg;
     g.nTSeg = (g.T + tSeg - 1) / tSeg;
     tiles *= g.nTSeg;
@@ -646,13 +714,52 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const 
 // the reference layout (below 96 columns the regular kernel is down to its 64-column tile: measured at 80 columns
 // wave 3.7 -> 4.9, MHD induction 3.4 -> 4.4 TB/s, NS momentum 3.7 -> 3.5; from 100 columns up the regular tiles win).
 constexpr int FLAT_NT = 512, FLAT_H = 32;
+#ifndef FLAT_MAX_Y
+#define FLAT_MAX_Y 96           // contiguous extents below this take the flat (merged-axis) form when the layout allows
+#endif
+#ifndef FLAT_NT_GAIN
+#define FLAT_NT_GAIN 8          // a narrower chunk must save this many per cent of a row's lanes to be taken (measured:
+                                // profiles/r06/flat_ab_chunk_width.txt - 4 chunks of 320 lost 7 % to 3 of 448 at Nt = 20, 256 wide)
+#endif
+#ifndef FLAT_SYNC
+#define FLAT_SYNC 0            // experiment: a bare s_barrier per plane in the kernels that stage nothing
+#endif
+#ifndef FLAT_NOLDS_NT
+#define FLAT_NOLDS_NT 512       // widest chunk of a functor that stages nothing (no LDS, no barrier: the workgroup size is free)
+#endif
+
+// Round 6: only the fields a functor reads x-NEIGHBOURS of (Staged<Fn>, as in march_kernel) go through LDS, and their halo is
+// as wide as an x-neighbour is far - ceil(Ty / 4) quads per side instead of a fixed 32 (Ty = 10 on a 256-wide grid: 6 halo
+// quads per 320-quad chunk instead of 64 - a fifth of the chunk's loads).  A field that is read at the centre and along
+// t / y only takes its y-neighbours from the adjacent lane (wavefront shuffle), the first / last lane of a wave fetching one
+// scalar - no LDS store, no halo, and when no field is staged (every MHD functor in the surrogate's Nt-fastest layout: its
+// taps lie on the kernel's t and y axes) no LDS and no barrier at all.
+#ifndef FLAT_STAGE_ALL
+#define FLAT_STAGE_ALL 0        // experiment: 1 = every field through LDS (rounds 2-5), whatever the functor reads
+#endif
+#ifndef FLAT_HALO_FULL
+#define FLAT_HALO_FULL 0        // experiment: 1 = FLAT_H halo quads per side whatever Ty (rounds 2-5)
+#endif
+template <class Fn> struct AllStaged {
+    static constexpr int count = Fn::F, FX = Fn::F;
+    static __device__ __forceinline__ constexpr bool has(int) { return true; }
+    static __device__ __forceinline__ constexpr int slot(int i) { return i; }
+};
+template <class Fn> using FlatStaged = typename std::conditional<FLAT_STAGE_ALL != 0, AllStaged<Fn>, Staged<Fn>>::type;
+
+template <int F> struct FlatHalo {
+    float4 q[F];     // staged fields: the halo quad this thread fetches
+    float e[F];      // unstaged fields: the y- cell of a wave's first lane / the y+ cell of its last lane
+};
 
 template <class Fn>
 __global__ void __launch_bounds__(FLAT_NT, MinWaves<Fn>::value)
 flat_march_kernel(const Geom g, const typename Fn::Params prm)
 {
     constexpr int F = Fn::F;
-    __shared__ float4 lds[2][F][FLAT_NT + 2 * FLAT_H];
+    using SX = FlatStaged<Fn>;
+    constexpr bool ANY = SX::count > 0;
+    __shared__ float4 lds[2][SX::FX][ANY ? FLAT_NT + 2 * FLAT_H : 1];
     const int q = threadIdx.x;
     unsigned Lb = xcd_remap(blockIdx.x, gridDim.x);
     const int ch = Lb % g.nYT; Lb /= g.nYT;
@@ -670,12 +777,14 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
         t1 = min(t1, g.T - 1);
     }
 
-    // halo duty: the first / last FLAT_H threads fetch one quad left / right of the chunk (L % 4 == 0: a quad is
-    // entirely inside the row or entirely padding)
-    const bool hl = q < FLAT_H, hr = q >= NT - FLAT_H;
-    const int hm = hl ? m0 - 4 * FLAT_H + 4 * q : m0 + 4 * NT + 4 * (q - (NT - FLAT_H));
+    // halo duty (staged fields): the first / last HQ threads fetch one quad left / right of the chunk, HQ = the quads an
+    // x-neighbour (Ty cells away) can reach into (L % 4 == 0: a quad is entirely inside the row or entirely padding).
+    // The LDS image keeps room for FLAT_H quads per side: the left halo ends at slot FLAT_H, the right one starts at FLAT_H + NT.
+    const int HQ = FLAT_HALO_FULL ? FLAT_H : min(FLAT_H, (Ty + 3) >> 2);
+    const bool hl = q < HQ, hr = q >= NT - HQ;
+    const int hm = hl ? m0 - 4 * (HQ - q) : m0 + 4 * NT + 4 * (q - (NT - HQ));
     const bool hok = (hl || hr) && hm >= 0 && hm < L;
-    const int hslot = hl ? q : q + 2 * FLAT_H;      // right halo quad k sits at FLAT_H + NT + k, k = q - (NT - FLAT_H)
+    const int hslot = hl ? FLAT_H - HQ + q : FLAT_H + NT + (q - (NT - HQ));
 
     // which of my four cells have a y- / y+ neighbour inside their own x row
     bool lok[4], rok[4];
@@ -688,18 +797,25 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
             ph = ph + 1 == Ty ? 0 : ph + 1;
         }
     }
+    // edge duty (unstaged fields): a wave's first lane fetches the cell before its quad, its last lane the cell after -
+    // if that cell is a y-neighbour at all (same x row; the row's last cell has rok == false, so nothing beyond L is read)
+    const bool ledge = (q & 63) == 0, redge = (q & 63) == 63;
+    const bool eload = inb && (ledge ? lok[0] : (redge && rok[3]));
 
     // a plane of a field of this sample = a wave-uniform buffer descriptor; the thread's own quad and its halo quad are
     // two 32-bit byte offsets shared by every field (the flat form takes fields of one in-plane layout): as 64-bit
     // pointers they cost 4 registers per field (JOREK temperature in its native layout: 139 registers, one workgroup per CU)
     const unsigned int voff = (unsigned int)m * 4u, hoff = (unsigned int)hm * 4u;       // (hm < 0: never loaded)
+    const unsigned int eoff = ledge ? voff - 4u : voff + 16u;                           // (never loaded where it would be outside)
     float *outp = g.out + (long long)b * g.oB + m;
     const long long oT = g.oT;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    auto quad = [&](int i, int t, unsigned int off) __attribute__((always_inline)) {
+    auto rsrc = [&](int i, int t) __attribute__((always_inline)) {
         const float *p = g.f[i] + ((long long)b * g.sB[i] + (long long)t * g.sT[i]);
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, -1, 0x00020000),
-                                                              (int)off, 0, 0);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, -1, 0x00020000);
+    };
+    auto quad = [&](int i, int t, unsigned int off) __attribute__((always_inline)) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc(i, t), (int)off, 0, 0);
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
 
@@ -711,47 +827,67 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
             else dst[i] = f4(0.f);
         }
     };
-    auto load_halo = [&](int t, float4(&dst)[F]) __attribute__((always_inline)) {
-        const bool ok = hok && (t >= 0) && (t < g.T);
+    auto load_halo = [&](int t, FlatHalo<F> &h) __attribute__((always_inline)) {
+        const bool okt = (t >= 0) && (t < g.T);
 #pragma unroll
         for (int i = 0; i < F; ++i) {
-            if (ok) dst[i] = quad(i, t, hoff);
-            else dst[i] = f4(0.f);
+            if (SX::has(i)) {
+                h.e[i] = 0.f;
+                if (hok && okt) h.q[i] = quad(i, t, hoff);
+                else h.q[i] = f4(0.f);
+            } else {
+                h.q[i] = f4(0.f);
+                h.e[i] = (eload && okt) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc(i, t), (int)eoff, 0, 0)) : 0.f;
+            }
         }
     };
 
-    auto step = [&](int t, float4(&P)[F], float4(&C)[F], float4(&N)[F], float4(&D)[F], float4(&hc)[F],
-                    float4(&hn)[F]) __attribute__((always_inline)) {
+    auto step = [&](int t, float4(&P)[F], float4(&C)[F], float4(&N)[F], float4(&D)[F], FlatHalo<F> &hc,
+                    FlatHalo<F> &hn) __attribute__((always_inline)) {
         const int bi = (t - t0) & 1;
 #pragma unroll
         for (int i = 0; i < F; ++i) {
-            lds[bi][i][FLAT_H + q] = C[i];
-            if (hl || hr) lds[bi][i][hslot] = hc[i];
+            if (!SX::has(i)) continue;
+            const int k = SX::slot(i);
+            lds[bi][k][FLAT_H + q] = C[i];
+            if (hl || hr) lds[bi][k][hslot] = hc.q[i];
         }
         load_halo(t + 1, hn);
         load_own(t + 2, D);
-        lds_barrier();
+        if constexpr (ANY) lds_barrier();
+        else if (FLAT_SYNC) __builtin_amdgcn_s_barrier();       // (no data to order: keeps the workgroup's waves on one plane)
 
         Nbr n[F];
 #pragma unroll
         for (int i = 0; i < F; ++i) {
-            const float *row = reinterpret_cast<const float *>(&lds[bi][i][0]) + 4 * (FLAT_H + q);      // my first cell
             n[i].c = C[i];
             n[i].tm = P[i];
             n[i].tp = N[i];
-            if ((Ty & 3) == 0) {                     // wave-uniform: the x neighbours are whole quads
-                n[i].xm = lds[bi][i][FLAT_H + q - (Ty >> 2)];
-                n[i].xp = lds[bi][i][FLAT_H + q + (Ty >> 2)];
-            } else if ((Ty & 1) == 0) {              // Ty = 10, 30, 50 (T_out of the reference scripts): 8-byte aligned pairs
-                const float2 a = *reinterpret_cast<const float2 *>(row - Ty), b = *reinterpret_cast<const float2 *>(row + 2 - Ty);
-                const float2 c = *reinterpret_cast<const float2 *>(row + Ty), d = *reinterpret_cast<const float2 *>(row + 2 + Ty);
-                n[i].xm = make_float4(a.x, a.y, b.x, b.y);
-                n[i].xp = make_float4(c.x, c.y, d.x, d.y);
+            float lft, rgt;
+            if (SX::has(i)) {
+                const int k = SX::slot(i);
+                const float *row = reinterpret_cast<const float *>(&lds[bi][k][0]) + 4 * (FLAT_H + q);      // my first cell
+                if ((Ty & 3) == 0) {                     // wave-uniform: the x neighbours are whole quads
+                    n[i].xm = lds[bi][k][FLAT_H + q - (Ty >> 2)];
+                    n[i].xp = lds[bi][k][FLAT_H + q + (Ty >> 2)];
+                } else if ((Ty & 1) == 0) {              // Ty = 10, 30, 50 (T_out of the reference scripts): 8-byte aligned pairs
+                    const float2 a = *reinterpret_cast<const float2 *>(row - Ty), b = *reinterpret_cast<const float2 *>(row + 2 - Ty);
+                    const float2 c = *reinterpret_cast<const float2 *>(row + Ty), d = *reinterpret_cast<const float2 *>(row + 2 + Ty);
+                    n[i].xm = make_float4(a.x, a.y, b.x, b.y);
+                    n[i].xp = make_float4(c.x, c.y, d.x, d.y);
+                } else {
+                    n[i].xm = make_float4(row[-Ty], row[1 - Ty], row[2 - Ty], row[3 - Ty]);
+                    n[i].xp = make_float4(row[Ty], row[Ty + 1], row[Ty + 2], row[Ty + 3]);
+                }
+                lft = row[-1];
+                rgt = row[4];
             } else {
-                n[i].xm = make_float4(row[-Ty], row[1 - Ty], row[2 - Ty], row[3 - Ty]);
-                n[i].xp = make_float4(row[Ty], row[Ty + 1], row[Ty + 2], row[Ty + 3]);
+                n[i].xm = n[i].xp = f4(__builtin_nanf(""));      // never read by the functor (or the result says so)
+                lft = lane_below(C[i].w);
+                rgt = lane_above(C[i].x);
+                lft = ledge ? hc.e[i] : lft;
+                rgt = redge ? hc.e[i] : rgt;
             }
-            const float lft = row[-1], rgt = row[4];
             n[i].ym = make_float4(lok[0] ? lft : 0.f, lok[1] ? C[i].x : 0.f, lok[2] ? C[i].y : 0.f, lok[3] ? C[i].z : 0.f);
             n[i].yp = make_float4(rok[0] ? C[i].y : 0.f, rok[1] ? C[i].z : 0.f, rok[2] ? C[i].w : 0.f, rok[3] ? rgt : 0.f);
         }
@@ -760,7 +896,8 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
         if (inb) stg4(outp + (long long)t * oT, r);
     };
 
-    float4 w0[F], w1[F], w2[F], w3[F], h0[F], h1[F];
+    float4 w0[F], w1[F], w2[F], w3[F];
+    FlatHalo<F> h0, h1;
     load_own(t0 - 1, w0);
     load_own(t0, w1);
     load_own(t0 + 1, w2);
@@ -779,20 +916,23 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
 template <class Fn>
 int launch_flat(Geom &g, const typename Fn::Params &prm, hipStream_t st)
 {
-    static_assert(2 * Fn::F * (FLAT_NT + 2 * FLAT_H) * 16 <= 160 * 1024, "chunk does not fit the 160 KiB LDS");
+    static_assert(2 * FlatStaged<Fn>::FX * (FLAT_NT + 2 * FLAT_H) * 16 <= 160 * 1024, "chunk does not fit the 160 KiB LDS");
     g.nXT = 1;
     if ((long long)g.X * g.Y >= (1LL << 30)) return PRE_E_UNSUPPORTED;      // a thread's place in a plane is a 32-bit byte offset
     // chunk = 512 quads, or 448 / 384 / 320 / 256 when that leaves fewer idle lanes in the row's last chunk (the
     // surrogate's Nt = 10 on a 256-wide grid is a row of 640 quads: two chunks of 320 instead of 512 + 128)
     const long long quads = (long long)g.X * g.Y / 4;
-    // cost of a row = chunks x (quads + 64 halo quads staged per chunk); ties go to the wider chunk
-    int nt = FLAT_NT;
-    for (int c = FLAT_NT - 64; c >= 256; c -= 64)
-        if ((quads + c - 1) / c * (c + 2 * FLAT_H) < (quads + nt - 1) / nt * (nt + 2 * FLAT_H)) nt = c;
+    // cost of a row = chunks x (quads + the halo quads staged per chunk: ceil(Ty / 4) per side for a functor that stages
+    // any field, none otherwise); ties go to the wider chunk
+    const int halo = FLAT_HALO_FULL ? 2 * FLAT_H : FlatStaged<Fn>::count > 0 ? 2 * ((g.Y + 3) / 4 < FLAT_H ? (g.Y + 3) / 4 : FLAT_H) : 0;
+    int nt = FlatStaged<Fn>::count > 0 ? FLAT_NT : FLAT_NOLDS_NT;
+    for (int c = nt - 64; c >= 256; c -= 64)
+        if ((quads + c - 1) / c * (c + halo) * 100 < (quads + nt - 1) / nt * (nt + halo) * (100 - FLAT_NT_GAIN)) nt = c;
     g.nYT = (int)((quads + nt - 1) / nt);
     long long tiles = (long long)g.B * g.nYT;
-    int tSeg = g.T;
-    while (tiles * ((g.T + tSeg - 1) / tSeg) < 2048 && tSeg > 16) tSeg = (tSeg + 1) / 2;
+    static int per_cu[FLAT_NT / 64 + 1] = {};                                 // (by chunk width; 0 = not asked yet)
+    if (!per_cu[nt / 64]) per_cu[nt / 64] = resident_per_cu(flat_march_kernel<Fn>, nt);
+    const int tSeg = pick_tseg(tiles, g.T, (long long)per_cu[nt / 64] * chip_cus());
     g.tSeg = tSeg;
     g.nTSeg = (g.T + tSeg - 1) / tSeg;
     tiles *= g.nTSeg;
@@ -865,7 +1005,7 @@ int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const
     // one long axis for the flat form of the kernel: only their product has to be a multiple of 4.
     if ((flags & PRE_FLAG_HALO_X) && relabeled) return PRE_E_UNSUPPORTED;      // the halo rows are on the caller's x axis
     if (flags & PRE_FLAG_HALO_X) allow_flat = false;                           // (the flat form pads x with zeros)
-    bool flat = allow_flat && D[p[2]] < 96 && ostride(p[1]) == D[p[2]] && (D[p[1]] * D[p[2]]) % 4 == 0 && D[p[1]] > 1;
+    bool flat = allow_flat && D[p[2]] < FLAT_MAX_Y && ostride(p[1]) == D[p[2]] && (D[p[1]] * D[p[2]]) % 4 == 0 && D[p[1]] > 1;
     for (int i = 0; i < nf; ++i) flat = flat && stride(fs[i], p[1]) == D[p[2]];
     g.flat = flat;
     if (!flat && (relaxed ? D[p[2]] < 4 : D[p[2]] % 4 != 0)) return PRE_E_UNSUPPORTED;
