@@ -380,6 +380,9 @@ struct NoBC {};
 #ifndef MARCH6_MINW
 #define MARCH6_MINW 1
 #endif
+#ifndef MARCH6_AHEAD
+#define MARCH6_AHEAD 2          // 3: the functors of five or more fields request their own cells three planes ahead
+#endif
 #ifndef MARCH_COOP_MAXF
 #define MARCH_COOP_MAXF 4
 #endif
@@ -405,6 +408,7 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
 {
     constexpr int F = Fn::F;
     using SX = Staged<Fn>;
+    constexpr int AHEAD = (F >= 5 && MARCH6_AHEAD == 3) ? 3 : 2;       // planes between a plane's request and its use as t + 1
     static_assert(NR >= 2, "tile needs at least two rows (top and bottom halo owners differ)");
     __shared__ float4 lds[2][SX::FX][NR + 2][TYQ];
 
@@ -553,7 +557,7 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
         // (measured +7 % on NS momentum vs the other order; non-temporal stores: -25 %; round 3: the own-cell loads with
         // the slc / nt bit -5 ... -12 % on every functor, with glc +-0)
         load_halo(t + 1, hn);
-        load_own(t + 2, D);
+        load_own(t + AHEAD, D);
         if constexpr (SX::count > 0) lds_barrier();
 
         Nbr n[F];
@@ -582,21 +586,44 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
         }
     };
 
-    float4 w0[F], w1[F], w2[F], w3[F];
     Halo<F, BC, COOP> h0, h1;
-    load_own(t0 - 1, w0);
-    load_own(t0, w1);
-    load_own(t0 + 1, w2);
-    load_halo(t0, h0);
-
-    for (int t = t0; t < t1; t += 4) {
-        step(t, w0, w1, w2, w3, h0, h1);
-        if (t + 1 >= t1) break;
-        step(t + 1, w1, w2, w3, w0, h1, h0);
-        if (t + 2 >= t1) break;
-        step(t + 2, w2, w3, w0, w1, h0, h1);
-        if (t + 3 >= t1) break;
-        step(t + 3, w3, w0, w1, w2, h1, h0);
+    if constexpr (AHEAD == 3) {
+        // experiment (MARCH6_AHEAD=3): the own cells of plane t + 3 are requested before plane t is computed - a five-plane
+        // ring, five steps per trip; the halo pair has then flipped an odd number of times and is copied back (F + F/4
+        // registers per five planes)
+        float4 w0[F], w1[F], w2[F], w3[F], w4[F];
+        load_own(t0 - 1, w0);
+        load_own(t0, w1);
+        load_own(t0 + 1, w2);
+        load_own(t0 + 2, w3);
+        load_halo(t0, h0);
+        for (int t = t0; t < t1; t += 5) {
+            step(t, w0, w1, w2, w4, h0, h1);
+            if (t + 1 >= t1) break;
+            step(t + 1, w1, w2, w3, w0, h1, h0);
+            if (t + 2 >= t1) break;
+            step(t + 2, w2, w3, w4, w1, h0, h1);
+            if (t + 3 >= t1) break;
+            step(t + 3, w3, w4, w0, w2, h1, h0);
+            if (t + 4 >= t1) break;
+            step(t + 4, w4, w0, w1, w3, h0, h1);
+            h0 = h1;
+        }
+    } else {
+        float4 w0[F], w1[F], w2[F], w3[F];
+        load_own(t0 - 1, w0);
+        load_own(t0, w1);
+        load_own(t0 + 1, w2);
+        load_halo(t0, h0);
+        for (int t = t0; t < t1; t += 4) {
+            step(t, w0, w1, w2, w3, h0, h1);
+            if (t + 1 >= t1) break;
+            step(t + 1, w1, w2, w3, w0, h1, h0);
+            if (t + 2 >= t1) break;
+            step(t + 2, w2, w3, w0, w1, h0, h1);
+            if (t + 3 >= t1) break;
+            step(t + 3, w3, w0, w1, w2, h1, h0);
+        }
     }
 }
 
