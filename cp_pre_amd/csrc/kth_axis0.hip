@@ -70,6 +70,9 @@ namespace {
 #ifndef KA_U_B
 #define KA_U_B 16
 #endif
+#ifndef KA_REV
+#define KA_REV 1                // the collect sweep of the tag forms runs from the tile's last rows to its first (ka_sweep_h_rev)
+#endif
 #ifndef KA_KEEP
 #define KA_KEEP 80
 #endif
@@ -284,6 +287,51 @@ __device__ __forceinline__ void ka_sweep_h(const float *__restrict__ col, bool c
 #pragma unroll
         for (int h = 0; h < U; h += H)
             if (h < left) g(*reinterpret_cast<float(*)[H]>(&v[h]), left - h < H ? left - h : H);
+    }
+}
+
+// ... and the same BACKWARDS: the partial last batch first, then the full batches from the highest rows down to `first`.
+// The collect sweep of the two-sweep forms runs this way (round 6): the histogram sweep has just read the tile's rows in
+// ascending order, so its LAST rows are the ones most recently brought on die - with one 1-2 MB tile per CU in flight,
+// half a gigabyte chip-wide, the 256 MiB Infinity Cache still holds the rows at most ~2000 loads back when the second
+// sweep starts, and none of the rows the forward order asked for first (they are the oldest).  The rows a thread keeps in
+// registers between the sweeps are its FIRST rows, the coldest ones.  Which elements join which list does not depend on
+// the order (the lists are sorted afterwards).
+template <int U, int H, class G>
+__device__ __forceinline__ void ka_sweep_h_rev(const float *__restrict__ col, bool cok, int n, long long M, int wave, G &&g, int first = 0)
+{
+    static_assert(U % H == 0, "half batches");
+    if (!cok) return;
+    constexpr int STEP = U * KA_WAVES, SPAN = (U - 1) * KA_WAVES;
+    const int loff = (int)(threadIdx.x & 63u) * 4;
+    const long long stride = (long long)KA_WAVES * M;
+    const int i0 = wave + first * KA_WAVES;
+    const int nb = n - SPAN - i0 > 0 ? (n - SPAN - i0 + STEP - 1) / STEP : 0;       // full batches (wave-uniform)
+    {
+        const int i = i0 + nb * STEP;
+        if (i < n) {
+            const float *p = col + (long long)i * M;
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const __amdgpu_buffer_rsrc_t r =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, i + u * KA_WAVES < n ? 256 : 0, 0x00020000);
+                v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, loff, 0, 0));
+                p += stride;
+            }
+            const int left = (n - i + KA_WAVES - 1) / KA_WAVES;       // rows of mine in this batch (wave-uniform)
+#pragma unroll
+            for (int h = 0; h < U; h += H)
+                if (h < left) g(*reinterpret_cast<float(*)[H]>(&v[h]), left - h < H ? left - h : H);
+        }
+    }
+    for (int j = nb - 1; j >= 0; --j) {
+        const float *p = col + (long long)(i0 + j * STEP) * M;
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ka_row(p + (long long)(U - 1 - u) * stride, loff);      // (highest row first)
+#pragma unroll
+        for (int h = 0; h < U; h += H) g(*reinterpret_cast<float(*)[H]>(&v[h]), H);
     }
 }
 
@@ -815,7 +863,11 @@ __device__ __forceinline__ bool ka_fast_tags(const float *__restrict__ col, bool
 #pragma unroll
         for (int u = 0; u < KEEP; u += H) collect(*reinterpret_cast<float(*)[H]>(&kept[u]), H);
     }
+#if KA_REV
+    ka_sweep_h_rev<U, H>(col, cok, n, M, wave, collect, KEEP);
+#else
     ka_sweep_h<U, H>(col, cok, n, M, wave, collect, KEEP);
+#endif
     __syncthreads();
     if (state) {                                               // (whole waves: cmax is theirs)
         const unsigned int base = cnt[myslot * 64 + lane] - count * 256u;

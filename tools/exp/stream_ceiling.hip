@@ -36,7 +36,8 @@ __global__ void fill_kernel(float *p, size_t n)
 }
 
 template <int F, int D, int LDSB>
-__global__ void __launch_bounds__(512) stream_kernel(const float *in, float *out, int T, int X, int Y, long long sF, long long sB)
+__global__ void __launch_bounds__(512) stream_kernel(const float *in, float *out, int T, int X, int Y, long long sF, long long sB,
+                                                     long long plane, long long oB)
 {
     __shared__ float pad[LDSB / 4];
     const int q = threadIdx.x, ty = threadIdx.y;
@@ -48,7 +49,6 @@ __global__ void __launch_bounds__(512) stream_kernel(const float *in, float *out
     const int x = xt * 8 + ty, y = (yt * 64 + q) * 4;
     pad[ty * 64 + q] = (float)x;                                  // (keeps the allocation alive)
     const unsigned voff = (unsigned)((x * Y + y) * 4);
-    const long long plane = (long long)X * Y;
     auto rsrc = [&](int i, int t) __attribute__((always_inline)) {
         const float *p = in + (long long)b * sB + (long long)i * sF + (long long)t * plane;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, -1, 0x00020000);
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(512) stream_kernel(const float *in, float *out
     };
 #pragma unroll
     for (int s = 0; s < D; ++s) load(s, w[s]);
-    float *op = out + (long long)b * T * plane + (long long)x * Y + y;
+    float *op = out + (long long)b * oB + (long long)x * Y + y;
     for (int t0 = 0; t0 < T; t0 += D + 1) {
 #pragma unroll
         for (int s = 0; s <= D; ++s) {
@@ -81,10 +81,22 @@ __global__ void __launch_bounds__(512) stream_kernel(const float *in, float *out
     if (pad[(ty * 64 + q + 1) & 511] == -12345.f) out[0] = 0.f;
 }
 
+// padP / padF / padB: floats added to the plane / field / sample stride of the INPUT (0 = the dense [B,F,T,X,Y] tensor the
+// reference's `vars` is); padO: floats added to the sample stride of the output
 template <int F, int D, int LDSB>
-void run(const float *in, float *out, int B, int T, int X, int Y, int Ftot)
+void run(const float *in, float *out, int B, int T, int X, int Y, int Ftot, long long padP = 0, long long padF = 0, long long padB = 0,
+         long long padO = 0)
 {
-    const long long plane = (long long)X * Y, sF = (long long)T * plane, sB = (long long)Ftot * sF;
+    const long long plane = (long long)X * Y + padP, sF = (long long)T * plane + padF, sB = (long long)Ftot * sF + padB;
+    const long long oB = (long long)T * plane + padO;
+    // the padded views must lie inside the two allocations (checked on the host: an out-of-bounds stream faults the GPU)
+    extern size_t g_nin, g_nout;
+    const long long need_in = (long long)(B - 1) * sB + (long long)(Ftot - 1) * sF + (long long)(T - 1) * plane + (long long)X * Y;
+    const long long need_out = (long long)(B - 1) * oB + (long long)(T - 1) * plane + (long long)X * Y;
+    if (need_in > (long long)g_nin || need_out > (long long)g_nout) {
+        printf("F = %d, pads plane %lld field %lld sample %lld out %lld: does not fit the buffers, skipped\n", F, padP, padF, padB, padO);
+        return;
+    }
     const unsigned grid = (unsigned)((long long)B * (X / 8) * (Y / 256));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -94,32 +106,54 @@ void run(const float *in, float *out, int B, int T, int X, int Y, int Ftot)
     const int reps = 5;
     for (int r = 0; r < reps + 1; ++r) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((stream_kernel<F, D, LDSB>), dim3(grid), dim3(64, 8), 0, 0, in, out, T, X, Y, sF, sB);
+        hipLaunchKernelGGL((stream_kernel<F, D, LDSB>), dim3(grid), dim3(64, 8), 0, 0, in, out, T, X, Y, sF, sB, plane, oB);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         if (r) { sum += ms; best = ms < best ? ms : best; }
     }
-    const double bytes = 4.0 * (F + 1) * B * T * plane;
-    printf("F = %d input streams + 1 output, prefetch %d planes, %3d KB LDS declared -> %d workgroup(s) of 512 per CU: "
+    const double bytes = 4.0 * (F + 1) * B * T * (double)X * Y;
+    printf("F = %d + 1 streams, prefetch %d, %3d KB LDS -> %d wg/CU, pads plane %lld field %lld sample %lld out %lld floats: "
            "%7.3f ms mean (%7.3f best)  %6.0f GB/s = %.3f of 8 TB/s\n",
-           F, D, LDSB / 1024, per_cu, sum / reps, best, bytes / (sum / reps) / 1e6, bytes / (sum / reps) / 1e6 / 8000.0);
+           F, D, LDSB / 1024, per_cu, padP, padF, padB, padO, sum / reps, best, bytes / (sum / reps) / 1e6, bytes / (sum / reps) / 1e6 / 8000.0);
     fflush(stdout);
 }
 
-int main()
+size_t g_nin = 0, g_nout = 0;
+
+int main(int argc, char **argv)
 {
-    const int B = 1024, Ftot = 6, T = 64, X = 256, Y = 256;
-    const size_t nin = (size_t)B * Ftot * T * X * Y, nout = (size_t)B * T * X * Y;
+    const int B = 1000, Ftot = 6, T = 64, X = 256, Y = 256;             // (1000 samples: room for the padded strides in the same buffers)
+    const size_t nin = (size_t)1024 * Ftot * T * X * Y + (64u << 20), nout = (size_t)1024 * T * X * Y + (16u << 20);
     float *in, *out;
+    g_nin = nin; g_nout = nout;
     CK(hipMalloc(&in, nin * 4));
     CK(hipMalloc(&out, nout * 4));
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, in, nin);          // (not zeros: U(0.5, 1.5) like the benchmarks' fields)
     CK(hipMemset(out, 0, nout * 4));
     CK(hipDeviceSynchronize());
-    printf("fields [%d,%d,%d,%d,%d] fp32 (%.0f GB), output [%d,%d,%d,%d]; tile 8 x 256 cells per 512-thread workgroup, T marched\n",
-           B, Ftot, T, X, Y, nin * 4 / 1e9, B, T, X, Y);
+    printf("fields [%d,%d,%d,%d,%d] fp32, output [%d,%d,%d,%d]; tile 8 x 256 cells per 512-thread workgroup, T marched\n",
+           B, Ftot, T, X, Y, B, T, X, Y);
+    if (argc > 1) {            // the stride experiment: do power-of-two plane / field / sample strides cost these streams anything?
+        for (int rep = 0; rep < 2; ++rep) {
+            run<6, 2, 100 * 1024>(in, out, B, T, X, Y, Ftot);
+            run<6, 2, 100 * 1024>(in, out, B, T, X, Y, Ftot, 0, 0, 0, 1088);
+            run<6, 2, 100 * 1024>(in, out, B, T, X, Y, Ftot, 0, 1088);
+            run<6, 2, 100 * 1024>(in, out, B, T, X, Y, Ftot, 0, 1088, 0, 4160);
+            run<6, 2, 100 * 1024>(in, out, B, T, X, Y, Ftot, 0, 16448, 0, 4160);
+            run<6, 2, 100 * 1024>(in, out, B, T, X, Y, Ftot, 64);
+            run<6, 2, 100 * 1024>(in, out, B, T, X, Y, Ftot, 1024);
+            run<6, 2, 100 * 1024>(in, out, B, T, X, Y, Ftot, 1024, 1088, 0, 4160);
+            run<3, 2, 50 * 1024>(in, out, B, T, X, Y, Ftot);
+            run<3, 2, 50 * 1024>(in, out, B, T, X, Y, Ftot, 0, 1088, 0, 4160);
+            run<3, 2, 50 * 1024>(in, out, B, T, X, Y, Ftot, 1024, 1088, 0, 4160);
+            run<1, 2, 50 * 1024>(in, out, B, T, X, Y, Ftot);
+            run<1, 2, 50 * 1024>(in, out, B, T, X, Y, Ftot, 0, 0, 0, 4160);
+            run<1, 2, 50 * 1024>(in, out, B, T, X, Y, Ftot, 1024, 0, 0, 4160);
+        }
+        return 0;
+    }
     run<6, 2, 100 * 1024>(in, out, B, T, X, Y, Ftot);
     run<6, 3, 100 * 1024>(in, out, B, T, X, Y, Ftot);
     run<6, 2, 50 * 1024>(in, out, B, T, X, Y, Ftot);
