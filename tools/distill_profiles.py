@@ -13,7 +13,7 @@ def short(k):
     """'void (anonymous namespace)::march_kernel<(anonymous namespace)::NSMomentum<0>, 8, 64, false>(...)' ->
     'march_kernel<NSMomentum<0>,8,64>'; torch/rccl kernels keep a trimmed name."""
     k = k.replace("(anonymous namespace)::", "").replace("void ", "")
-    k = re.sub(r"\(.*$", "", k).strip()
+    k = re.sub(r"\(.*$", "", k).strip().replace("> >", ">>")
     k = re.sub(r",\s*false,\s*true>$", ",SEG>", k)             # march_kernel<Fn,NR,TYQ,BC=false,SEG=true>
     k = re.sub(r",\s*false,\s*false>$", ">", k)
     k = re.sub(r",\s*(false|true)>$", lambda m: ">" if m.group(1) == "false" else ",BC>", k)
@@ -36,6 +36,9 @@ CMDS = {"trace": ("c3_joint", "--no-secondary --no-parity --steps 3 --warmup 1")
 EQS = ("induction", "continuity", "momentum", "energy", "gauss")
 for e in EQS:
     CMDS[f"trace_c4_{e}"] = (f"c4_{e}", f"--config c4 --equation {e} --steps 3 --warmup 1")
+for e in ("induction", "momentum"):
+    CMDS[f"trace_c4_{e}_nt"] = (f"c4_{e}_ntfast", f"--config c4 --equation {e} --layout nt --steps 3 --warmup 1")
+CMDS["trace_c5w"] = ("c5_whole", "--config c5 --batch 65536 --steps 3 --warmup 1")
 for src, (tag, cmd) in CMDS.items():
     f = newest(f"gpurun_out/prof/{src}/**/*_kernel_stats.csv")
     if not f:
@@ -65,7 +68,7 @@ def counters(src):
     return res
 
 
-OURS = ("march_kernel", "moments_kernel", "moments_segmax_kernel", "joint_score_kernel", "joint_score_pruned_kernel", "segmin_kernel",
+OURS = ("march_kernel", "flat_march_kernel", "moments_kernel", "moments_segmax_kernel", "joint_score_kernel", "joint_score_pruned_kernel", "segmin_kernel",
         "std_from_moments_kernel", "kth_")
 sys.path.insert(0, os.getcwd())
 import bench                                             # split_slabs / CONFIGS: the workloads the passes ran
@@ -132,6 +135,27 @@ for e in EQS:
     cells = shp[0] * shp[1] * shp[2] * shp[3]
     hbm_report(f"c4_{e}", f"fetch_c4_{e}", f"write_c4_{e}", cfg["kernel"], f"--config c4 --equation {e} --steps 1 --warmup 0 --no-cpu-baseline",
                {"batch": shp[0], "nt": shp[1], "nx": shp[2], "ny": shp[3]}, cfg["bpc"] * cells, note=f" {list(shp)} ({e})")
+# C3 marginal (same x-slabs, |res| into the row-padded score buffer)
+hbm_report("c3_marginal", "fetch_m", "write_m", MK, "--steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-parity --mode marginal",
+           {"batch": c3[0], "nt": c3[1], "nx": c3[2], "ny": c3[3], "slab": slab, "slab_axis": axis, "rows": "interior"},
+           sum(16 * sl * cells_xy for sl in slabs) / len(slabs),
+           sum((12 * (sl + 2) + 4 * sl) * cells_xy for sl in slabs) / len(slabs),
+           note=f" marginal mode: [4096,64,S+2,512] x3 -> |res| [4096,64,S,512] in rows 64 floats further apart, S in {slabs}")
+# C4 in the surrogate's Nt-fastest layout
+for e in ("induction", "momentum"):
+    cfg = bench.mhd_config(e)
+    shp = cfg["shape"]
+    cells = shp[0] * shp[1] * shp[2] * shp[3]
+    kern = cfg["kernel"].replace("march_kernel<", "flat_march_kernel<").replace("<0>,8,64>", "<3>>")
+    hbm_report(f"c4_{e}_ntfast", f"fetch_c4_{e}_nt", f"write_c4_{e}_nt", kern,
+               f"--config c4 --equation {e} --layout nt --steps 1 --warmup 0 --no-cpu-baseline",
+               {"batch": shp[0], "nt": shp[1], "nx": shp[2], "ny": shp[3]}, cfg["bpc"] * cells,
+               note=f" {list(shp)} ({e}), fields [BS,6,Nx,Ny,Nt].permute(0,1,4,2,3)")
+# C5 at its single-GPU size
+cfg5 = bench.CONFIGS["c5"]
+hbm_report("c5_whole", "fetch_c5w", "write_c5w", cfg5["kernel"], "--config c5 --batch 65536 --steps 1 --warmup 0 --no-cpu-baseline",
+           {"batch": 65536, "nt": cfg5["shape"][1], "nx": cfg5["shape"][2], "ny": 0}, cfg5["bpc"] * 65536 * cfg5["shape"][1] * cfg5["shape"][2],
+           note=" [65536, 200, 512]")
 for c in ("c2", "c5"):
     cfg = bench.CONFIGS[c]
     shp = cfg["shape"]

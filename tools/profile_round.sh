@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
 #   gpurun --timeout 1100 -- 'bash tools/profile_round.sh'
-# then   python tools/distill_profiles.py r05   turns gpurun_out/prof/* into profiles/r04/*.
+# then   python tools/distill_profiles.py r06   turns gpurun_out/prof/* into profiles/r06/*.
 # Trace and counter passes are separate runs (PMC is never combined with other trace domains).
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -28,6 +28,9 @@ run sq2      --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BA
 run sq1m     --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d "$P/sq1m" -- $B --steps 1 --warmup 0 --batch 1024 --mode marginal
 run sq2m     --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d "$P/sq2m" -- $B --steps 1 --warmup 0 --batch 1024 --mode marginal
 run fetchm   --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetchm" -- $B --steps 1 --warmup 0 --batch 1024 --mode marginal
+# C3 marginal at the full batch: HBM traffic of the residual kernel writing |res| into the row-padded score buffer
+run fetch_m  --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch_m" -- $B --steps 1 --warmup 0 --mode marginal
+run write_m  --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write_m" -- $B --steps 1 --warmup 0 --mode marginal
 fi
 if [ "$PART" != "a" ]; then
 for c in c2 c5; do
@@ -41,6 +44,16 @@ for e in induction continuity momentum energy gauss; do
     run fetch_c4_$e --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch_c4_$e" -- $B --config c4 --equation $e --steps 1 --warmup 0
     run write_c4_$e --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write_c4_$e" -- $B --config c4 --equation $e --steps 1 --warmup 0
 done
+# C4 fed the reference callers' Nt-fastest views (Marginal/MHD_Residuals_CP.py:326-346): flat_march_kernel<...<3>>
+for e in induction momentum; do
+    run trace_c4_${e}_nt --kernel-trace --stats --output-format csv -d "$P/trace_c4_${e}_nt" -- $B --config c4 --equation $e --layout nt --steps 3 --warmup 1
+    run fetch_c4_${e}_nt --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch_c4_${e}_nt" -- $B --config c4 --equation $e --layout nt --steps 1 --warmup 0
+    run write_c4_${e}_nt --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write_c4_${e}_nt" -- $B --config c4 --equation $e --layout nt --steps 1 --warmup 0
+done
+# C5 at its single-GPU size [65536,200,512]
+run trace_c5w --kernel-trace --stats --output-format csv -d "$P/trace_c5w" -- $B --config c5 --batch 65536 --steps 3 --warmup 1
+run fetch_c5w --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch_c5w" -- $B --config c5 --batch 65536 --steps 1 --warmup 0
+run write_c5w --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write_c5w" -- $B --config c5 --batch 65536 --steps 1 --warmup 0
 # the six-field functors: instruction mix and waits
 for e in momentum energy; do
     run sq1_c4_$e --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d "$P/sq1_c4_$e" -- $B --config c4 --equation $e --steps 1 --warmup 0
