@@ -748,6 +748,10 @@ constexpr int FLAT_NT = 512, FLAT_H = 32;
 #define FLAT_NT_GAIN 8          // a narrower chunk must save this many per cent of a row's lanes to be taken (measured:
                                 // profiles/r06/flat_ab_chunk_width.txt - 4 chunks of 320 lost 7 % to 3 of 448 at Nt = 20, 256 wide)
 #endif
+#ifndef FLAT_Q4
+#define FLAT_Q4 0              // 1: a second instantiation for Ty % 4 == 0 without six of the eight row-end masks per field -
+                               // measured -0.2 ... -0.4 % (profiles/r06/flat_ab_q4.txt): not worth doubling the instantiations
+#endif
 #ifndef FLAT_SYNC
 #define FLAT_SYNC 0            // experiment: a bare s_barrier per plane in the kernels that stage nothing
 #endif
@@ -779,7 +783,9 @@ template <int F> struct FlatHalo {
     float e[F];      // unstaged fields: the y- cell of a wave's first lane / the y+ cell of its last lane
 };
 
-template <class Fn>
+// Q4 (experiment, -DFLAT_Q4=1): Ty is a multiple of 4 (Nt = 64, 40, 20, ...): a quad never straddles a row end, so only its
+// first cell can lack a y- neighbour and only its last a y+ one - six of the eight masks per field are gone.
+template <class Fn, bool Q4>
 __global__ void __launch_bounds__(FLAT_NT, MinWaves<Fn>::value)
 flat_march_kernel(const Geom g, const typename Fn::Params prm)
 {
@@ -819,8 +825,8 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
         int ph = m % Ty;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            lok[j] = ph != 0;
-            rok[j] = ph != Ty - 1;
+            lok[j] = (Q4 && j > 0) || ph != 0;
+            rok[j] = (Q4 && j < 3) || ph != Ty - 1;
             ph = ph + 1 == Ty ? 0 : ph + 1;
         }
     }
@@ -894,7 +900,7 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
             if (SX::has(i)) {
                 const int k = SX::slot(i);
                 const float *row = reinterpret_cast<const float *>(&lds[bi][k][0]) + 4 * (FLAT_H + q);      // my first cell
-                if ((Ty & 3) == 0) {                     // wave-uniform: the x neighbours are whole quads
+                if (Q4) {                                // the x neighbours are whole quads
                     n[i].xm = lds[bi][k][FLAT_H + q - (Ty >> 2)];
                     n[i].xp = lds[bi][k][FLAT_H + q + (Ty >> 2)];
                 } else if ((Ty & 1) == 0) {              // Ty = 10, 30, 50 (T_out of the reference scripts): 8-byte aligned pairs
@@ -915,8 +921,13 @@ flat_march_kernel(const Geom g, const typename Fn::Params prm)
                 lft = ledge ? hc.e[i] : lft;
                 rgt = redge ? hc.e[i] : rgt;
             }
-            n[i].ym = make_float4(lok[0] ? lft : 0.f, lok[1] ? C[i].x : 0.f, lok[2] ? C[i].y : 0.f, lok[3] ? C[i].z : 0.f);
-            n[i].yp = make_float4(rok[0] ? C[i].y : 0.f, rok[1] ? C[i].z : 0.f, rok[2] ? C[i].w : 0.f, rok[3] ? rgt : 0.f);
+            if constexpr (Q4) {
+                n[i].ym = make_float4(lok[0] ? lft : 0.f, C[i].x, C[i].y, C[i].z);
+                n[i].yp = make_float4(C[i].y, C[i].z, C[i].w, rok[3] ? rgt : 0.f);
+            } else {
+                n[i].ym = make_float4(lok[0] ? lft : 0.f, lok[1] ? C[i].x : 0.f, lok[2] ? C[i].y : 0.f, lok[3] ? C[i].z : 0.f);
+                n[i].yp = make_float4(rok[0] ? C[i].y : 0.f, rok[1] ? C[i].z : 0.f, rok[2] ? C[i].w : 0.f, rok[3] ? rgt : 0.f);
+            }
         }
         float4 r = Fn::eval(n, prm);
         if (g.flags & PRE_FLAG_ABS) r = fabs4(r);
@@ -957,14 +968,17 @@ int launch_flat(Geom &g, const typename Fn::Params &prm, hipStream_t st)
         if ((quads + c - 1) / c * (c + halo) * 100 < (quads + nt - 1) / nt * (nt + halo) * (100 - FLAT_NT_GAIN)) nt = c;
     g.nYT = (int)((quads + nt - 1) / nt);
     long long tiles = (long long)g.B * g.nYT;
-    static int per_cu[FLAT_NT / 64 + 1] = {};                                 // (by chunk width; 0 = not asked yet)
-    if (!per_cu[nt / 64]) per_cu[nt / 64] = resident_per_cu(flat_march_kernel<Fn>, nt);
-    const int tSeg = pick_tseg(tiles, g.T, (long long)per_cu[nt / 64] * chip_cus());
+    const bool q4 = FLAT_Q4 && (g.Y & 3) == 0;
+    static int per_cu[2][FLAT_NT / 64 + 1] = {};                              // (by form and chunk width; 0 = not asked yet)
+    if (!per_cu[q4][nt / 64])
+        per_cu[q4][nt / 64] = q4 ? resident_per_cu(flat_march_kernel<Fn, FLAT_Q4 != 0>, nt) : resident_per_cu(flat_march_kernel<Fn, false>, nt);
+    const int tSeg = pick_tseg(tiles, g.T, (long long)per_cu[q4][nt / 64] * chip_cus());
     g.tSeg = tSeg;
     g.nTSeg = (g.T + tSeg - 1) / tSeg;
     tiles *= g.nTSeg;
     if (tiles <= 0 || tiles * nt > 0xffffffffLL) return PRE_E_SHAPE;
-    hipLaunchKernelGGL((flat_march_kernel<Fn>), dim3((unsigned)tiles), dim3(nt), 0, st, g, prm);
+    if (q4) hipLaunchKernelGGL((flat_march_kernel<Fn, FLAT_Q4 != 0>), dim3((unsigned)tiles), dim3(nt), 0, st, g, prm);
+    else hipLaunchKernelGGL((flat_march_kernel<Fn, false>), dim3((unsigned)tiles), dim3(nt), 0, st, g, prm);
     PRE_LAUNCH_CHECK();
     return PRE_OK;
 }
