@@ -74,7 +74,12 @@ def upload_rows(host, device=None):
         return host.to(device or "cuda")
     buf = torch.empty(n * (M + PAD), dtype=torch.float32, device=device or "cuda")
     view = buf.as_strided((n, M), (M + PAD, 1))
-    view.copy_(host.reshape(n, M))                          # ONE strided H2D copy (hipMemcpy2D under torch)
+    flat = host.reshape(n, M)
+    # (torch stages a host -> strided-device copy through a dense device temporary of the copy's size: row blocks of at
+    # most 1 GiB keep that temporary small whatever the matrix - a 100 GB score matrix must not need 200 GB for a moment)
+    rows = max(1, (1 << 28) // M)
+    for r0 in range(0, n, rows):
+        view[r0:r0 + rows].copy_(flat[r0:r0 + rows])
     strides, acc = [], 1
     for d in reversed(host.shape[1:]):
         strides.append(acc)

@@ -32,7 +32,7 @@ def bench_line(log):
 
 CMDS = {"trace": ("c3_joint", "--no-secondary --no-parity --steps 3 --warmup 1"),
         "trace_m": ("c3_marginal", "--no-secondary --no-parity --steps 2 --warmup 1 --mode marginal"),
-        "trace_c2": ("c2", "--config c2 --steps 3 --warmup 1"), "trace_c5": ("c5", "--config c5 --steps 3 --warmup 1")}
+        "trace_c1": ("c1", "--config c1 --steps 3 --warmup 1"), "trace_c2": ("c2", "--config c2 --steps 3 --warmup 1"), "trace_c5": ("c5", "--config c5 --steps 3 --warmup 1")}
 EQS = ("induction", "continuity", "momentum", "energy", "gauss")
 for e in EQS:
     CMDS[f"trace_c4_{e}"] = (f"c4_{e}", f"--config c4 --equation {e} --steps 3 --warmup 1")
@@ -156,7 +156,7 @@ cfg5 = bench.CONFIGS["c5"]
 hbm_report("c5_whole", "fetch_c5w", "write_c5w", cfg5["kernel"], "--config c5 --batch 65536 --steps 1 --warmup 0 --no-cpu-baseline",
            {"batch": 65536, "nt": cfg5["shape"][1], "nx": cfg5["shape"][2], "ny": 0}, cfg5["bpc"] * 65536 * cfg5["shape"][1] * cfg5["shape"][2],
            note=" [65536, 200, 512]")
-for c in ("c2", "c5"):
+for c in ("c1", "c2", "c5"):
     cfg = bench.CONFIGS[c]
     shp = cfg["shape"]
     cells = 1

@@ -6,8 +6,8 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 P=$R/gpurun_out/prof
-PART=${PART:-all}       # a: the C3 passes, b: the other configs (a gpurun call is at most 20 minutes: run the two apart)
-[ "$PART" != "b" ] && rm -rf "$P"
+PART=${PART:-all}       # a: the C3 passes, b: the other configs (a gpurun call is at most 20 minutes: run the two apart), c1: C1 alone
+[ "$PART" != "b" ] && [ "$PART" != "c1" ] && rm -rf "$P"
 mkdir -p "$P"
 cd /tmp && export TMPDIR=/tmp
 run() {  # tag, rocprof args..., -- bench args
@@ -32,8 +32,15 @@ run fetchm   --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetchm" 
 run fetch_m  --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch_m" -- $B --steps 1 --warmup 0 --mode marginal
 run write_m  --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write_m" -- $B --steps 1 --warmup 0 --mode marginal
 fi
+if [ "$PART" = "c1" ]; then
+    c=c1
+    run trace_$c --kernel-trace --stats --output-format csv -d "$P/trace_$c" -- $B --config $c --steps 3 --warmup 1
+    run fetch_$c --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch_$c" -- $B --config $c --steps 1 --warmup 0
+    run write_$c --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write_$c" -- $B --config $c --steps 1 --warmup 0
+    echo done >&2; exit 0
+fi
 if [ "$PART" != "a" ]; then
-for c in c2 c5; do
+for c in c1 c2 c5; do
     run trace_$c --kernel-trace --stats --output-format csv -d "$P/trace_$c" -- $B --config $c --steps 3 --warmup 1
     run fetch_$c --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$P/fetch_$c" -- $B --config $c --steps 1 --warmup 0
     run write_$c --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$P/write_$c" -- $B --config $c --steps 1 --warmup 0
