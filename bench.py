@@ -492,7 +492,7 @@ def summary_of(out):
     worst tensor-scale relative error of the checked samples]} for the headline and every secondary, compact (3 significant
     digits) - the last key of the line.  Short keys: c4_<equation> = the C4 shard's joint-CP job per equation (c4_ind =
     `c4_shard`), *_nt = the same fed the reference callers' Nt-fastest views, c4_marg = `c4_marginal_rank8` (kernel + select
-    at n = 8192), r8 = `c3_strong_rank8`."""
+    at n = 8192), r8 = `c3_strong_rank8`, *_g = the launch-bound step as one HIP graph replay ([ms])."""
     def r3(x):
         return None if x is None else float(f"{x:.3g}")
 
@@ -513,6 +513,8 @@ def summary_of(out):
                     s[tag + ("_j" if mode == "joint" else "_m")] = [r3(e[mode]["ms_per_step"]), r3(e[mode]["frac"]), par(e)]
         elif key in short:
             s[short[key]] = [r3(e.get("ms_per_step")), r3(e.get("frac")), par(e)]
+        elif key.endswith("_graph"):                     # the step as ONE HIP graph replay: [ms], equal to the eager step or "differs"
+            s[key.replace("_graph", "_g")] = [r3(e.get("ms_per_step_graph"))] if e.get("replay_equals_eager") else "differs"
     return s
 
 
@@ -551,20 +553,42 @@ def measure_others(dev):
     return found
 
 
-def measure_c1_graph(dev, reps=200):
-    """C1 is launch-bound (a 40 us kernel + a 40 us select behind ~10 host launches): the same step - fused residual with
-    the |.| epilogue -> per-cell q-hat at the 10 levels - recorded ONCE into a HIP graph and replayed
-    (tests/test_gpu_parity.py::test_marginal_step_is_hip_graph_capturable checks a replay against an eager run)."""
+def measure_graph(dev, name, reps=None):
+    """The launch-bound configs as ONE HIP graph replay per step.  C1 (a 40 us kernel + a 40 us select behind ~10 host
+    launches), C2 (1.6 ms + 1.1 ms) and the C5 shard (1.3 ms + six calibration launches of 0.01-0.6 ms): the same step as the
+    eager secondary - fused residual -> calibration at the 10 levels - recorded ONCE and replayed; the library never
+    allocates, synchronises or reads device data on the host path, and the joint stream takes the fixed branch-and-bound
+    route (`prune="always"`: no counter is read back).  A replay is checked against an eager run
+    (tests/test_gpu_parity.py::test_marginal_step_is_hip_graph_capturable, ::test_joint_stream_is_hip_graph_capturable_...)."""
     from cp_pre_amd import inductive_cp as icp
     from cp_pre_amd import pipeline
     from cp_pre_amd import residuals as R
-    B, T, X = CONFIGS["c1"]["shape"]
+    shp = CONFIGS[name]["shape"]
     alphas = [float(a) for a in icp.ALPHA_LEVELS]
-    u = synth_(torch.empty(B, T, X, device=dev), 1) + 1.0
-    op = R.Advection(1.0, 0.005, 0.01, disc=2)
+    cells = 1
+    for d in shp:
+        cells *= d
+    if name == "c1":
+        u = synth_(torch.empty(*shp, device=dev), 1) + 1.0
+        op = R.Advection(1.0, 0.005, 0.01, disc=2)
+        step = lambda: pipeline.marginal_qhat(op.residual(u, boundary=True, absolute=True), alphas)
+        what = "marginal step (residual + per-cell q-hat x10)"
+    elif name == "c2":
+        u = synth_(torch.empty(*shp, device=dev), 2)
+        op = R.PRE_Wave(dt=0.005, dx=0.01, c=1.0)
+        wout = pipeline.row_padded(shp[0], shp[1:], device=dev)
+        step = lambda: pipeline.marginal_qhat(op.residual(u, boundary=True, absolute=True, out=wout), alphas)
+        what = "marginal step (residual + per-cell q-hat x10)"
+    else:
+        u = synth_(torch.empty(*shp, device=dev), 1) + 1.0
+        op = R.Burgers(2.0 / shp[2], 1.25 / shp[1], 0.002)
 
-    def step():
-        return pipeline.marginal_qhat(op.residual(u, boundary=True, absolute=True), alphas)
+        def step():
+            jc = pipeline.JointCalibration(shp[0], dev, prune="always")
+            jc.add_slab(op.residual(u, boundary=True).unsqueeze(1), crop=(0, 1, 1))
+            return jc.finish(alphas)
+        what = "joint step (residual + moments + modulation + branch-and-bound scores + q-hat x10)"
+    reps = reps or (200 if name == "c1" else 30)
 
     def timed(fn, n):
         fn()
@@ -589,8 +613,8 @@ def measure_c1_graph(dev, reps=200):
     torch.cuda.synchronize()
     same = bool(torch.equal(q, step()))
     replay = timed(graph.replay, reps)
-    return {"workload": f"C1 [{B},{T},{X}] marginal step (residual + per-cell q-hat x10) as ONE HIP graph replay", "steps": reps,
-            "ms_per_step_eager": eager, "ms_per_step_graph": replay, "cells_per_s_graph": B * T * X / (replay * 1e-3),
+    return {"workload": f"{name.upper()} {list(shp)} {what} as ONE HIP graph replay", "steps": reps,
+            "ms_per_step_eager": eager, "ms_per_step_graph": replay, "cells_per_s_graph": cells / (replay * 1e-3),
             "replay_equals_eager": same}
 
 
@@ -1246,11 +1270,16 @@ def main():
                     sec[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 torch.cuda.empty_cache()
             sec.update(measure_others(dev))
-            try:                                                  # (last: a capture that fails must not cost the others)
-                note("secondary c1_graph")
-                sec["c1_graph"] = measure_c1_graph(dev)
-            except Exception as e:
-                sec["c1_graph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            for gname in ("c1", "c2", "c5"):                      # (last: a capture that fails must not cost the others)
+                try:
+                    note(f"secondary {gname}_graph")
+                    sec[gname + "_graph"] = measure_graph(dev, gname)
+                    if not sec[gname + "_graph"]["replay_equals_eager"]:
+                        note(f"GRAPH REPLAY DIFFERS from the eager step in {gname}_graph")
+                        code = 3
+                except Exception as e:
+                    sec[gname + "_graph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                torch.cuda.empty_cache()
             out["secondary"] = sec
             # a secondary whose residual missed the oracle (or whose q-hat cells missed their sorted columns) fails the run
             for key, e in sec.items():
