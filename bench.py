@@ -505,7 +505,7 @@ def summary_of(out):
              "c5_shard": "c5", "c5_whole": "c5_whole", "c1": "c1", "c2": "c2"}
     for key, e in (out.get("secondary") or {}).items():
         if not isinstance(e, dict) or "error" in e:
-            s[short.get(key, key)] = "error"
+            s[short.get(key, key.replace("_graph", "_g"))] = "error"
         elif key in ("c3_strong_rank8", "c3_rank8_ntfast"):
             tag = "c3_r8" if key == "c3_strong_rank8" else "c3_r8_nt"
             for mode in ("joint", "marginal"):

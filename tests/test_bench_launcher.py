@@ -37,6 +37,43 @@ def test_split_slabs():
             assert sum(parts) == nt and max(parts) <= s and max(parts) - min(parts) <= 1
 
 
+def test_summary_is_compact_and_complete():
+    """`summary` - the LAST key of the line - must show [ms, roofline fraction, oracle parity] of the headline and of every
+    secondary in well under 1 KB (a record that keeps only the tail of the line still shows every config), flag a
+    secondary that failed, and say "differs" when a graph replay did not reproduce its eager step."""
+    sec = {"c3_marginal": {"ms_per_step": 265.9031, "frac": 0.72118, "parity": {"residual_rel_err": 1.2204995e-07}},
+           "c3_strong_rank8": {"joint": {"ms_per_step": 30.2199, "frac": 0.71955}, "marginal": {"ms_per_step": 32.0178, "frac": 0.72692},
+                               "parity": {"residual_rel_err": 1.2048e-07}},
+           "c3_rank8_ntfast": {"joint": {"ms_per_step": 31.9668, "frac": 0.70617}, "marginal": {"ms_per_step": 34.0884, "frac": 0.66932},
+                               "parity": {"residual_rel_err": 1.2086e-07}},
+           "c4_marginal_rank8": {"ms_per_step": 20.367, "frac": 0.712, "parity": {"residual_rel_err": 2.328e-07}},
+           "c4_marginal_rank8_ntfast": {"ms_per_step": 20.553, "frac": 0.694, "parity": {"residual_rel_err": 1.7517e-07}},
+           "c1": {"ms_per_step": 0.0927, "frac": 0.11, "parity": {"residual_rel_err": 0.0}},
+           "c2": {"ms_per_step": 2.91, "frac": 0.67, "parity": {"residual_rel_err": 0.0}},
+           "c4_shard": {"ms_per_step": 18.9, "frac": 0.706, "parity": {"residual_rel_err": 2.33e-07}},
+           "c4_continuity": {"error": "RuntimeError: boom"},
+           "c4_momentum": {"ms_per_step": 25.1, "frac": 0.688, "parity": {"residual_rel_err": 1.38e-07}},
+           "c4_energy": {"ms_per_step": 28.7, "frac": 0.688, "parity": {"residual_rel_err": 1.81e-07}},
+           "c4_gauss": {"ms_per_step": 12.8, "frac": 0.71, "parity": {"residual_rel_err": 0.0}},
+           "c4_shard_ntfast": {"ms_per_step": 18.6, "frac": 0.703, "parity": {"residual_rel_err": 1.75e-07}},
+           "c5_shard": {"ms_per_step": 2.23, "frac": 0.694, "parity": {"residual_rel_err": 5.7e-08}},
+           "c5_whole": {"ms_per_step": 15.8, "frac": 0.722, "parity": {"residual_rel_err": 1.13e-07}},
+           "c1_graph": {"ms_per_step_graph": 0.03706, "replay_equals_eager": True},
+           "c2_graph": {"ms_per_step_graph": 2.4474, "replay_equals_eager": False},
+           "c5_graph": {"error": "capture failed"}}
+    out = {"ms_per_step": 242.78265, "roofline": {"frac": 0.7189119}, "parity": {"residual_rel_err": 1.22e-07}, "secondary": sec}
+    s = bench.summary_of(out)
+    text = json.dumps(s)
+    assert len(text) < 1000, len(text)
+    assert s["c3"] == [243.0, 0.719, 1.22e-07] and s["c3_marg"] == [266.0, 0.721, 1.22e-07]
+    assert s["c3_r8_j"][:2] == [30.2, 0.72] and s["c3_r8_nt_m"][:2] == [34.1, 0.669] and s["c4_marg_nt"][0] == 20.6
+    assert s["c4_cont"] == "error" and s["c5_g"] == "error" and s["c2_g"] == "differs" and s["c1_g"] == [0.0371]
+    for key in ("c1", "c2", "c4_ind", "c4_mom", "c4_en", "c4_gauss", "c4_ind_nt", "c4_marg", "c5", "c5_whole"):
+        assert len(s[key]) == 3, key
+    assert bench.summary_of({"ms_per_step": 1.0, "roofline": {"frac": 0.5}}) == {"c3": [1.0, 0.5, None]}     # N > 1: no secondaries
+    assert bench.med([3.0, 1.0, 47.0, 2.0, 2.5]) == 2.5 and bench.med([1.0, 3.0]) == 2.0
+
+
 def _run(argv, env_extra=None, timeout=240):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(env_extra or {})
