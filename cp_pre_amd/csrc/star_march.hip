@@ -17,6 +17,7 @@
 // taken from the caller's dense 3x3x3 kernels, so the reference's kernel-construction
 // quirks are inherited (see include/cp_pre_hip.h).
 #include "common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -969,10 +970,14 @@ int launch_flat(Geom &g, const typename Fn::Params &prm, hipStream_t st)
     g.nYT = (int)((quads + nt - 1) / nt);
     long long tiles = (long long)g.B * g.nYT;
     const bool q4 = FLAT_Q4 && (g.Y & 3) == 0;
-    static int per_cu[2][FLAT_NT / 64 + 1] = {};                              // (by form and chunk width; 0 = not asked yet)
-    if (!per_cu[q4][nt / 64])
-        per_cu[q4][nt / 64] = q4 ? resident_per_cu(flat_march_kernel<Fn, FLAT_Q4 != 0>, nt) : resident_per_cu(flat_march_kernel<Fn, false>, nt);
-    const int tSeg = pick_tseg(tiles, g.T, (long long)per_cu[q4][nt / 64] * chip_cus());
+    // (by form and chunk width; 0 = not asked yet.  Host threads may race to fill a slot: they write the same value)
+    static std::atomic<int> per_cu[2][FLAT_NT / 64 + 1] = {};
+    int occ = per_cu[q4][nt / 64].load(std::memory_order_relaxed);
+    if (!occ) {
+        occ = q4 ? resident_per_cu(flat_march_kernel<Fn, FLAT_Q4 != 0>, nt) : resident_per_cu(flat_march_kernel<Fn, false>, nt);
+        per_cu[q4][nt / 64].store(occ, std::memory_order_relaxed);
+    }
+    const int tSeg = pick_tseg(tiles, g.T, (long long)occ * chip_cus());
     g.tSeg = tSeg;
     g.nTSeg = (g.T + tSeg - 1) / tSeg;
     tiles *= g.nTSeg;

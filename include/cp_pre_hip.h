@@ -11,7 +11,8 @@
  *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued
  *     asynchronously on it, nothing synchronises, nothing allocates;
  *   - return value: 0 = ok, <0 = argument error (PRE_E_*), >0 = hipError_t;
- *   - no global state, re-entrant, host-thread-safe.
+ *   - no mutable global state (two device properties are cached on first use, read-only afterwards: the CU count and each
+ *     marching kernel's resident workgroups per CU, which size its t segments), re-entrant, host-thread-safe.
  */
 #ifndef CP_PRE_HIP_H
 #define CP_PRE_HIP_H
