@@ -346,6 +346,10 @@ __device__ __forceinline__ float wave_max(float v)
 // that can raise the maximum pay for the exact divide, and the result is bit-identical to
 // dividing everything.
 constexpr int JS_RB = 32;
+#ifndef JS_TARGET_CELLS
+#define JS_TARGET_CELLS 65536    // cells a block of the full score pass takes at least (spans of JS_RB rows; round 6: 8192 ->
+                                 // 65536, -5 ... -11 % on every shape of profiles/r06/score_pass_block_ab.txt: 32 KB blocks were too short-lived)
+#endif
 // NaN: np.max propagates it.  A NaN residual or modulation fails `av <= thr*sv` and reaches the divide; 0/0 (a
 // constant cell: modulation 0 and residual 0) reaches it through `sv == 0`; a NaN quotient sets the sticky flag and
 // the sample's score becomes NaN.
@@ -989,9 +993,9 @@ static int joint_score_launch(const float *a, const float *b, const float *mod, 
             return PRE_OK;
         }
     }
-    // spans of JS_RB rows; a block takes as many as give it >= ~8 k cells (but leaves >= ~2 k blocks when possible)
+    // spans of JS_RB rows; a block takes as many as give it >= JS_TARGET_CELLS cells (but leaves >= ~2 k blocks when possible)
     const long long spans = (T * X + JS_RB - 1) / JS_RB;
-    long long groups = 8192 / (JS_RB * Y);
+    long long groups = JS_TARGET_CELLS / (JS_RB * Y);
     if (groups < 1) groups = 1;
     while (groups > 1 && (spans / groups) * n < 2048) groups /= 2;
     const long long chunks = (spans + groups - 1) / groups;
