@@ -381,6 +381,9 @@ struct NoBC {};
 #ifndef MARCH6_MINW
 #define MARCH6_MINW 1
 #endif
+#ifndef MARCH1_TSEG
+#define MARCH1_TSEG 8          // planes per march of a one-field functor on batched 3-D fields with T >= 32 (0: pick_tseg alone)
+#endif
 #ifndef MARCH6_AHEAD
 #define MARCH6_AHEAD 2          // 3: the functors of five or more fields request their own cells three planes ahead
 #endif
@@ -715,7 +718,13 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const 
     // the 2-plane window prologue too often (pick_tseg)
     long long tiles = (long long)g.B * g.nXT * g.nYT;
     static const int per_cu = resident_per_cu(march_kernel<Fn, NR, TYQ, BC>, NR * TYQ);
-    const int tSeg = pick_tseg(tiles, g.T, (long long)per_cu * chip_cus());
+    int tSeg = pick_tseg(tiles, g.T, (long long)per_cu * chip_cus());
+    // One-field functors on batched 3-D fields (the wave / single-operator stencils: 1R + 1W) run 3-4 % faster as marches of 8
+    // planes than of the whole T axis - more, shorter workgroups keep the chip's reads in a narrower band of each array, and
+    // the three planes a segment reads for nothing are its neighbour's own, met in L2 (profiles/r06/march_ab_one_field_tseg.txt:
+    // [512,32,256,256] 5.43 -> 5.60 TB/s, [1024,64,256,256] 5.52 -> 5.75; T = 10 loses, 4 planes lose on 512-wide grids; the
+    // probe without a window prologue: 1 + 1 streams 5.32 -> 6.09 TB/s at 2 planes, 6 + 1 streams +1.8 % at best).
+    if (MARCH1_TSEG > 0 && Fn::F == 1 && g.B > 1 && g.T >= 4 * MARCH1_TSEG && tSeg > MARCH1_TSEG) tSeg = MARCH1_TSEG;
     g.tSeg = tSeg;
     g.nTSeg = (g.T + tSeg - 1) / tSeg;
     tiles *= g.nTSeg;

@@ -35,7 +35,9 @@ __global__ void fill_kernel(float *p, size_t n)
     }
 }
 
-template <int F, int D, int LDSB>
+// TS: planes a workgroup marches (0 = the whole T axis); the t segments of a sample are dealt like the product's: for each sample,
+// for each segment, all its tiles
+template <int F, int D, int LDSB, int TS = 0>
 __global__ void __launch_bounds__(512) stream_kernel(const float *in, float *out, int T, int X, int Y, long long sF, long long sB,
                                                      long long plane, long long oB)
 {
@@ -44,8 +46,11 @@ __global__ void __launch_bounds__(512) stream_kernel(const float *in, float *out
     const int nXT = X / 8, nYT = Y / 256;
     unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int yt = L % nYT; L /= nYT;
-    const int xt = L % nXT;
-    const int b = L / nXT;
+    const int xt = L % nXT; L /= nXT;
+    const int nseg = TS ? (T + TS - 1) / TS : 1;
+    const int ts = L % nseg;
+    const int b = L / nseg;
+    const int tb = TS ? ts * TS : 0, te = TS ? (tb + TS < T ? tb + TS : T) : T;
     const int x = xt * 8 + ty, y = (yt * 64 + q) * 4;
     pad[ty * 64 + q] = (float)x;                                  // (keeps the allocation alive)
     const unsigned voff = (unsigned)((x * Y + y) * 4);
@@ -55,7 +60,7 @@ __global__ void __launch_bounds__(512) stream_kernel(const float *in, float *out
     };
     float4 w[D + 1][F];
     auto load = [&](int t, float4(&dst)[F]) __attribute__((always_inline)) {
-        if (t < T) {
+        if (t < te) {
 #pragma unroll
             for (int i = 0; i < F; ++i) {
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc(i, t), (int)voff, 0, 0);
@@ -64,13 +69,13 @@ __global__ void __launch_bounds__(512) stream_kernel(const float *in, float *out
         }
     };
 #pragma unroll
-    for (int s = 0; s < D; ++s) load(s, w[s]);
+    for (int s = 0; s < D; ++s) load(tb + s, w[s]);
     float *op = out + (long long)b * oB + (long long)x * Y + y;
-    for (int t0 = 0; t0 < T; t0 += D + 1) {
+    for (int t0 = tb; t0 < te; t0 += D + 1) {
 #pragma unroll
         for (int s = 0; s <= D; ++s) {
             const int t = t0 + s;
-            if (t >= T) break;
+            if (t >= te) break;
             load(t + D, w[(s + D) % (D + 1)]);
             float4 r = w[s][0];
 #pragma unroll
@@ -83,7 +88,7 @@ __global__ void __launch_bounds__(512) stream_kernel(const float *in, float *out
 
 // padP / padF / padB: floats added to the plane / field / sample stride of the INPUT (0 = the dense [B,F,T,X,Y] tensor the
 // reference's `vars` is); padO: floats added to the sample stride of the output
-template <int F, int D, int LDSB>
+template <int F, int D, int LDSB, int TS = 0>
 void run(const float *in, float *out, int B, int T, int X, int Y, int Ftot, long long padP = 0, long long padF = 0, long long padB = 0,
          long long padO = 0)
 {
@@ -97,16 +102,16 @@ void run(const float *in, float *out, int B, int T, int X, int Y, int Ftot, long
         printf("F = %d, pads plane %lld field %lld sample %lld out %lld: does not fit the buffers, skipped\n", F, padP, padF, padB, padO);
         return;
     }
-    const unsigned grid = (unsigned)((long long)B * (X / 8) * (Y / 256));
+    const unsigned grid = (unsigned)((long long)B * (X / 8) * (Y / 256) * (TS ? (T + TS - 1) / TS : 1));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     int per_cu = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel<F, D, LDSB>, 512, 0));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel<F, D, LDSB, TS>, 512, 0));
     float best = 1e30f, sum = 0.f;
     const int reps = 5;
     for (int r = 0; r < reps + 1; ++r) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((stream_kernel<F, D, LDSB>), dim3(grid), dim3(64, 8), 0, 0, in, out, T, X, Y, sF, sB, plane, oB);
+        hipLaunchKernelGGL((stream_kernel<F, D, LDSB, TS>), dim3(grid), dim3(64, 8), 0, 0, in, out, T, X, Y, sF, sB, plane, oB);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -114,9 +119,9 @@ void run(const float *in, float *out, int B, int T, int X, int Y, int Ftot, long
         if (r) { sum += ms; best = ms < best ? ms : best; }
     }
     const double bytes = 4.0 * (F + 1) * B * T * (double)X * Y;
-    printf("F = %d + 1 streams, prefetch %d, %3d KB LDS -> %d wg/CU, pads plane %lld field %lld sample %lld out %lld floats: "
+    printf("F = %d + 1 streams, prefetch %d, %3d KB LDS -> %d wg/CU, %d planes per workgroup, pads plane %lld field %lld sample %lld out %lld floats: "
            "%7.3f ms mean (%7.3f best)  %6.0f GB/s = %.3f of 8 TB/s\n",
-           F, D, LDSB / 1024, per_cu, padP, padF, padB, padO, sum / reps, best, bytes / (sum / reps) / 1e6, bytes / (sum / reps) / 1e6 / 8000.0);
+           F, D, LDSB / 1024, per_cu, TS ? TS : T, padP, padF, padB, padO, sum / reps, best, bytes / (sum / reps) / 1e6, bytes / (sum / reps) / 1e6 / 8000.0);
     fflush(stdout);
 }
 
@@ -135,6 +140,23 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
     printf("fields [%d,%d,%d,%d,%d] fp32, output [%d,%d,%d,%d]; tile 8 x 256 cells per 512-thread workgroup, T marched\n",
            B, Ftot, T, X, Y, B, T, X, Y);
+    if (argc > 1 && argv[1][0] == 't') {      // the segment experiment: shorter marches = more, shorter workgroups in dispatch order
+        for (int rep = 0; rep < 2; ++rep) {
+            run<6, 2, 100 * 1024, 0>(in, out, B, T, X, Y, Ftot);
+            run<6, 2, 100 * 1024, 32>(in, out, B, T, X, Y, Ftot);
+            run<6, 2, 100 * 1024, 16>(in, out, B, T, X, Y, Ftot);
+            run<6, 2, 100 * 1024, 8>(in, out, B, T, X, Y, Ftot);
+            run<6, 2, 100 * 1024, 4>(in, out, B, T, X, Y, Ftot);
+            run<3, 2, 50 * 1024, 0>(in, out, B, T, X, Y, Ftot);
+            run<3, 2, 50 * 1024, 16>(in, out, B, T, X, Y, Ftot);
+            run<3, 2, 50 * 1024, 8>(in, out, B, T, X, Y, Ftot);
+            run<3, 2, 50 * 1024, 4>(in, out, B, T, X, Y, Ftot);
+            run<1, 2, 50 * 1024, 0>(in, out, B, T, X, Y, Ftot);
+            run<1, 2, 50 * 1024, 8>(in, out, B, T, X, Y, Ftot);
+            run<1, 2, 50 * 1024, 2>(in, out, B, T, X, Y, Ftot);
+        }
+        return 0;
+    }
     if (argc > 1) {            // the stride experiment: do power-of-two plane / field / sample strides cost these streams anything?
         for (int rep = 0; rep < 2; ++rep) {
             run<6, 2, 100 * 1024>(in, out, B, T, X, Y, Ftot);

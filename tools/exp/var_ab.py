@@ -38,7 +38,7 @@ def main():
         libs[n] = handle(os.path.abspath(p))
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
-    bpc = {"momentum": 28, "energy": 28, "continuity": 16, "induction": 20, "ns": 16}
+    bpc = {"momentum": 28, "energy": 28, "continuity": 16, "induction": 20, "ns": 16, "wave": 8}
     for shp in args.shapes.split(","):
         B, T, X, Y = (int(v) for v in shp.split("x"))
         if args.layout == "nt":
@@ -48,7 +48,9 @@ def main():
         mhd, ns = R.MHD(), R.NavierStokes(1e-2, 1.0 / X, 1.0 / Y)
         cells = B * T * X * Y
         for eq in args.eqs.split(","):
+            wave = R.PRE_Wave(dt=0.005, dx=0.01, c=1.0)
             fn = (lambda: ns.residual_momentum(w[:, :3], boundary=True)) if eq == "ns" else \
+                 (lambda: wave.residual(w[:, 0], boundary=True)) if eq == "wave" else \
                  (lambda eq=eq: getattr(mhd, "residual_" + eq)(w, boundary=True))
             times = {n: [] for n in names}
             ref = None
