@@ -35,6 +35,7 @@ struct Geom {
     int tSeg, nTSeg, nXT, nYT;
     int flags;
     int flat;                    // 1: short contiguous axis merged with the next one (flat_march_kernel)
+    int tfree;                   // 1: no operator of the functor has a tap along the marched axis (set by the entry points)
 };
 
 // c, t-, t+, x-, x+, y-, y+
@@ -384,6 +385,13 @@ struct NoBC {};
 #ifndef MARCH1_TSEG
 #define MARCH1_TSEG 8          // planes per march of a one-field functor on batched 3-D fields with T >= 32 (0: pick_tseg alone)
 #endif
+#ifndef TFREE_TSEG
+#define TFREE_TSEG 8            // planes per march when no operator has a tap along the marched axis (2: +5 ... +22 % slower, 4: mixed,
+                                // 8: -2 ... -10 % against pick_tseg's 32+: profiles/r06/march_ab_tfree_tseg.txt)
+#endif
+#ifndef MARCH1_ANYB
+#define MARCH1_ANYB 0
+#endif
 #ifndef MARCH6_AHEAD
 #define MARCH6_AHEAD 2          // 3: the functors of five or more fields request their own cells three planes ahead
 #endif
@@ -496,6 +504,10 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
     }
     float *outp = g.out + (long long)b * g.oB + (long long)x * g.oX + y;
     const long long oT = g.oT;
+    // the planes this workgroup may touch: all of them - or, when no operator has a tap along the marched axis (1-D residuals
+    // on [1,B,T,X], spatial operators, D_x / Laplacians on 3-D fields), its own segment only: a segment then costs no window
+    // prologue, and the host cuts the axis into marches of a few planes (TFREE_TSEG)
+    const int tlo = g.tfree ? t0 : 0, thi = g.tfree ? t1 : g.T;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto plane = [&](int i, int t) __attribute__((always_inline)) {
         const float *p = g.f[i] + ((long long)b * g.sB[i] - g.sX[i] + (long long)t * g.sT[i]);
@@ -503,7 +515,7 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
     };
 
     auto load_own = [&](int t, float4(&dst)[F]) __attribute__((always_inline)) {
-        const bool ok = ldown && (t >= 0) && (t < g.T);
+        const bool ok = ldown && (t >= tlo) && (t < thi);
 #pragma unroll
         for (int i = 0; i < F; ++i) {
             if (ok) {
@@ -511,13 +523,13 @@ march_kernel(const Geom g, const typename Fn::Params prm, const typename std::co
                 dst[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
             } else {
                 dst[i] = f4(BC ? ghost : 0.f);
-                if (tailq && (t >= 0) && (t < g.T))
+                if (tailq && (t >= tlo) && (t < thi))
                     dst[i].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(plane(i, t), (int)voff[i], 0, 0));
             }
         }
     };
     auto load_halo = [&](int t, Halo<F, BC, COOP> &h) __attribute__((always_inline)) {
-        const bool okt = (t >= 0) && (t < g.T);
+        const bool okt = (t >= tlo) && (t < thi);
 #pragma unroll
         for (int i = 0; i < F; ++i) {
             if (!SX::has(i)) {                                   // no x-neighbours of this field are read: no halo row
@@ -724,7 +736,9 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const 
     // the three planes a segment reads for nothing are its neighbour's own, met in L2 (profiles/r06/march_ab_one_field_tseg.txt:
     // [512,32,256,256] 5.43 -> 5.60 TB/s, [1024,64,256,256] 5.52 -> 5.75; T = 10 loses, 4 planes lose on 512-wide grids; the
     // probe without a window prologue: 1 + 1 streams 5.32 -> 6.09 TB/s at 2 planes, 6 + 1 streams +1.8 % at best).
-    if (MARCH1_TSEG > 0 && Fn::F == 1 && g.B > 1 && g.T >= 4 * MARCH1_TSEG && tSeg > MARCH1_TSEG) tSeg = MARCH1_TSEG;
+    if (MARCH1_TSEG > 0 && Fn::F == 1 && (g.B > 1 || MARCH1_ANYB) && g.T >= 4 * MARCH1_TSEG && tSeg > MARCH1_TSEG) tSeg = MARCH1_TSEG;
+    // no tap along the marched axis: segments are free (the kernel loads its own planes only) - marches of TFREE_TSEG planes
+    if (TFREE_TSEG > 0 && g.tfree && tSeg > TFREE_TSEG) tSeg = TFREE_TSEG;
     g.tSeg = tSeg;
     g.nTSeg = (g.T + tSeg - 1) / tSeg;
     tiles *= g.nTSeg;
@@ -1063,6 +1077,7 @@ int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const
     bool flat = allow_flat && D[p[2]] < FLAT_MAX_Y && ostride(p[1]) == D[p[2]] && (D[p[1]] * D[p[2]]) % 4 == 0 && D[p[1]] > 1;
     for (int i = 0; i < nf; ++i) flat = flat && stride(fs[i], p[1]) == D[p[2]];
     g.flat = flat;
+    g.tfree = 0;
     if (!flat && (relaxed ? D[p[2]] < 4 : D[p[2]] % 4 != 0)) return PRE_E_UNSUPPORTED;
     for (int i = 0; i < nf; ++i) {
         g.f[i] = fs[i]->ptr; g.sB[i] = fs[i]->sB; g.sT[i] = stride(fs[i], p[0]); g.sX[i] = stride(fs[i], p[1]);
@@ -1094,6 +1109,15 @@ int prepare(Geom &g, int &relabeled, const pre_field_t *const *fs, int nf, const
 // every other permuted layout runs the general-star instantiation
 inline int relabeled_mode(int mode, int rel) { return rel == 0 ? mode : (rel == 1 && mode < 2 ? mode + 3 : 2); }
 
+// no operator has a tap along the kernel's marched axis (after prepare() has relabelled the stars): the marching kernel then
+// loads a segment's own planes only (Geom::tfree)
+inline int no_t_taps(Star *const *stars, int n)
+{
+    for (int k = 0; k < n; ++k)
+        if (stars[k]->tm != 0.f || stars[k]->tp != 0.f) return 0;
+    return 1;
+}
+
 template <template <int> class FnT, class P>
 int launch_mode(int mode, Geom &g, const P &prm, hipStream_t st)
 {
@@ -1123,6 +1147,7 @@ int pre_star_try_linear1(const pre_field_t *in, const pre_out_t *out, const floa
     int rc = prepare(g, rel, fs, 1, out, B, T, X, Y, flags, stars, 1, true);
     if (rc) return rc;
     *tail_axis = -1;
+    g.tfree = no_t_taps(stars, 1);
     if (g.Yc < g.Y && (flags & PRE_FLAG_HALO_X)) return PRE_E_UNSUPPORTED;      // (the tail pass pads x with zeros)
     if (g.Yc < g.Y) {
         *tail_axis = rel == 0 ? 2 : (rel == 1 ? 0 : 1);
@@ -1152,6 +1177,7 @@ int pre_residual_ns_momentum_f32(const pre_field_t *u, const pre_field_t *v, con
     int rc = prepare(g, rel, fs, 3, out, B, T, X, Y, flags, stars, 4);
     if (rc) return rc;
     prm.dxdy = dx * dy; prm.dtdy = dt * dy; prm.dtdx = dt * dx; prm.nudt = nu * dt;
+    g.tfree = no_t_taps(stars, 4);
     return launch_mode<NSMomentum>(relabeled_mode(mode, rel), g, prm, as_stream(stream));
 }
 
@@ -1169,6 +1195,7 @@ int pre_residual_linear2_f32(const pre_field_t *f0, const pre_field_t *f1, const
     int rc = prepare(g, rel, fs, 2, out, B, T, X, Y, flags, stars, 2);
     if (rc) return rc;
     prm.ratio = ratio;
+    g.tfree = no_t_taps(stars, 2);
     return launch<Linear2>(g, prm, as_stream(stream));
 }
 
@@ -1200,6 +1227,7 @@ int pre_residual_burgers_f32(const float *u, const int64_t in_strides[3], float 
     int rc = prepare(g, rel, fs, 1, &o, 1, B, T, X, flags, stars, 3);
     if (rc) return rc;
     prm.dx = dx; prm.dt = dt; prm.nu = nu; prm.c3 = c3;
+    g.tfree = no_t_taps(stars, 3);             // (always: the marched axis of [1,B,T,X] is the batch)
     return launch_mode<Burgers>(rel == 0 ? mode : (rel == 2 && mode == 0 ? 3 : 2), g, prm, as_stream(stream));
 }
 
@@ -1224,16 +1252,19 @@ int pre_residual_mhd_f32(int eq, const pre_field_t fields[6], const pre_out_t *o
         const pre_field_t *fs[3] = {all[0], all[1], all[2]};
         int rc = prepare(g, rel, fs, 3, out, B, T, X, Y, flags, stars, 3);
         if (rc) return rc;
+        g.tfree = no_t_taps(stars, 3);
         return launch_mode<MHDContinuity>(relabeled_mode(mode, rel), g, prm, st);
     }
     if (eq == 3) {
         const pre_field_t *fs[4] = {all[1], all[2], all[4], all[5]};
         int rc = prepare(g, rel, fs, 4, out, B, T, X, Y, flags, stars, 3);
         if (rc) return rc;
+        g.tfree = no_t_taps(stars, 3);
         return launch_mode<MHDInduction>(relabeled_mode(mode, rel), g, prm, st);
     }
     int rc = prepare(g, rel, all, 6, out, B, T, X, Y, flags, stars, 3);
     if (rc) return rc;
+    g.tfree = no_t_taps(stars, 3);
     if (eq == 1) return launch_mode<MHDMomentum>(relabeled_mode(mode, rel), g, prm, st);
     return launch_mode<MHDEnergy>(relabeled_mode(mode, rel), g, prm, st);
 }
@@ -1264,11 +1295,13 @@ int pre_residual_jorek_f32(int eq, const pre_field_t fields[3], const pre_field_
         const pre_field_t *fs[3] = {&fields[0], &fields[1], Rb};
         int rc = prepare(g, rel, fs, 3, out, B, T, X, Y, flags, stars, 5);
         if (rc) return rc;
+        g.tfree = no_t_taps(stars, 5);
         return launch_mode<JorekContinuity>(relabeled_mode(mode, rel), g, prm, st);
     }
     const pre_field_t *fs[4] = {&fields[0], &fields[1], &fields[2], Rb};
     int rc = prepare(g, rel, fs, 4, out, B, T, X, Y, flags, stars, 5);
     if (rc) return rc;
+    g.tfree = no_t_taps(stars, 5);
     return launch_mode<JorekTemperature>(relabeled_mode(mode, rel), g, prm, st);
 }
 
@@ -1324,6 +1357,7 @@ int pre_spatial2d_bc_f32(const float *in, const int64_t in_strides[3], float *ou
     int rel;
     rc = prepare(g, rel, fs, 1, &o, 1, B, X, Y, flags & ~PRE_FLAG_INTERIOR_T, nullptr, 0, false, false);
     if (rc) return rc;
+    g.tfree = 1;                               // (a 2-D operator: the marched axis is the batch of planes)
     return launch<Linear1, true>(g, prm, as_stream(stream), &info);
 }
 
@@ -1347,6 +1381,7 @@ int pre_spatial2d_linear2_bc_f32(const float *in0, const int64_t s0[3], const fl
     int rel;
     rc = prepare(g, rel, fs, 2, &o, 1, B, X, Y, flags & ~PRE_FLAG_INTERIOR_T, nullptr, 0, false, false);
     if (rc) return rc;
+    g.tfree = 1;
     return launch<Linear2, true>(g, prm, as_stream(stream), &info);
 }
 
