@@ -385,6 +385,9 @@ struct NoBC {};
 #ifndef MARCH1_TSEG
 #define MARCH1_TSEG 8          // planes per march of a one-field functor on batched 3-D fields with T >= 32 (0: pick_tseg alone)
 #endif
+#ifndef MARCHN_TSEG
+#define MARCHN_TSEG 0
+#endif
 #ifndef TFREE_TSEG
 #define TFREE_TSEG 8            // planes per march when no operator has a tap along the marched axis (2: +5 ... +22 % slower, 4: mixed,
                                 // 8: -2 ... -10 % against pick_tseg's 32+: profiles/r06/march_ab_tfree_tseg.txt)
@@ -739,6 +742,7 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const 
     if (MARCH1_TSEG > 0 && Fn::F == 1 && (g.B > 1 || MARCH1_ANYB) && g.T >= 4 * MARCH1_TSEG && tSeg > MARCH1_TSEG) tSeg = MARCH1_TSEG;
     // no tap along the marched axis: segments are free (the kernel loads its own planes only) - marches of TFREE_TSEG planes
     if (TFREE_TSEG > 0 && g.tfree && tSeg > TFREE_TSEG) tSeg = TFREE_TSEG;
+    if (MARCHN_TSEG > 0 && tSeg > MARCHN_TSEG) tSeg = MARCHN_TSEG;             // (experiment: a cap for every functor)
     g.tSeg = tSeg;
     g.nTSeg = (g.T + tSeg - 1) / tSeg;
     tiles *= g.nTSeg;
