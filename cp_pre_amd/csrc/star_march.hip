@@ -383,7 +383,8 @@ struct NoBC {};
 #define MARCH6_MINW 1
 #endif
 #ifndef MARCH1_TSEG
-#define MARCH1_TSEG 8          // planes per march of a one-field functor on batched 3-D fields with T >= 32 (0: pick_tseg alone)
+#define MARCH1_TSEG 0          // 8: marches of 8 planes for a one-field functor WITH t-taps on batched 3-D fields (T >= 32) - measured
+                               // -3 ... -4 % of the wave kernel's time for +10 % of fabric traffic (FETCH 1.007x -> 1.11x): not taken
 #endif
 #ifndef MARCHN_TSEG
 #define MARCHN_TSEG 0
@@ -734,11 +735,9 @@ int launch_tiled(Geom &g, const typename Fn::Params &prm, hipStream_t st, const 
     long long tiles = (long long)g.B * g.nXT * g.nYT;
     static const int per_cu = resident_per_cu(march_kernel<Fn, NR, TYQ, BC>, NR * TYQ);
     int tSeg = pick_tseg(tiles, g.T, (long long)per_cu * chip_cus());
-    // One-field functors on batched 3-D fields (the wave / single-operator stencils: 1R + 1W) run 3-4 % faster as marches of 8
-    // planes than of the whole T axis - more, shorter workgroups keep the chip's reads in a narrower band of each array, and
-    // the three planes a segment reads for nothing are its neighbour's own, met in L2 (profiles/r06/march_ab_one_field_tseg.txt:
-    // [512,32,256,256] 5.43 -> 5.60 TB/s, [1024,64,256,256] 5.52 -> 5.75; T = 10 loses, 4 planes lose on 512-wide grids; the
-    // probe without a window prologue: 1 + 1 streams 5.32 -> 6.09 TB/s at 2 planes, 6 + 1 streams +1.8 % at best).
+    // (experiment, off: one-field functors WITH t-taps on batched 3-D fields - the wave kernel - run 3-4 % faster as marches of
+    // 8 planes than of the whole T axis, profiles/r06/march_ab_one_field_tseg.txt, but the three planes a segment reads for
+    // nothing show up at the fabric: FETCH 1.007x -> 1.11x algorithmic.  The tap-free rule below has no such cost.)
     if (MARCH1_TSEG > 0 && Fn::F == 1 && (g.B > 1 || MARCH1_ANYB) && g.T >= 4 * MARCH1_TSEG && tSeg > MARCH1_TSEG) tSeg = MARCH1_TSEG;
     // no tap along the marched axis: segments are free (the kernel loads its own planes only) - marches of TFREE_TSEG planes
     if (TFREE_TSEG > 0 && g.tfree && tSeg > TFREE_TSEG) tSeg = TFREE_TSEG;
