@@ -111,6 +111,9 @@ __global__ void __launch_bounds__(256) moments_kernel(const float *__restrict__ 
 // maximum is a wave reduction and one store.  Per cell and split the samples are added in ascending order, as
 // moments_kernel does (the split counts differ, so the fp64 sums agree up to the order of the additions).
 constexpr int MS_TMAX = 16;
+#ifndef MS_WANT1
+#define MS_WANT1 1024           // blocks the many-plane moments pass wants at least (more = the batch axis split finer)
+#endif
 #ifndef MS_STAGE
 #define MS_STAGE 1
 #endif
@@ -966,7 +969,7 @@ int pre_moments_segmax_f64(const float *a, int64_t row_stride, int64_t n, int64_
     long long splits = 1;
     // (the few-plane forms run 8 waves per SIMD; the 1024-thread form one block per CU at a time: enough splits of the batch axis
     // that the last, partial round of blocks is a small share - 800 blocks on 256 CUs were 3.1 rounds, the fourth a quarter full)
-    const long long want = us == 16 ? 16384 : us > 1 ? 2048 : 1024;
+    const long long want = us == 16 ? 16384 : us > 1 ? 2048 : MS_WANT1;
     while (bx * (bt / 256) * TC * splits < want && splits * 32 * us < n) splits *= 2;
     const int rows = (int)((n + splits - 1) / splits);
     splits = (n + rows - 1) / rows;
