@@ -38,11 +38,15 @@ rank; strong: the --batch samples are split over the ranks.
 
 The default line (--config c3, joint, one GPU) also carries `secondary`: the other BASELINE configurations measured in
 the same process after the C3 joint job (whose number stays `value`) - C3 marginal on the same resident slab, the per-rank
-job of the strong-scaled 8-GPU curve ([512,64,512,512] x3 whole grid, joint and marginal, through a one-rank RCCL group), C1,
-C2, the C4 shard for each of its five equations, the C5 shard and C5 at its single-GPU size [65536,200,512] - 2 warm-up + 5
-steps each, so that every config's number is one the driver's own run produced (--no-secondary skips them) - and `parity`:
-after the timed region two samples of the last slab are re-evaluated by the CPU oracle (the checker, never the thing
-measured) and compared with what the HIP kernel left in the residual buffer; above 1e-5 the process exits non-zero.
+job of the strong-scaled 8-GPU curve ([512,64,512,512] x3 whole grid, joint and marginal, through a one-rank RCCL group) in
+the reference layout and in the reference callers' Nt-fastest layout (`c3_rank8_ntfast`), C4 the way its script runs it
+(`c4_marginal_rank8[_ntfast]`: |residual| written plane-major + ONE select at n = 8192), C1, C2, the C4 shard for each of its
+five equations and with Nt-fastest fields, the C5 shard, C5 at its single-GPU size [65536,200,512], and the launch-bound
+steps (C1, C2, C5 shard) as HIP graph replays - 2 warm-up + 5 steps each (the MEDIAN step), so that every config's number is
+one the driver's own run produced (--no-secondary skips them).  Every entry carries `parity`: after its timed loop two
+samples are re-evaluated by the CPU oracle (the checker, never the thing measured) and compared with what the HIP kernel
+wrote (marginal entries: three q-hat cells against torch.sort as well); above 1e-5 the process exits 3.  The LAST key of the
+line, `summary`, repeats [ms per step, roofline fraction, parity] of every config in ~0.7 KB.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (fused
 residual kernel, HIP events on its stream; `achieved` = SURVEY 8(d) bytes: 16 B x the interior
